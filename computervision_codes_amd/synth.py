@@ -1,0 +1,125 @@
+"""Deterministic synthetic weights and inputs.
+
+No checkpoints or datasets ship with the reference (`__checkpoint__/*/download_link.txt` are empty),
+so parity and benchmarks run on synthetic parameters.  Every tensor of a state dict is filled from a
+counter-based generator (splitmix64 of (seed, key index, element index)), so that the same state
+dict can be regenerated anywhere -- in the oracle harness that imports the reference, in the tests
+and on the GPU box -- without shipping 50-350 MB of weights.
+
+The fill rules keep activations O(1) through deep stacks and make BatchNorm folding non-trivial:
+  * ``running_var``                       U[0.5, 1.5]
+  * ``running_mean``                      U[-0.1, 0.1]
+  * ``num_batches_tracked`` / int buffers left untouched
+  * 1-D ``weight`` (BN / LN scale)        U[0.5, 1.5]
+  * ``bias`` and other 1-D tensors        U[-0.1, 0.1]
+  * >=2-D tensors                         U(-a, a), a = gain / sqrt(fan_in)
+    gain = sqrt(3) (unit variance per fan-in; keeps ResNet-50 features O(1..10)).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, Tuple
+
+import numpy as np
+import torch
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on a uint64 array (wrapping arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(seed: int, stream: int, n: int) -> np.ndarray:
+    """n doubles in [0,1): element i = splitmix64(splitmix64(seed, stream) + i) >> 11 / 2^53."""
+    base = _splitmix64(np.array([(seed * 0x100000001B3 + stream) & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0]
+    with np.errstate(over="ignore"):
+        ctr = (np.arange(n, dtype=np.uint64) + base) & _M64
+    bits = _splitmix64(ctr) >> np.uint64(11)
+    return bits.astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _range_for(name: str, shape: Tuple[int, ...]) -> Tuple[float, float]:
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "running_var":
+        return 0.5, 1.5
+    if leaf == "running_mean":
+        return -0.1, 0.1
+    if len(shape) <= 1:
+        if leaf == "weight":
+            return 0.5, 1.5
+        return -0.1, 0.1
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    if leaf == "relative_position_bias_table" or "query_embed" in name or leaf in ("W", "b", "pe"):
+        # lookup tables / per-class vectors: no fan-in meaning
+        a = 0.5 if leaf != "W" else math.sqrt(3.0 / shape[-1])
+        return -a, a
+    gain = math.sqrt(3.0)
+    a = gain / math.sqrt(max(fan_in, 1))
+    return -a, a
+
+
+def fill_state_dict(template: Dict[str, torch.Tensor], seed: int = 47) -> Dict[str, torch.Tensor]:
+    """Return a new state dict with every floating tensor of `template` refilled deterministically.
+
+    `template` only supplies names, order, shapes and dtypes (e.g. ``module.state_dict()`` or the
+    shape tables in ``computervision_codes_amd.shapes``).  Integer tensors are copied unchanged.
+    """
+    out: Dict[str, torch.Tensor] = {}
+    for ki, (name, t) in enumerate(template.items()):
+        if not torch.is_floating_point(t):
+            out[name] = t.clone()
+            continue
+        lo, hi = _range_for(name, tuple(t.shape))
+        u = uniform01(seed, ki, t.numel())
+        v = (lo + (hi - lo) * u).astype(np.float32).reshape(tuple(t.shape))
+        out[name] = torch.from_numpy(v).to(t.dtype)
+    return out
+
+
+def fill_from_shapes(shapes: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 47) -> Dict[str, torch.Tensor]:
+    """Same as `fill_state_dict` from an ordered (name, shape) list; int64 for *num_batches_tracked*
+    and *relative_position_index* entries is handled by the callers that need them."""
+    tmpl = {}
+    for name, shape in shapes:
+        if name.endswith("num_batches_tracked"):
+            tmpl[name] = torch.zeros((), dtype=torch.int64)
+        else:
+            tmpl[name] = torch.empty(shape, dtype=torch.float32)
+    return fill_state_dict(tmpl, seed)
+
+
+def synthetic_frames(batch: int, height: int = 224, width: int = 224, seed: int = 1234) -> torch.Tensor:
+    """uint8 frames [B,H,W,3], U{0..255}."""
+    u = uniform01(seed, 0xF00D, batch * height * width * 3)
+    return torch.from_numpy((u * 256.0).astype(np.uint8).reshape(batch, height, width, 3))
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def normalize_frames(frames_u8: torch.Tensor) -> torch.Tensor:
+    """ToTensor + Normalize as `Spatial_cnn/dataloader.py:153-162`: uint8 NHWC -> float32 NCHW."""
+    x = frames_u8.to(torch.float32).div(255.0).permute(0, 3, 1, 2)
+    mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, dtype=torch.float32).view(1, 3, 1, 1)
+    return ((x - mean) / std).contiguous()
+
+
+def synthetic_features(t: int, d: int, seed: int = 47) -> torch.Tensor:
+    """Frame features [1,T,D] ~ N(0,1) via Box-Muller on the counter stream."""
+    n = t * d
+    u1 = uniform01(seed, 0xFEA7, n)
+    u2 = uniform01(seed, 0xFEA8, n)
+    z = np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+    return torch.from_numpy(z.astype(np.float32).reshape(1, t, d))
