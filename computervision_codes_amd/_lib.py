@@ -1,0 +1,81 @@
+"""ctypes binding of libmt4hip.so (C-ABI declared in include/mt4hip.h).
+
+There is NO fallback: if the HIP library is missing or a symbol is absent, importing the product
+fails loudly.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C computervision_codes_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+# torch owns device memory and streams and ships its own libamdhip64; it must be loaded FIRST so that
+# libmt4hip.so binds to the same HIP runtime instance (a second runtime cannot see torch's allocations).
+import torch  # noqa: F401  (import order matters)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmt4hip.so")
+
+MT4_F32 = 0
+MT4_BF16 = 1
+
+
+class ConvDesc(C.Structure):
+    """mirror of `mt4_conv_desc` (include/mt4hip.h)"""
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32),
+        ("stride_h", C.c_int32), ("stride_w", C.c_int32),
+        ("pad_h", C.c_int32), ("pad_w", C.c_int32),
+        ("dil_h", C.c_int32), ("dil_w", C.c_int32),
+        ("relu", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile", C.c_int32),
+    ]
+
+
+_vp, _i32 = C.c_void_p, C.c_int32
+_FLOAT3 = C.c_float * 3
+
+# name -> (restype, argtypes); must list every symbol of include/mt4hip.h
+SIGNATURES = {
+    "mt4_abi_version": (C.c_int, []),
+    "mt4_strerror": (C.c_char_p, [C.c_int]),
+    "mt4_last_hip_error": (C.c_int, []),
+    "mt4_conv_nhwc": (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    "mt4_conv_tile_count": (C.c_int, []),
+    "mt4_conv_packed_k": (C.c_int64, [_i32, _i32, _i32, _i32]),
+    "mt4_pack_conv_weight": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_pack_stem_weight": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "mt4_preprocess_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _FLOAT3, _FLOAT3, _i32, _vp]),
+    "mt4_pad_nchw_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_maxpool3x3s2_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_global_avgpool_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_linear_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+}
+
+
+class Mt4Error(RuntimeError):
+    pass
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the MI355X HIP library is not built. "
+            "Run `make -C computervision_codes_amd/csrc` (needs hipcc); there is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = lib.mt4_strerror(code).decode()
+        raise Mt4Error(f"{what or 'mt4 call'} failed: {msg} (code {code}, hip error {lib.mt4_last_hip_error()})")

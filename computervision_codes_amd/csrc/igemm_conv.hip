@@ -1,0 +1,440 @@
+// Implicit-GEMM convolution for gfx950 (MI355X), channels-last, fp32 and bf16 on MFMA.
+//
+//   D[n][m] = sum_k Wp[n][k] * im2col(x)[m][k]      n = output channel, m = output pixel
+//
+// Both GEMM operands are K-contiguous: the packed weight row [Kpad] and, per kernel tap, the Cin run of
+// one input pixel.  A K-step is 128 bytes of K per row (8 chunks of 16 B = 32 fp32 or 64 bf16), so the
+// LDS image, the global->LDS staging and the b128 fragment reads are byte-identical for the two dtypes;
+// only the MFMA differs (fp32: 4 x v_mfma_f32_16x16x4_f32 per 16-B fragment pair, exact fp32 FMA chain;
+// bf16: 1 x v_mfma_f32_16x16x32_bf16).  The weight tile is the MFMA A operand and the pixel tile the B
+// operand, so an accumulator lane owns 4 CONSECUTIVE output channels of one pixel: the fused epilogue
+// (bias + residual + ReLU) loads/stores 16-B (fp32) or 8-B (bf16) vectors along the NHWC channel axis.
+//
+// LDS: [stage][row][8 chunks], chunk index XOR-swizzled with (row & 7): conflict-free for the 8-lane
+// ds_write_b128 groups (one 128-B row) and the 16-lane ds_read_b128 groups (16 rows x one chunk).
+// Tiles are dealt to XCDs in contiguous ranges (n-tile fastest), so all column tiles of a pixel tile hit
+// one XCD's L2 and activations are fetched from HBM once.
+#include "mt4_common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+struct ConvK {
+    const char* x;
+    const char* w;
+    const float* bias;
+    const char* res;
+    char* y;
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, sh, sw, ph, pw, dh, dw, relu;
+    int M, HoWo, CPT, SPT, taps, nsteps, n_tiles;
+    long long x_img_bytes;  // H*W*Cin*esize
+    int w_row_bytes;        // nsteps*128
+};
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool FAST, bool OUT_F32>
+__global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int ROWS = BM + BN;
+    constexpr int NLD = ROWS / 32;
+    constexpr int NLD_X = BM / 32;
+    constexpr int NLD_W = BN / 32;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int STAGE_BYTES = ROWS * 128;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    static_assert(BM % 32 == 0 && BN % 32 == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int r16 = lane & 15, q = lane >> 4;
+
+    // ---- block -> tile, XCD-contiguous (bijective for any grid size)
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x;
+        const int q8 = nb >> 3, r8 = nb & 7;
+        const int xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+    }
+    const int tile_m = bid / a.n_tiles;
+    const int tile_n = bid - tile_m * a.n_tiles;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int ld_row = tid >> 3, ld_chunk = tid & 7;
+    const int st_off = ld_row * 128 + ((ld_chunk ^ (ld_row & 7)) << 4);
+
+    // ---- per-thread staging rows: NLD_X pixel rows, then NLD_W weight rows
+    const char* px_base[NLD_X];
+    int px_hi0[NLD_X], px_wi0[NLD_X];
+    bool px_ok[NLD_X];
+#pragma unroll
+    for (int i = 0; i < NLD_X; ++i) {
+        const int m = m0 + ld_row + 32 * i;
+        px_ok[i] = m < a.M;
+        const int mm = px_ok[i] ? m : 0;
+        const int b = mm / a.HoWo;
+        const int rem = mm - b * a.HoWo;
+        const int ho = rem / a.Wo;
+        const int wo = rem - ho * a.Wo;
+        px_hi0[i] = ho * a.sh - a.ph;
+        px_wi0[i] = wo * a.sw - a.pw;
+        px_base[i] = a.x + (long long)b * a.x_img_bytes;
+    }
+    const char* w_ptr[NLD_W];
+    bool w_ok[NLD_W];
+#pragma unroll
+    for (int i = 0; i < NLD_W; ++i) {
+        const int n = n0 + ld_row + 32 * i;
+        w_ok[i] = n < a.Cout;
+        w_ptr[i] = a.w + (long long)(w_ok[i] ? n : 0) * a.w_row_bytes + ld_chunk * 16;
+    }
+
+    uint4 stg[NLD];
+    int f_kh = 0, f_kw = 0, f_cs = 0;  // FAST-mode K position of the NEXT step to load
+
+    auto load_step = [&](int step) {
+        int kh, kw, choff;
+        bool tap_ok = true;
+        if (FAST) {
+            kh = f_kh;
+            kw = f_kw;
+            choff = (f_cs * 8 + ld_chunk) * 16;
+            if (++f_cs == a.SPT) {
+                f_cs = 0;
+                if (++f_kw == a.KW) {
+                    f_kw = 0;
+                    ++f_kh;
+                }
+            }
+        } else {
+            const int g = step * 8 + ld_chunk;
+            const int tap = g / a.CPT;
+            const int cc = g - tap * a.CPT;
+            kh = tap / a.KW;
+            kw = tap - kh * a.KW;
+            choff = cc * 16;
+            tap_ok = tap < a.taps;
+        }
+        const int dhi = kh * a.dh, dwi = kw * a.dw;
+#pragma unroll
+        for (int i = 0; i < NLD_X; ++i) {
+            const int hi = px_hi0[i] + dhi, wi = px_wi0[i] + dwi;
+            const bool ok = tap_ok && px_ok[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) v = *(const uint4*)(px_base[i] + (long long)(hi * a.W + wi) * (a.Cin * ES) + choff);
+            stg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NLD_W; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (w_ok[i]) v = *(const uint4*)(w_ptr[i] + (long long)step * 128);
+            stg[NLD_X + i] = v;
+        }
+    };
+    auto store_stage = [&](int stage) {
+        char* base = smem + stage * STAGE_BYTES + st_off;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *(uint4*)(base + i * 32 * 128) = stg[i];
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int rd_x = (wave_m * WM + r16) * 128;
+    const int rd_w = (BM + wave_n * WN + r16) * 128;
+
+    load_step(0);
+    store_stage(0);
+    __syncthreads();
+
+    const int nsteps = a.nsteps;
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        const bool more = step + 1 < nsteps;
+        if (more) load_step(step + 1);
+        const char* sb = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int sw_off = ((kk * 4 + q) ^ (r16 & 7)) << 4;
+            uint4 fx[MT], fw[NT];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) fx[j] = *(const uint4*)(sb + rd_x + j * 16 * 128 + sw_off);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) fw[i] = *(const uint4*)(sb + rd_w + i * 16 * 128 + sw_off);
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, fw[i]), __builtin_bit_cast(bf16x8_t, fx[j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[i].x), __uint_as_float(fx[j].x),
+                                                                         acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[i].y), __uint_as_float(fx[j].y),
+                                                                         acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[i].z), __uint_as_float(fx[j].z),
+                                                                         acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[i].w), __uint_as_float(fx[j].w),
+                                                                         acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        if (more) store_stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- fused epilogue: bias + residual + relu, 4 consecutive channels per lane
+    const bool vec_ok = (a.Cout & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = m0 + wave_m * WM + j * 16 + r16;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int n = n0 + wave_n * WN + i * 16 + q * 4;
+            if (n >= a.Cout) continue;
+            f32x4 v = acc[i][j];
+            const long long o = (long long)m * a.Cout + n;
+            if (vec_ok) {
+                if (a.bias) {
+                    const float4 bb = *(const float4*)(a.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (a.res) {
+                    if constexpr (sizeof(T) == 2) {
+                        const uint2 rr = *(const uint2*)(a.res + o * 2);
+                        v[0] += bf16_to_f32((u16)(rr.x & 0xffff)); v[1] += bf16_to_f32((u16)(rr.x >> 16));
+                        v[2] += bf16_to_f32((u16)(rr.y & 0xffff)); v[3] += bf16_to_f32((u16)(rr.y >> 16));
+                    } else {
+                        const float4 rr = *(const float4*)(a.res + o * 4);
+                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                    }
+                }
+                if (a.relu) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                if constexpr (OUT_F32) {
+                    *(float4*)(a.y + o * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    *(uint2*)(a.y + o * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= a.Cout) break;
+                    float f = v[e];
+                    if (a.bias) f += a.bias[n + e];
+                    if (a.res) {
+                        if constexpr (sizeof(T) == 2) f += bf16_to_f32(*(const u16*)(a.res + (o + e) * 2));
+                        else f += *(const float*)(a.res + (o + e) * 4);
+                    }
+                    if (a.relu) f = fmaxf(f, 0.f);
+                    if constexpr (OUT_F32) *(float*)(a.y + (o + e) * 4) = f;
+                    else *(u16*)(a.y + (o + e) * 2) = f32_to_bf16(f);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+namespace {
+
+struct TileCfg {
+    int bm, bn;
+};
+// tile ids are 1-based in the C-ABI
+constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {64, 128}, {32, 64}, {32, 32}};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+template <typename T, int BM, int BN, int WM_, int WN_, bool OUT_F32>
+int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
+    const int m_tiles = cdiv(k.M, BM);
+    ConvK kk = k;
+    kk.n_tiles = cdiv(k.Cout, BN);
+    const int grid = m_tiles * kk.n_tiles;
+    constexpr int lds = 2 * (BM + BN) * 128;
+    if (fast) {
+        auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, true, OUT_F32>;
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, kk);
+    } else {
+        auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, false, OUT_F32>;
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, kk);
+    }
+    return mt4_check_launch();
+}
+
+template <typename T, bool OUT_F32>
+int launch_dtype(const ConvK& k, int tile, bool fast, hipStream_t s) {
+    switch (tile) {
+        case 1: return launch_tile<T, 128, 128, 2, 2, OUT_F32>(k, fast, s);
+        case 2: return launch_tile<T, 128, 64, 2, 2, OUT_F32>(k, fast, s);
+        case 3: return launch_tile<T, 64, 64, 2, 2, OUT_F32>(k, fast, s);
+        case 4: return launch_tile<T, 64, 128, 2, 2, OUT_F32>(k, fast, s);
+        case 5: return launch_tile<T, 32, 64, 1, 4, OUT_F32>(k, fast, s);
+        case 6: return launch_tile<T, 32, 32, 2, 2, OUT_F32>(k, fast, s);
+    }
+    return MT4_EINVAL;
+}
+
+int auto_tile(int M, int N) {
+    // largest tile that still gives >= ~2 blocks per CU; fall back to the smallest
+    const long long want = 512;
+    int best = kNumTiles;
+    for (int t = 0; t < kNumTiles; ++t) {
+        const int bm = kTiles[t].bm, bn = kTiles[t].bn;
+        if (bn > 64 && N <= 64) continue;
+        if (bn > 32 && N <= 32) continue;
+        const long long tiles = (long long)cdiv(M, bm) * cdiv(N, bn);
+        if (tiles >= want) return t + 1;
+    }
+    // not enough work to fill the chip: take the tile with the most blocks that wastes least
+    long long best_tiles = -1;
+    for (int t = 0; t < kNumTiles; ++t) {
+        const long long tiles = (long long)cdiv(M, kTiles[t].bm) * cdiv(N, kTiles[t].bn);
+        if (tiles > best_tiles) {
+            best_tiles = tiles;
+            best = t + 1;
+        }
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" int mt4_conv_tile_count(void) { return kNumTiles; }
+
+extern "C" int64_t mt4_conv_packed_k(int32_t Cin, int32_t KH, int32_t KW, int32_t dtype) {
+    const int es = dtype == MT4_BF16 ? 2 : 4;
+    const int cpt = cdiv(Cin * es, 16);
+    const int chunks = cdiv(KH * KW * cpt, 8) * 8;
+    return (int64_t)chunks * (16 / es);
+}
+
+extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
+    mt4_clear_error();
+    if (!d || !d->x || !d->w || !d->y) return MT4_EINVAL;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0 || d->KH <= 0 ||
+        d->KW <= 0 || d->stride_h <= 0 || d->stride_w <= 0 || d->dil_h <= 0 || d->dil_w <= 0)
+        return MT4_EINVAL;
+    if (d->dtype != MT4_F32 && d->dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    if (d->out_dtype != MT4_F32 && d->out_dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    if (d->dtype == MT4_F32 && d->out_dtype != MT4_F32) return MT4_EUNSUPPORTED;
+    const int es = d->dtype == MT4_BF16 ? 2 : 4;
+    if ((d->Cin * es) % 16 != 0) return MT4_EALIGN;
+    if (((uintptr_t)d->x | (uintptr_t)d->w | (uintptr_t)d->y | (uintptr_t)d->residual | (uintptr_t)d->bias) & 15) return MT4_EALIGN;
+    // Ho/Wo may not exceed what the geometry yields (every read is bounds-checked anyway)
+    {
+        const long long eh = (long long)d->H + 2LL * d->pad_h - (long long)d->dil_h * (d->KH - 1) - 1;
+        const long long ew = (long long)d->W + 2LL * d->pad_w - (long long)d->dil_w * (d->KW - 1) - 1;
+        if (eh < 0 || ew < 0) return MT4_EINVAL;
+        if (d->Ho > eh / d->stride_h + 1 || d->Wo > ew / d->stride_w + 1) return MT4_EINVAL;
+    }
+    const long long M = (long long)d->B * d->Ho * d->Wo;
+    if (M > 0x7fffffffLL || M * d->Cout * 4 > (1LL << 40)) return MT4_EUNSUPPORTED;
+
+    ConvK k{};
+    k.x = (const char*)d->x; k.w = (const char*)d->w; k.bias = d->bias; k.res = (const char*)d->residual; k.y = (char*)d->y;
+    k.B = d->B; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
+    k.KH = d->KH; k.KW = d->KW; k.sh = d->stride_h; k.sw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w;
+    k.dh = d->dil_h; k.dw = d->dil_w; k.relu = d->relu;
+    k.M = (int)M; k.HoWo = d->Ho * d->Wo;
+    k.CPT = (d->Cin * es) / 16;
+    k.taps = d->KH * d->KW;
+    k.nsteps = cdiv(k.taps * k.CPT, 8);
+    k.w_row_bytes = k.nsteps * 128;
+    k.x_img_bytes = (long long)d->H * d->W * d->Cin * es;
+    const bool fast = (k.CPT % 8) == 0;
+    k.SPT = fast ? k.CPT / 8 : 1;
+    int tile = d->tile;
+    if (tile < 0 || tile > kNumTiles) return MT4_EINVAL;
+    if (tile == 0) tile = auto_tile(k.M, k.Cout);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == MT4_F32) return launch_dtype<float, true>(k, tile, fast, s);
+    if (d->out_dtype == MT4_F32) return launch_dtype<u16, true>(k, tile, fast, s);
+    return launch_dtype<u16, false>(k, tile, fast, s);
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ out,
+                                        int Cout, int Cin, int KH, int KW, int CPT_E, long long Kpad) {
+    // one thread per packed element
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)Cout * Kpad) return;
+    const int n = (int)(idx / Kpad);
+    const long long k = idx - (long long)n * Kpad;
+    const int tap = (int)(k / CPT_E);
+    const int c = (int)(k - (long long)tap * CPT_E);
+    float v = 0.f;
+    if (tap < KH * KW && c < Cin) {
+        const int kh = tap / KW, kw = tap - kh * KW;
+        v = w[(((long long)n * Cin + c) * KH + kh) * KW + kw];
+        if (scale) v *= scale[n];
+    }
+    if constexpr (sizeof(T) == 2) out[idx] = f32_to_bf16(v);
+    else out[idx] = v;
+}
+
+extern "C" int mt4_pack_conv_weight(const float* w_oihw, const float* scale, void* w_packed, int32_t Cout, int32_t Cin,
+                                    int32_t KH, int32_t KW, int32_t dtype, void* stream) {
+    mt4_clear_error();
+    if (!w_oihw || !w_packed || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return MT4_EINVAL;
+    if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    const int es = dtype == MT4_BF16 ? 2 : 4;
+    const int E = 16 / es;
+    const int cpt = cdiv(Cin * es, 16);
+    const long long Kpad = mt4_conv_packed_k(Cin, KH, KW, dtype);
+    const long long total = (long long)Cout * Kpad;
+    const int grid = (int)((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MT4_BF16)
+        hipLaunchKernelGGL(pack_conv_weight_kernel<u16>, dim3(grid), dim3(256), 0, s, w_oihw, scale, (u16*)w_packed, Cout, Cin,
+                           KH, KW, cpt * E, Kpad);
+    else
+        hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(grid), dim3(256), 0, s, w_oihw, scale, (float*)w_packed, Cout,
+                           Cin, KH, KW, cpt * E, Kpad);
+    return mt4_check_launch();
+}
+
+// stem: [64][3][7][7] -> taps (kh, kwp) with 8-element slots (kw%2)*4 + c, kw = 2*kwp + slot/4
+template <typename T>
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ out,
+                                        int Cout, long long Kpad) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)Cout * Kpad) return;
+    const int n = (int)(idx / Kpad);
+    const int k = (int)(idx - (long long)n * Kpad);
+    const int tap = k >> 3, slot = k & 7;
+    const int kh = tap >> 2, kwp = tap & 3;
+    const int kw = 2 * kwp + (slot >> 2), c = slot & 3;
+    float v = 0.f;
+    if (kh < 7 && kw < 7 && c < 3) {
+        v = w[(((long long)n * 3 + c) * 7 + kh) * 7 + kw];
+        if (scale) v *= scale[n];
+    }
+    if constexpr (sizeof(T) == 2) out[idx] = f32_to_bf16(v);
+    else out[idx] = v;
+}
+
+extern "C" int mt4_pack_stem_weight(const float* w_oihw, const float* scale, void* w_packed, int32_t Cout, int32_t dtype,
+                                    void* stream) {
+    mt4_clear_error();
+    if (!w_oihw || !w_packed || Cout <= 0) return MT4_EINVAL;
+    if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    const long long Kpad = mt4_conv_packed_k(8, 7, 4, dtype);
+    const long long total = (long long)Cout * Kpad;
+    const int grid = (int)((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MT4_BF16)
+        hipLaunchKernelGGL(pack_stem_weight_kernel<u16>, dim3(grid), dim3(256), 0, s, w_oihw, scale, (u16*)w_packed, Cout, Kpad);
+    else
+        hipLaunchKernelGGL(pack_stem_weight_kernel<float>, dim3(grid), dim3(256), 0, s, w_oihw, scale, (float*)w_packed, Cout,
+                           Kpad);
+    return mt4_check_launch();
+}

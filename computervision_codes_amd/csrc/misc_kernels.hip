@@ -1,0 +1,209 @@
+// Small memory-bound kernels around the convolution stack: frame preprocessing, pooling, heads.
+#include "mt4_common.h"
+
+thread_local int g_mt4_last_hip_error = 0;
+
+extern "C" int mt4_abi_version(void) { return 1; }
+extern "C" int mt4_last_hip_error(void) { return g_mt4_last_hip_error; }
+extern "C" const char* mt4_strerror(int code) {
+    switch (code) {
+        case MT4_OK: return "ok";
+        case MT4_EINVAL: return "invalid argument";
+        case MT4_EALIGN: return "alignment contract violated";
+        case MT4_ELAUNCH: return "kernel launch failed";
+        case MT4_EUNSUPPORTED: return "unsupported dtype/shape";
+    }
+    return "unknown error";
+}
+
+// ------------------------------------------------------------------------------------------------ stem input
+// out [B][H+6][Wp][4], Wp = round_up(W+6, 2); interior at (+3,+3); channel 3 and borders zero.
+template <typename T, bool FROM_U8>
+__global__ void stem_input_kernel(const void* __restrict__ in, T* __restrict__ out, int B, int H, int W, int Hp, int Wp,
+                                  float m0, float m1, float m2, float s0, float s1, float s2) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one padded pixel per thread
+    const long long total = (long long)B * Hp * Wp;
+    if (idx >= total) return;
+    const int wp = (int)(idx % Wp);
+    const long long t = idx / Wp;
+    const int hp = (int)(t % Hp);
+    const int b = (int)(t / Hp);
+    const int h = hp - 3, w = wp - 3;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+        if (FROM_U8) {
+            const uint8_t* p = (const uint8_t*)in + (((long long)b * H + h) * W + w) * 3;
+            // same op order as ToTensor (/255) then Normalize ((x-mean)/std)
+            v0 = ((float)p[0] / 255.0f - m0) / s0;
+            v1 = ((float)p[1] / 255.0f - m1) / s1;
+            v2 = ((float)p[2] / 255.0f - m2) / s2;
+        } else {
+            const float* p = (const float*)in;
+            const long long hw = (long long)H * W;
+            const long long o = (long long)b * 3 * hw + (long long)h * W + w;
+            v0 = p[o]; v1 = p[o + hw]; v2 = p[o + 2 * hw];
+        }
+    }
+    if constexpr (sizeof(T) == 2) {
+        *(uint2*)(out + idx * 4) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, 0.f));
+    } else {
+        *(float4*)(out + idx * 4) = make_float4(v0, v1, v2, 0.f);
+    }
+}
+
+static int stem_input_launch(const void* in, void* out, int B, int H, int W, const float* mean, const float* std, int dtype,
+                             bool from_u8, hipStream_t s) {
+    mt4_clear_error();
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0) return MT4_EINVAL;
+    if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    const int Hp = H + 6, Wp = (W + 6 + 1) & ~1;
+    const long long total = (long long)B * Hp * Wp;
+    const int grid = (int)((total + 255) / 256);
+    const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
+    const float s0 = std ? std[0] : 1.f, s1 = std ? std[1] : 1.f, s2 = std ? std[2] : 1.f;
+    if (dtype == MT4_BF16) {
+        if (from_u8) hipLaunchKernelGGL((stem_input_kernel<u16, true>), dim3(grid), dim3(256), 0, s, in, (u16*)out, B, H, W, Hp, Wp, m0, m1, m2, s0, s1, s2);
+        else hipLaunchKernelGGL((stem_input_kernel<u16, false>), dim3(grid), dim3(256), 0, s, in, (u16*)out, B, H, W, Hp, Wp, m0, m1, m2, s0, s1, s2);
+    } else {
+        if (from_u8) hipLaunchKernelGGL((stem_input_kernel<float, true>), dim3(grid), dim3(256), 0, s, in, (float*)out, B, H, W, Hp, Wp, m0, m1, m2, s0, s1, s2);
+        else hipLaunchKernelGGL((stem_input_kernel<float, false>), dim3(grid), dim3(256), 0, s, in, (float*)out, B, H, W, Hp, Wp, m0, m1, m2, s0, s1, s2);
+    }
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_preprocess_u8(const uint8_t* frames, void* out, int32_t B, int32_t H, int32_t W, const float mean[3],
+                                 const float std[3], int32_t dtype, void* stream) {
+    if (!mean || !std) return MT4_EINVAL;
+    return stem_input_launch(frames, out, B, H, W, mean, std, dtype, true, (hipStream_t)stream);
+}
+
+extern "C" int mt4_pad_nchw_f32(const float* x, void* out, int32_t B, int32_t H, int32_t W, int32_t dtype, void* stream) {
+    return stem_input_launch(x, out, B, H, W, nullptr, nullptr, dtype, false, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ maxpool 3x3/2 pad 1
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const int CV = C / E;  // 16-byte vectors per pixel
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * Ho * Wo * CV;
+    if (idx >= total) return;
+    const int cv = (int)(idx % CV);
+    long long t = idx / CV;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float best[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) best[e] = -INFINITY;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hi = ho * 2 - 1 + kh;
+        if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int wi = wo * 2 - 1 + kw;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            const uint4 v = *(const uint4*)(x + (((long long)b * H + hi) * W + wi) * C + cv * E);
+            if constexpr (sizeof(T) == 2) {
+                const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    best[2 * e] = fmaxf(best[2 * e], bf16_to_f32((u16)(u[e] & 0xffff)));
+                    best[2 * e + 1] = fmaxf(best[2 * e + 1], bf16_to_f32((u16)(u[e] >> 16)));
+                }
+            } else {
+                best[0] = fmaxf(best[0], __uint_as_float(v.x)); best[1] = fmaxf(best[1], __uint_as_float(v.y));
+                best[2] = fmaxf(best[2], __uint_as_float(v.z)); best[3] = fmaxf(best[3], __uint_as_float(v.w));
+            }
+        }
+    }
+    uint4 o;
+    if constexpr (sizeof(T) == 2) {
+        o = make_uint4(pack_bf16x2(best[0], best[1]), pack_bf16x2(best[2], best[3]), pack_bf16x2(best[4], best[5]),
+                       pack_bf16x2(best[6], best[7]));
+    } else {
+        o = make_uint4(__float_as_uint(best[0]), __float_as_uint(best[1]), __float_as_uint(best[2]), __float_as_uint(best[3]));
+    }
+    *(uint4*)(y + (((long long)b * Ho + ho) * Wo + wo) * C + cv * E) = o;
+}
+
+extern "C" int mt4_maxpool3x3s2_nhwc(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                                     void* stream) {
+    mt4_clear_error();
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return MT4_EINVAL;
+    if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    const int es = dtype == MT4_BF16 ? 2 : 4;
+    if ((C * es) % 16 != 0 || (((uintptr_t)x | (uintptr_t)y) & 15)) return MT4_EALIGN;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)B * Ho * Wo * (C * es / 16);
+    const int grid = (int)((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MT4_BF16) hipLaunchKernelGGL(maxpool3x3s2_kernel<u16>, dim3(grid), dim3(256), 0, s, (const u16*)x, (u16*)y, B, H, W, C, Ho, Wo);
+    else hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, Ho, Wo);
+    return mt4_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ global average pool
+// one block per (frame, 256-channel slab... ) : thread = one channel, loops over HW (coalesced across threads)
+template <typename T>
+__global__ void global_avgpool_kernel(const T* __restrict__ x, float* __restrict__ y, int HW, int C) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const T* p = x + (long long)b * HW * C + c;
+    float s = 0.f;
+    for (int i = 0; i < HW; ++i) {
+        if constexpr (sizeof(T) == 2) s += bf16_to_f32(p[(long long)i * C]);
+        else s += p[(long long)i * C];
+    }
+    y[(long long)b * C + c] = s / (float)HW;
+}
+
+extern "C" int mt4_global_avgpool_nhwc(const void* x, float* y, int32_t B, int32_t HW, int32_t C, int32_t dtype, void* stream) {
+    mt4_clear_error();
+    if (!x || !y || B <= 0 || HW <= 0 || C <= 0) return MT4_EINVAL;
+    if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    if (B > 65535) return MT4_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(cdiv(C, 256), B);
+    if (dtype == MT4_BF16) hipLaunchKernelGGL(global_avgpool_kernel<u16>, grid, dim3(256), 0, s, (const u16*)x, y, HW, C);
+    else hipLaunchKernelGGL(global_avgpool_kernel<float>, grid, dim3(256), 0, s, (const float*)x, y, HW, C);
+    return mt4_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ linear heads (fp32)
+// one wave per output element row-dot: block = 4 waves, each wave computes y[b][n] for one n, looping n
+__global__ void linear_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                  float* __restrict__ y, int K, int N) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const float* xr = x + (long long)b * K;
+    for (int n = wave; n < N; n += nw) {
+        const float* wr = w + (long long)n * K;
+        float s = 0.f;
+        if ((K & 3) == 0) {
+            for (int k = lane * 4; k < K; k += 256) {
+                const float4 a = *(const float4*)(xr + k);
+                const float4 c = *(const float4*)(wr + k);
+                s += a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+            }
+        } else {
+            for (int k = lane; k < K; k += 64) s += xr[k] * wr[k];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) y[(long long)b * N + n] = s + (bias ? bias[n] : 0.f);
+    }
+}
+
+extern "C" int mt4_linear_f32(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t K, int32_t N,
+                              void* stream) {
+    mt4_clear_error();
+    if (!x || !w || !y || B <= 0 || K <= 0 || N <= 0) return MT4_EINVAL;
+    if ((K & 3) == 0 && (((uintptr_t)x | (uintptr_t)w) & 15)) return MT4_EALIGN;
+    hipLaunchKernelGGL(linear_f32_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, K, N);
+    return mt4_check_launch();
+}

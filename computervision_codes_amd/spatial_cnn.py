@@ -1,0 +1,158 @@
+"""Spatial_cnn on MI355X: host-side mirror of `MT4MTLKD/Spatial_cnn/network.py` (VideoNas / BaseModel /
+Classifier) with the torchvision ResNet-18/50 trunk (`Spatial_transformer/models/resnet.py` graph).
+
+Same state-dict keys (`basemodel.basemodel.*`, `classifier_*`, `wi/wv/wt/mi/mv/mt`) and the same return
+tuple as the reference.  Every Conv2d+BatchNorm2d(eval)[+ReLU][+residual] is ONE launch of the
+implicit-GEMM kernel (BN folded at load time), activations are NHWC in `dtype` (float32 for the 1e-3
+parity mode, bfloat16 for throughput), heads run in fp32 on the fp32 pooled feature.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .shapes import resnet_feat_dim, spatial_cnn_shapes
+from .synth import IMAGENET_MEAN, IMAGENET_STD
+
+_DEPTHS = {"resnet18": (2, 2, 2, 2), "resnet50": (3, 4, 6, 3)}
+_HEADS = (("i", 6), ("v", 10), ("t", 15), ("ivt", 100))
+
+
+class VideoNas:
+    """Drop-in for `Spatial_cnn.network.VideoNas` (eval / extraction path).
+
+    args needs: network ('resnet18'|'resnet50'), loss_type, student_dim, teacher_dim, train."""
+
+    def __init__(self, args=None, num_tool=6, num_verb=10, num_target=15, num_triplet=100, dtype: torch.dtype = torch.float32,
+                 device: str = "cuda"):
+        self.args = args
+        self.network = args.network
+        self.loss_type = args.loss_type
+        self.feat_dim = getattr(args, "student_dim", None) or resnet_feat_dim(self.network)
+        assert self.feat_dim == resnet_feat_dim(self.network), "student_dim must equal the trunk's feature width"
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.training = False
+        self._table = spatial_cnn_shapes(self.network, self.feat_dim, getattr(args, "teacher_dim", 1536), self.loss_type)
+        self._sd: Dict[str, torch.Tensor] = {}
+        self._p: Dict[str, object] = {}
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def cuda(self):
+        return self
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        names = [k for k, _ in self._table]
+        missing = [k for k in names if k not in sd]
+        if strict and (missing or len(sd) != len(names)):
+            raise KeyError(f"state dict mismatch: missing {missing[:4]}, unexpected {[k for k in sd if k not in names][:4]}")
+        for k, shp in self._table:
+            if k in sd:
+                if tuple(sd[k].shape) != tuple(shp):
+                    raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != {shp}")
+                self._sd[k] = sd[k].detach()
+        self._pack()
+        return self
+
+    # ------------------------------------------------------------------ load-time packing (BN folding)
+    def _fold(self, conv: str, bn: str, stem: bool = False):
+        sd, dev = self._sd, self.device
+        g = sd[bn + ".weight"].double()
+        beta = sd[bn + ".bias"].double()
+        mu = sd[bn + ".running_mean"].double()
+        var = sd[bn + ".running_var"].double()
+        scale = g / torch.sqrt(var + 1e-5)
+        bias = (beta - mu * scale).float().to(dev).contiguous()
+        w = sd[conv + ".weight"].float().to(dev)
+        sc = scale.float().to(dev)
+        wp = ops.pack_stem_weight(w, sc, self.dtype) if stem else ops.pack_conv_weight(w, sc, self.dtype)
+        return wp, bias
+
+    def _pack(self):
+        pre = "basemodel.basemodel."
+        p: Dict[str, object] = {}
+        p["stem"] = self._fold(pre + "conv1", pre + "bn1", stem=True)
+        bottleneck = self.network == "resnet50"
+        for li, n in enumerate(_DEPTHS[self.network], start=1):
+            for b in range(n):
+                q = f"{pre}layer{li}.{b}."
+                for ci in ((1, 2, 3) if bottleneck else (1, 2)):
+                    p[f"{q}conv{ci}"] = self._fold(f"{q}conv{ci}", f"{q}bn{ci}")
+                if (q + "downsample.0.weight") in self._sd:
+                    p[q + "ds"] = self._fold(q + "downsample.0", q + "downsample.1")
+        ws, bs, self._head_slices, o = [], [], {}, 0
+        for task, k in _HEADS:
+            if self.loss_type in (task, "all"):
+                ws.append(self._sd[f"classifier_{task}.fc.weight"].float())
+                bs.append(self._sd[f"classifier_{task}.fc.bias"].float())
+                self._head_slices[task] = (o, o + k)
+                o += k
+        p["heads.w"] = torch.cat(ws, 0).to(self.device).contiguous()
+        p["heads.b"] = torch.cat(bs, 0).to(self.device).contiguous()
+        self._p = p
+
+    # ------------------------------------------------------------------ trunk
+    def _conv(self, x, key, k, stride=1, pad=0, residual=None, relu=True):
+        wp, b = self._p[key]
+        return ops.conv_nhwc(x, wp, b, kh=k, kw=k, stride=(stride, stride), pad=(pad, pad), residual=residual, relu=relu)
+
+    def trunk_from_padded(self, xp: torch.Tensor, h: int, w: int) -> torch.Tensor:
+        """xp: stem input [B,H+6,Wp,4] (ops.preprocess_u8 / ops.pad_nchw).  Returns pooled fp32 [B,C]."""
+        b, hp, wp_, _ = xp.shape
+        wst, bst = self._p["stem"]
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        xv = xp.view(b, hp, wp_ // 2, 8)  # pixel pairs: one 7-wide kernel row = 4 pairs (one zero slot)
+        y = torch.empty((b, ho, wo, wst.shape[0]), dtype=self.dtype, device=xp.device)
+        ops.conv_nhwc(xv, wst, bst, kh=7, kw=4, stride=(2, 1), relu=True, out=y)
+        x = ops.maxpool3x3s2(y)
+        pre = "basemodel.basemodel."
+        bottleneck = self.network == "resnet50"
+        for li, n in enumerate(_DEPTHS[self.network], start=1):
+            for bi in range(n):
+                q = f"{pre}layer{li}.{bi}."
+                s = 2 if (bi == 0 and li > 1) else 1
+                idt = self._conv(x, q + "ds", 1, stride=s, relu=False) if (q + "ds") in self._p else x
+                if bottleneck:  # resnet.py:101-121 (stride on the 3x3)
+                    o = self._conv(x, q + "conv1", 1)
+                    o = self._conv(o, q + "conv2", 3, stride=s, pad=1)
+                    x = self._conv(o, q + "conv3", 1, residual=idt)
+                else:           # resnet.py:35-72
+                    o = self._conv(x, q + "conv1", 3, stride=s, pad=1)
+                    x = self._conv(o, q + "conv2", 3, pad=1, residual=idt)
+        return ops.global_avgpool(x)
+
+    def _finish(self, feat: torch.Tensor):
+        b = feat.shape[0]
+        logits = ops.linear_f32(feat, self._p["heads.w"], self._p["heads.b"])
+        outs = {}
+        for task, k in _HEADS:
+            if task in self._head_slices:
+                lo, hi = self._head_slices[task]
+                outs[task] = logits[:, lo:hi]
+            else:  # network.py:79-82: zeros for absent heads
+                outs[task] = torch.zeros((b, k), device=feat.device)
+        return (0, outs["i"]), (0, outs["v"]), (0, outs["t"]), (feat, outs["ivt"])
+
+    def forward(self, inputs: torch.Tensor, tool=None, verb=None, target=None):
+        """inputs: normalised float32 NCHW [B,3,H,W] on the GPU (the reference's module boundary)."""
+        if self.training or getattr(self.args, "train", False):
+            raise NotImplementedError("training / KD branch (network.py:47-71) is not part of the extraction path yet")
+        if not self._p:
+            raise RuntimeError("load_state_dict first")
+        _, _, h, w = inputs.shape
+        return self._finish(self.trunk_from_padded(ops.pad_nchw(inputs, self.dtype), h, w))
+
+    __call__ = forward
+
+    def extract_u8(self, frames_u8: torch.Tensor):
+        """Fused input path: uint8 frames [B,H,W,3] -> (ToTensor+Normalize on the GPU) -> forward."""
+        _, h, w, _ = frames_u8.shape
+        return self._finish(self.trunk_from_padded(ops.preprocess_u8(frames_u8, IMAGENET_MEAN, IMAGENET_STD, self.dtype), h, w))

@@ -1,0 +1,148 @@
+"""Temporal_tenco on MI355X: host-side mirror of `MT4MTLKD/Temporal_tenco/network.py` (VideoNas).
+
+Same constructor arguments, state-dict keys and return structure as the reference module; the
+arithmetic runs in libmt4hip.so.  Activations stay frame-major ([T][C], the layout of the frame
+feature files and of the module's own input [1,T,D]) -- the reference's permute to [1,D,T]
+(`network.py:42`) is folded into addressing, and the [1,K,T] logits it returns are permuted VIEWS
+of our [T][K] buffers (same shape and values, different strides).
+
+One DilatedResidualLayer (`network.py:186-198`) = two launches of the implicit-GEMM kernel:
+dilated k3 conv + bias + ReLU, then 1x1 conv + bias + residual.  The four 1x1 heads
+(`network.py:21-24`) are concatenated into one [131][C] GEMM per FPN level.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .shapes import tenco_shapes
+
+
+class VideoNas:
+    """Drop-in for `Temporal_tenco.network.VideoNas` (inference path; eval semantics).
+
+    args needs: fpn, output, hier (only output=False / hier=False -- what every shipped script uses --
+    are implemented; the others raise).
+    """
+
+    def __init__(self, args, num_layers_PG, num_layers_R, num_R, num_f_maps, dim, num_classes, num_i=6, num_v=10,
+                 num_t=15, device: str = "cuda"):
+        if getattr(args, "output", False) or getattr(args, "hier", False):
+            raise NotImplementedError("--output / --hier are never set by the shipped scripts (Scripts/*.sh)")
+        self.args = args
+        self.use_fpn = bool(getattr(args, "fpn", False))
+        self.num_layers_PG, self.num_layers_R, self.num_R = num_layers_PG, num_layers_R, num_R
+        self.C, self.D, self.K = num_f_maps, dim, num_classes
+        self.head_sizes = (num_classes, num_i, num_v, num_t)
+        self.device = torch.device(device)
+        self.training = False
+        self._table = tenco_shapes(num_layers_PG, num_layers_R, num_R, num_f_maps, dim, num_classes, fpn=self.use_fpn,
+                                   num_i=num_i, num_v=num_v, num_t=num_t)
+        self._sd: Dict[str, torch.Tensor] = {}
+        self._p: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def eval(self):
+        self.training = False
+        return self
+
+    def cuda(self):
+        return self
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return dict(self._sd)
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        names = [k for k, _ in self._table]
+        missing = [k for k in names if k not in sd]
+        if strict and (missing or len(sd) != len(names)):
+            raise KeyError(f"state dict mismatch: missing {missing[:4]}, unexpected {[k for k in sd if k not in names][:4]}")
+        for k, shp in self._table:
+            if k in sd:
+                if tuple(sd[k].shape) != tuple(shp):
+                    raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != {shp}")
+                self._sd[k] = sd[k].detach().to(torch.float32)
+        self._pack()
+        return self
+
+    def _pack(self):
+        dev, p = self.device, {}
+
+        def pk(name):  # Conv1d weight [Cout,Cin,k] -> OIHW [Cout,Cin,1,k] -> packed
+            w = self._sd[name + ".weight"].to(dev)
+            p[name + ".w"] = ops.pack_conv_weight(w.unsqueeze(2), None, torch.float32)
+            p[name + ".b"] = self._sd[name + ".bias"].to(dev).contiguous()
+
+        stages = [("PG", self.num_layers_PG)] + [(f"Rs.{r}", self.num_layers_R) for r in range(self.num_R)]
+        pk("PG.conv_1x1")
+        for prefix, n in stages:
+            for i in range(n):
+                pk(f"{prefix}.layers.{i}.conv_dilated")
+                pk(f"{prefix}.layers.{i}.conv_1x1")
+        if not self.use_fpn:
+            pk("PG.conv_out")
+        else:
+            pk("fpn.latlayer1")
+            w = torch.cat([self._sd[f"conv_out{s}.weight"] for s in ("", "_i", "_v", "_t")], 0).to(dev)
+            b = torch.cat([self._sd[f"conv_out{s}.bias"] for s in ("", "_i", "_v", "_t")], 0).to(dev)
+            p["heads.w"] = ops.pack_conv_weight(w.unsqueeze(2), None, torch.float32)
+            p["heads.b"] = b.contiguous()
+        self._p = p
+
+    # ------------------------------------------------------------------ forward
+    def _c1(self, x, name, residual=None, relu=False):
+        return ops.conv_nhwc(x, self._p[name + ".w"], self._p[name + ".b"], kh=1, kw=1, residual=residual, relu=relu)
+
+    def _layer(self, x, prefix, d):
+        p = self._p
+        h = ops.conv_nhwc(x, p[prefix + ".conv_dilated.w"], p[prefix + ".conv_dilated.b"], kh=1, kw=3, pad=(0, d), dil=(1, d),
+                          relu=True)
+        return ops.conv_nhwc(h, p[prefix + ".conv_1x1.w"], p[prefix + ".conv_1x1.b"], kh=1, kw=1, residual=x)
+
+    def _stage(self, x, prefix, n):
+        for i in range(n):
+            x = self._layer(x, f"{prefix}.layers.{i}", 2 ** i)
+        return x
+
+    def forward(self, x: torch.Tensor, ismask: bool = False):
+        """x [B,T,D] float32 on the GPU.  Returns (out_list, out_list_i, out_list_v, out_list_t, f_list, f_list)
+        with tensors shaped like the reference's ([B,K,T] logits, [B,C,T] features)."""
+        if ismask and self.training:
+            raise NotImplementedError("train-time masking (network.py:43-48) is not part of the inference path")
+        if not self._p:
+            raise RuntimeError("load_state_dict first")
+        assert x.dim() == 3 and x.shape[2] == self.D and x.dtype == torch.float32
+        b, t, _ = x.shape
+        x4 = x.contiguous().view(b, 1, t, self.D)
+        f = self._stage(self._c1(x4, "PG.conv_1x1"), "PG", self.num_layers_PG)
+        f_list = [f]
+        out_list: List[torch.Tensor] = []
+        out_i: List[torch.Tensor] = []
+        out_v: List[torch.Tensor] = []
+        out_t: List[torch.Tensor] = []
+        as_ref = lambda y: y.view(b, t, -1).permute(0, 2, 1)  # [B,1,T,K] -> [B,K,T] view
+        if not self.use_fpn:
+            out_list.append(as_ref(self._c1(f, "PG.conv_out")))
+        # per-stage conv_out logits are computed and discarded by the reference (network.py:133,160): skipped
+        for r in range(self.num_R):
+            f = self._stage(f, f"Rs.{r}", self.num_layers_R)
+            f_list.append(f)
+        if self.use_fpn:
+            c1, c2, c3, p4 = f_list
+            p3 = self._c1(c3, "fpn.latlayer1", residual=p4)   # interpolate to equal length == identity
+            p2 = self._c1(c2, "fpn.latlayer1", residual=p3)
+            p1 = self._c1(c1, "fpn.latlayer1", residual=p2)
+            f_list = [p1, p2, p3, p4]
+            k0, k1, k2, k3 = self.head_sizes
+            for lvl in f_list:
+                y = as_ref(ops.conv_nhwc(lvl, self._p["heads.w"], self._p["heads.b"], kh=1, kw=1))
+                out_list.append(y[:, :k0])
+                out_i.append(y[:, k0:k0 + k1])
+                out_v.append(y[:, k0 + k1:k0 + k1 + k2])
+                out_t.append(y[:, k0 + k1 + k2:])
+        f_ref = [as_ref(ff) for ff in f_list]
+        return out_list, out_i, out_v, out_t, f_ref, f_ref
+
+    __call__ = forward

@@ -1,0 +1,57 @@
+"""CPU: libmt4hip.so loads and exports every symbol include/mt4hip.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mt4hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mt4_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    from computervision_codes_amd import _lib
+    names = _declared_symbols()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(_lib.lib, n), f"{n} declared in mt4hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_abi_version_and_error_strings():
+    from computervision_codes_amd import _lib
+    assert _lib.lib.mt4_abi_version() == 1
+    assert _lib.lib.mt4_strerror(0) == b"ok"
+    assert b"invalid" in _lib.lib.mt4_strerror(-1)
+
+
+def test_argument_validation_without_gpu():
+    """error paths return before any launch"""
+    from computervision_codes_amd import _lib
+    assert _lib.lib.mt4_conv_nhwc(None, None) == -1
+    d = _lib.ConvDesc()
+    assert _lib.lib.mt4_conv_nhwc(ctypes.byref(d), None) == -1
+    assert _lib.lib.mt4_linear_f32(None, None, None, None, 1, 1, 1, None) == -1
+    # packed K: fp32 512ch k3 = 3 taps x 128 chunks x 4; bf16 stem view = 32 chunks x 8
+    assert _lib.lib.mt4_conv_packed_k(512, 1, 3, 0) == 1536
+    assert _lib.lib.mt4_conv_packed_k(8, 7, 4, 1) == 256
+    assert _lib.lib.mt4_conv_packed_k(48, 1, 1, 0) == 64   # 12 chunks -> 16 chunks x 4
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from computervision_codes_amd import _lib, ops
+    with pytest.raises(_lib.Mt4Error):
+        ops.maxpool3x3s2(torch.zeros(1, 4, 4, 4))
+
+
+def test_struct_layout_matches_header():
+    from computervision_codes_amd import _lib
+    # 5 pointers + 19 int32
+    assert ctypes.sizeof(_lib.ConvDesc) == 5 * 8 + 19 * 4 + 4  # padded to 8

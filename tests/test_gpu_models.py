@@ -1,0 +1,131 @@
+"""GPU parity proper: the HIP-backed model mirrors vs (a) the golden outputs of the REFERENCE modules and
+(b) the CPU oracle, through the C-ABI, on the same synthetic weights and inputs.
+
+Tolerances (BASELINE.json north_star): per-frame logits within 1e-3 in fp32 mode; per-head argmax and
+top-5 sets identical.  bf16 mode (throughput mode) is checked at 5e-2 of the logit range and reported
+as such -- 53 stacked bf16 convs cannot hold 1e-3 (SURVEY 7 hard part (ii))."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from computervision_codes_amd import shapes, synth
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TENCO = ["tenco_tiny", "tenco_ragged", "tenco_config1", "tenco_4stage"]
+CNN = ["cnn_resnet18_odd", "cnn_resnet50_small", "cnn_resnet18_224", "cnn_resnet50_224", "cnn_resnet50_256x448"]
+
+
+def _maxerr(a, ref):
+    return (a.detach().float().cpu() - torch.from_numpy(np.asarray(ref))).abs().max().item()
+
+
+def _same_topk(a, ref, k):
+    a = a.detach().float().cpu()
+    ref = torch.from_numpy(np.asarray(ref))
+    k = min(k, a.shape[-1])
+    ia = a.topk(k, dim=-1).indices.sort(dim=-1).values
+    ir = ref.topk(k, dim=-1).indices.sort(dim=-1).values
+    return torch.equal(ia, ir)
+
+
+@pytest.mark.parametrize("name", TENCO)
+def test_tenco_vs_reference_golden(cuda, name):
+    from computervision_codes_amd.temporal_tenco import VideoNas
+    z, cfg = load_golden(name)
+    args = types.SimpleNamespace(fpn=cfg["fpn"], output=False, hier=False, mask=True)
+    m = VideoNas(args, cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["num_f_maps"], cfg["dim"], 100).eval()
+    table = shapes.tenco_shapes(cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["num_f_maps"], cfg["dim"], 100,
+                                fpn=cfg["fpn"])
+    m.load_state_dict(synth.fill_from_shapes(table, seed=cfg["seed"]))
+    x = synth.synthetic_features(cfg["T"], cfg["dim"], seed=cfg["seed"]).to(cuda)
+    out = m(x, False)
+    torch.cuda.synchronize()
+    for gi, g in enumerate(("ivt", "i", "v", "t")):
+        assert len(out[gi]) == sum(1 for k in z.files if k.startswith(f"logit_{g}_"))
+        for li, o in enumerate(out[gi]):
+            ref = z[f"logit_{g}_{li}"]
+            assert tuple(o.shape) == ref.shape
+            assert _maxerr(o, ref) < 1e-3, (g, li, _maxerr(o, ref))
+            # per-frame argmax over classes (dim 1 of [1,K,T]) bit-exact
+            assert torch.equal(o.float().cpu().argmax(1), torch.from_numpy(ref).argmax(1))
+    for li, f in enumerate(out[4]):
+        if f"feat_{li}" in z:
+            assert _maxerr(f, z[f"feat_{li}"]) < 1e-3
+        else:
+            flat = f.float().cpu().contiguous().flatten()
+            assert _maxerr(flat[:: max(1, flat.numel() // 4096)], z[f"feat_{li}_sample"]) < 1e-3
+
+
+def test_tenco_long_video_vs_oracle(cuda):
+    """T = 1500 (a full-video length, not in the fixtures): HIP vs the CPU oracle directly."""
+    from computervision_codes_amd.temporal_tenco import VideoNas
+    from oracle import tenco as o_tenco
+    cfgk = dict(num_layers_PG=11, num_layers_R=10, num_R=3)
+    args = types.SimpleNamespace(fpn=True, output=False, hier=False, mask=True)
+    table = shapes.tenco_shapes(11, 10, 3, 64, 64, 100, fpn=True)
+    sd = synth.fill_from_shapes(table, seed=3)
+    m = VideoNas(args, 11, 10, 3, 64, 64, 100).eval().load_state_dict(sd)
+    x = synth.synthetic_features(1500, 64, seed=3)
+    with torch.no_grad():
+        ref = o_tenco.tenco_forward(sd, x, fpn=True, **cfgk)
+    out = m(x.to(cuda), False)
+    for gi in range(4):
+        for o, r in zip(out[gi], ref[gi]):
+            assert _maxerr(o, r.numpy()) < 1e-3
+
+
+def _cnn_model(cfg, dtype):
+    from computervision_codes_amd.spatial_cnn import VideoNas
+    args = types.SimpleNamespace(network=cfg["network"], loss_type="all", student_dim=shapes.resnet_feat_dim(cfg["network"]),
+                                 teacher_dim=1536, train=False)
+    m = VideoNas(args=args, dtype=dtype).eval()
+    m.load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes(cfg["network"]), seed=cfg["seed"]))
+    return m
+
+
+@pytest.mark.parametrize("name", CNN)
+def test_spatial_cnn_fp32_vs_reference_golden(cuda, name):
+    z, cfg = load_golden(name)
+    m = _cnn_model(cfg, torch.float32)
+    frames = synth.synthetic_frames(cfg["B"], cfg["H"], cfg["W"], seed=cfg["seed"])
+    img = synth.normalize_frames(frames).to(cuda)
+    (k0, li), (k1, lv), (k2, lt), (feat, livt) = m(img)
+    assert k0 == 0 and k1 == 0 and k2 == 0
+    for o, key, k in ((li, "logit_i", 6), (lv, "logit_v", 10), (lt, "logit_t", 15), (livt, "logit_ivt", 100)):
+        assert tuple(o.shape) == z[key].shape
+        assert _maxerr(o, z[key]) < 1e-3, (key, _maxerr(o, z[key]))
+        assert torch.equal(o.float().cpu().argmax(1), torch.from_numpy(z[key]).argmax(1))
+        assert _same_topk(o, z[key], 5)
+    assert _maxerr(feat, z["feat"]) < 1e-3
+    # uint8 fast path: same numbers (normalisation done on the GPU)
+    (_, _), (_, _), (_, _), (feat2, livt2) = m.extract_u8(frames.to(cuda))
+    assert _maxerr(livt2, z["logit_ivt"]) < 1e-3 and _maxerr(feat2, z["feat"]) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["cnn_resnet50_small", "cnn_resnet50_224", "cnn_resnet18_224"])
+def test_spatial_cnn_bf16_mode(cuda, name):
+    """throughput mode: bf16 activations/weights, fp32 accumulate + fp32 epilogue.  Tolerance 5e-2 of the
+    logit range (NOT the 1e-3 parity claim, which the fp32 mode carries)."""
+    z, cfg = load_golden(name)
+    m = _cnn_model(cfg, torch.bfloat16)
+    frames = synth.synthetic_frames(cfg["B"], cfg["H"], cfg["W"], seed=cfg["seed"]).to(cuda)
+    (_, li), (_, lv), (_, lt), (feat, livt) = m.extract_u8(frames)
+    for o, key in ((li, "logit_i"), (lv, "logit_v"), (lt, "logit_t"), (livt, "logit_ivt")):
+        rng = float(np.abs(z[key]).max())
+        assert _maxerr(o, z[key]) < 5e-2 * rng, (key, _maxerr(o, z[key]), rng)
+    assert _maxerr(feat, z["feat"]) < 5e-2 * float(np.abs(z["feat"]).max())
+
+
+def test_spatial_cnn_batch_independence(cuda):
+    """frames are independent units (the multi-GPU sharding premise): a frame's output does not depend on
+    its batch neighbours or its position in the batch -- bit-exact."""
+    _, cfg = load_golden("cnn_resnet18_odd")
+    m = _cnn_model(cfg, torch.float32)
+    frames = synth.synthetic_frames(6, 64, 64, seed=77).to(cuda)
+    (_, _), (_, _), (_, _), (feat_all, l_all) = m.extract_u8(frames)
+    (_, _), (_, _), (_, _), (feat_2, l_2) = m.extract_u8(frames[4:6].contiguous())
+    assert torch.equal(feat_all[4:6], feat_2) and torch.equal(l_all[4:6], l_2)
