@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Headline benchmark: spatial-extract frames/s (Spatial_cnn ResNet-50, 224x224, bf16, synthetic frames
+resident in HBM) + per-video TCN latency (Temporal_tenco), beside the CPU oracle timed on the host.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the extraction hot path over one batch of B frames per GPU: uint8 frames ->
+normalise -> ResNet-50 trunk -> avgpool feature [B,2048] + 4 logit heads (`Spatial_cnn/test.py:143-177`).
+Frames are independent units, so ranks run disjoint batches with no data-path collective ("weak").
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--network", default="resnet50")
+    ap.add_argument("--height", type=int, default=224)
+    ap.add_argument("--width", type=int, default=224)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-temporal", action="store_true")
+    ap.add_argument("--per-layer", default="", help="write a per-conv-layer timing table (json) to this path")
+    return ap.parse_args()
+
+
+def conv_flops_per_frame(model, h, w):
+    """algorithmic conv FLOPs (2*MAC, true K = Cin*kh*kw) of the trunk for one frame"""
+    total = 0
+    for rec in model.conv_plan(h, w):
+        total += 2 * rec["Ho"] * rec["Wo"] * rec["Cout"] * rec["Cin"] * rec["kh"] * rec["kw"]
+    return total
+
+
+def time_conv_kernels(model, frames, iters=3):
+    """Average duration of the implicit-GEMM conv launches of one step, measured with HIP events recorded on
+    the stream the kernels are launched on (torch's current stream), one event pair per launch."""
+    from computervision_codes_amd import ops
+    pairs = []
+    orig = ops.conv_nhwc
+
+    def timed(*a, **k):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig(*a, **k)
+        e1.record()
+        pairs.append((e0, e1))
+        return y
+
+    ops.conv_nhwc = timed
+    try:
+        per_iter = []
+        for _ in range(iters):
+            pairs.clear()
+            model.extract_u8(frames)
+            torch.cuda.synchronize()
+            per_iter.append([a.elapsed_time(b) for a, b in pairs])
+    finally:
+        ops.conv_nhwc = orig
+    n = len(per_iter[0])
+    per_launch_ms = [min(it[i] for it in per_iter) for i in range(n)]
+    return per_launch_ms
+
+
+def cpu_baseline_spatial(network, h, w, seed):
+    """CPU oracle (port of the reference arithmetic) on the host cores, bounded sample."""
+    from computervision_codes_amd import shapes, synth
+    from oracle import spatial_cnn as o_cnn
+    sd = synth.fill_from_shapes(shapes.spatial_cnn_shapes(network), seed=seed)
+    bs = 8
+    img = synth.normalize_frames(synth.synthetic_frames(bs, h, w, seed=seed))
+    with torch.no_grad():
+        o_cnn.spatial_cnn_forward(sd, img, network)  # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            o_cnn.spatial_cnn_forward(sd, img, network)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > 12.0 or n >= 30:
+                break
+    return dict(value=round(bs * n / dt, 2), unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} batches of {bs} frames {h}x{w}, torch-CPU fp32 oracle, eval, no_grad")
+
+
+def temporal_bench(dev, do_cpu):
+    """per-video latency of the 4-stage Temporal_tenco head (D=512) at T=256 and T=2000, and config 1."""
+    from computervision_codes_amd import shapes, synth
+    from computervision_codes_amd.temporal_tenco import VideoNas
+    out = {}
+    cases = [("tenco4_T256", dict(num_R=3, dim=512, fpn=True, T=256)), ("tenco4_T2000", dict(num_R=3, dim=512, fpn=True, T=2000)),
+             ("config1_T256", dict(num_R=0, dim=2048, fpn=False, T=256))]
+    for name, c in cases:
+        args = types.SimpleNamespace(fpn=c["fpn"], output=False, hier=False, mask=True)
+        table = shapes.tenco_shapes(11, 10, c["num_R"], 512, c["dim"], 100, fpn=c["fpn"])
+        sd = synth.fill_from_shapes(table, seed=47)
+        m = VideoNas(args, 11, 10, c["num_R"], 512, c["dim"], 100).eval().load_state_dict(sd)
+        x = synth.synthetic_features(c["T"], c["dim"], seed=47).to(dev)
+        for _ in range(3):
+            m(x, False)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            m(x, False)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        lat = ts[len(ts) // 2]
+        nparam = sum(v.numel() for v in sd.values())
+        L = 11 + 10 * c["num_R"]
+        nlev = 4 if c["fpn"] else 1
+        alg_bytes = 4 * (nparam + c["T"] * (c["dim"] + 2 * 512 * L + nlev * (131 if c["fpn"] else 100)))
+        flops = 2 * c["T"] * (c["dim"] * 512 + L * (512 * 1536 + 512 * 512) + (3 * 512 * 512 + nlev * 131 * 512 if c["fpn"] else 100 * 512))
+        rec = dict(ms_per_video=round(lat, 4), T=c["T"], algorithmic_MB=round(alg_bytes / 1e6, 1),
+                   hbm_frac=round(alg_bytes / (lat * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                   f32_mfma_frac=round(flops / (lat * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+        if do_cpu:
+            from oracle import tenco as o_tenco
+            xc = x.cpu()
+            with torch.no_grad():
+                o_tenco.tenco_forward(sd, xc, 11, 10, c["num_R"], c["fpn"])
+                t0 = time.perf_counter()
+                n = 0
+                while n < 10 and time.perf_counter() - t0 < 4.0:
+                    o_tenco.tenco_forward(sd, xc, 11, 10, c["num_R"], c["fpn"])
+                    n += 1
+                rec["cpu_ms_per_video"] = round((time.perf_counter() - t0) / n * 1e3, 2)
+        out[name] = rec
+    return out
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)
+
+    from computervision_codes_amd import shapes, synth
+    from computervision_codes_amd.spatial_cnn import VideoNas
+
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    args = types.SimpleNamespace(network=a.network, loss_type="all", student_dim=shapes.resnet_feat_dim(a.network), teacher_dim=1536,
+                                 train=False)
+    model = VideoNas(args=args, dtype=dtype, device=str(dev)).eval()
+    model.load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes(a.network), seed=1234))
+    # every rank gets its own disjoint frames (seeded by rank), resident in HBM before timing starts
+    frames = synth.synthetic_frames(a.batch, a.height, a.width, seed=1234 + rank).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        model.extract_u8(frames)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = model.extract_u8(frames)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out[3][1]).all()
+
+    ms_per_step = dt / a.steps * 1e3
+    fps = world * a.batch * a.steps / dt
+
+    res = None
+    if rank == 0:
+        flops_frame = conv_flops_per_frame(model, a.height, a.width)
+        per_launch = time_conv_kernels(model, frames)
+        conv_ms = sum(per_launch)
+        peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_MFMA_TFLOPS
+        achieved = flops_frame * a.batch / (conv_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(f"{a.network}_{a.dtype}_b{a.batch}_{a.height}x{a.width}")
+            except Exception:
+                traffic = None
+        roofline = dict(bound="mfma", kernel="igemm_conv_kernel (all conv launches of one step)", achieved=round(achieved, 2),
+                        peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
+                        launches_per_step=len(per_launch), conv_ms_per_step=round(conv_ms, 4),
+                        gflop_per_frame=round(flops_frame / 1e9, 3))
+        if a.per_layer:
+            plan = model.conv_plan(a.height, a.width)
+            rows = []
+            for rec, ms in zip(plan, per_launch):
+                fl = 2 * a.batch * rec["Ho"] * rec["Wo"] * rec["Cout"] * rec["Cin"] * rec["kh"] * rec["kw"]
+                rows.append(dict(rec, ms=round(ms, 4), tflops=round(fl / (ms * 1e-3) / 1e12, 1)))
+            os.makedirs(os.path.dirname(os.path.abspath(a.per_layer)), exist_ok=True)
+            json.dump(rows, open(a.per_layer, "w"), indent=1)
+        res = {
+            "metric": "frames/sec spatial-extract + per-video TCN latency, Cholec80, 1/2/4/8 GPU",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"Spatial_cnn {a.network} extractor, {a.height}x{a.width} frames, {a.dtype}, eval "
+                                   f"(BASELINE configs[1])", "frames_per_gpu_per_step": a.batch,
+                       "global_frames_per_step": a.batch * world, "parallelism": f"frame-sharded x{world}, no collective"},
+            "roofline": roofline,
+        }
+        if world == 1 and not a.no_temporal:
+            res["temporal"] = temporal_bench(dev, do_cpu=not a.no_cpu_baseline)
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_spatial(a.network, a.height, a.width, 1234)
+            res["gpu_over_cpu"] = round(fps / res["cpu_baseline"]["value"], 1)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -129,6 +129,33 @@ class VideoNas:
                     x = self._conv(o, q + "conv2", 3, pad=1, residual=idt)
         return ops.global_avgpool(x)
 
+    def conv_plan(self, h: int, w: int):
+        """Geometry of every conv launch of one forward, in launch order (algorithmic dims: the stem is the
+        true 7x7x3).  Used by bench.py for FLOP accounting and per-layer tables."""
+        plan = []
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        plan.append(dict(name="stem", Cin=3, Cout=64, kh=7, kw=7, stride=2, Ho=ho, Wo=wo))
+        hh, ww = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+        cin = 64
+        bottleneck = self.network == "resnet50"
+        for li, (planes, n) in enumerate(zip((64, 128, 256, 512), _DEPTHS[self.network]), start=1):
+            for bi in range(n):
+                s = 2 if (bi == 0 and li > 1) else 1
+                h2, w2 = (hh - 1) // s + 1, (ww - 1) // s + 1
+                cout = planes * (4 if bottleneck else 1)
+                q = f"layer{li}.{bi}."
+                if bi == 0 and (s != 1 or cin != cout):
+                    plan.append(dict(name=q + "ds", Cin=cin, Cout=cout, kh=1, kw=1, stride=s, Ho=h2, Wo=w2))
+                if bottleneck:
+                    plan.append(dict(name=q + "conv1", Cin=cin, Cout=planes, kh=1, kw=1, stride=1, Ho=hh, Wo=ww))
+                    plan.append(dict(name=q + "conv2", Cin=planes, Cout=planes, kh=3, kw=3, stride=s, Ho=h2, Wo=w2))
+                    plan.append(dict(name=q + "conv3", Cin=planes, Cout=cout, kh=1, kw=1, stride=1, Ho=h2, Wo=w2))
+                else:
+                    plan.append(dict(name=q + "conv1", Cin=cin, Cout=planes, kh=3, kw=3, stride=s, Ho=h2, Wo=w2))
+                    plan.append(dict(name=q + "conv2", Cin=planes, Cout=planes, kh=3, kw=3, stride=1, Ho=h2, Wo=w2))
+                cin, hh, ww = cout, h2, w2
+        return plan
+
     def _finish(self, feat: torch.Tensor):
         b = feat.shape[0]
         logits = ops.linear_f32(feat, self._p["heads.w"], self._p["heads.b"])
