@@ -1,0 +1,63 @@
+"""Extraction harness: batches frames in file order, no shuffle, drop_last False, one
+feature block [N,D] per video (`Spatial_cnn/test.py:143-177`), sharded over ranks by whole videos.
+
+Videos are independent units, so N ranks need no data-path collective: every rank runs its own videos and
+rank 0 merges the per-rank dicts once at the end (`gather_feats`, an object gather on the host) to write the
+single pickle the temporal stage reads.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Iterable, List, Mapping, Sequence
+
+import numpy as np
+import torch
+
+
+def shard_videos(video_keys: Sequence[str], n_frames: Sequence[int], rank: int, world: int) -> List[int]:
+    """Greedy longest-first balancing of whole videos over ranks; deterministic on every rank.
+    Returns the indices (into video_keys) owned by `rank`, in original order."""
+    if len(video_keys) != len(n_frames):
+        raise ValueError("video_keys / n_frames length mismatch")
+    order = sorted(range(len(video_keys)), key=lambda i: (-int(n_frames[i]), i))
+    load = [0] * world
+    owner = [0] * len(video_keys)
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[i] = r
+        load[r] += int(n_frames[i])
+    return [i for i in range(len(video_keys)) if owner[i] == rank]
+
+
+def extract_video(frames: torch.Tensor, forward: Callable[[torch.Tensor], torch.Tensor], batch: int) -> np.ndarray:
+    """frames [N,...] in file order -> float32 [N,D]; `forward` maps a batch to its [b,D] features."""
+    out = []
+    for s in range(0, frames.shape[0], batch):   # last batch short: drop_last=False
+        out.append(forward(frames[s:s + batch]).detach().float().cpu())
+    return torch.vstack(out).numpy() if out else np.zeros((0, 0), np.float32)
+
+
+def gather_feats(local: Mapping[str, np.ndarray], group=None) -> Dict[str, np.ndarray]:
+    """Merge per-rank {video -> [N,D]} dicts on every rank (host-side object gather; no-op for 1 rank)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return dict(local)
+    parts: List[Dict[str, np.ndarray]] = [None] * dist.get_world_size(group)  # type: ignore
+    dist.all_gather_object(parts, dict(local), group=group)
+    merged: Dict[str, np.ndarray] = {}
+    for p in parts:
+        for k, v in p.items():
+            if k in merged:
+                raise ValueError(f"video {k} extracted by two ranks")
+            merged[k] = v
+    return merged
+
+
+def extract_dataset(videos: Mapping[str, torch.Tensor], forward: Callable[[torch.Tensor], torch.Tensor], batch: int,
+                    rank: int = 0, world: int = 1, group=None) -> Dict[str, np.ndarray]:
+    """videos: {key -> frames [N,...]} (same mapping on every rank).  Returns the merged {key -> [N,D]} with
+    keys in the original order."""
+    keys = list(videos.keys())
+    mine = shard_videos(keys, [videos[k].shape[0] for k in keys], rank, world)
+    local = {keys[i]: extract_video(videos[keys[i]], forward, batch) for i in mine}
+    merged = gather_feats(local, group)
+    return {k: merged[k] for k in keys}

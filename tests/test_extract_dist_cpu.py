@@ -1,0 +1,84 @@
+"""CPU: host logic of the extraction harness and its world_size-2 path over gloo (no GPU compute: the
+per-batch forward is a stand-in callable -- the sharding/merge/file logic is what is under test)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from computervision_codes_amd import extract, featfile
+
+
+def _fake_forward(batch):  # deterministic per-frame function: frame -> 4 moments
+    b = batch.float().flatten(1)
+    return torch.stack([b.mean(1), b.std(1), b.min(1).values, b.max(1).values], 1)
+
+
+def _videos():
+    g = torch.Generator().manual_seed(5)
+    return {f"{i:02d}": torch.rand((n, 3, 4, 4), generator=g) for i, n in enumerate([7, 1, 12, 5, 9], start=1)}
+
+
+def test_shard_videos_partitions_and_balances():
+    keys = ["a", "b", "c", "d", "e"]
+    n = [100, 10, 60, 50, 5]
+    parts = [extract.shard_videos(keys, n, r, 2) for r in range(2)]
+    assert sorted(parts[0] + parts[1]) == list(range(5))
+    loads = [sum(n[i] for i in p) for p in parts]
+    assert abs(loads[0] - loads[1]) <= 15
+    assert extract.shard_videos(keys, n, 0, 1) == list(range(5))
+    # more ranks than videos: some ranks own nothing
+    assert sum(len(extract.shard_videos(keys[:2], n[:2], r, 4)) for r in range(4)) == 2
+
+
+def test_extract_video_batching_matches_unbatched():
+    v = _videos()["03"]
+    full = _fake_forward(v).numpy()
+    for bs in (1, 5, 12, 64):
+        assert np.array_equal(extract.extract_video(v, _fake_forward, bs), full)  # ragged last batch kept
+
+
+def test_featfile_roundtrip_and_reference_layout(tmp_path):
+    feats = {k: _fake_forward(v).numpy() for k, v in _videos().items()}
+    p = featfile.feats_path(str(tmp_path), "SwinL2Res18", 1, "all")
+    assert p.endswith(os.path.join("0-5fold", "data_feats", "run_SwinL2Res18", "k1_feats.pkl"))
+    assert featfile.feats_path(str(tmp_path), "SwinL", 1, "i").endswith("k1_i_feats.pkl")
+    assert featfile.feats_path(str(tmp_path), "SwinL_MSTCT", 2, "v", "pred").endswith("k2_v_pred.pkl")
+    featfile.write_feats(p, feats)
+    raw = pickle.load(open(p, "rb"))   # exactly what the reference's readers do (dataloader.py:212-214)
+    assert isinstance(raw, dict) and list(raw) == list(feats)
+    for k in feats:
+        assert raw[k].dtype == np.float32 and raw[k].flags["C_CONTIGUOUS"] and np.array_equal(raw[k], feats[k])
+    assert all(np.array_equal(a, feats[k]) for k, a in featfile.read_feats(p).items())
+    featfile.write_npy_dir(str(tmp_path / "npy"), feats)
+    assert np.array_equal(np.load(tmp_path / "npy" / "VID03.npy"), feats["03"])
+    assert featfile.video_key("/data/CholecT45/data/VID79") == "79"
+    assert featfile.video_key("/data/CholecT50/data/VID111", "transformer") == "111"
+    with pytest.raises(ValueError):
+        featfile.write_feats(p, {"01": np.zeros((3,))})
+
+
+def _worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        merged = extract.extract_dataset(_videos(), _fake_forward, batch=4, rank=rank, world=world)
+        if rank == 0:
+            featfile.write_feats(os.path.join(outdir, "k1_feats.pkl"), merged)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_extraction_equals_single_process(tmp_path):
+    single = extract.extract_dataset(_videos(), _fake_forward, batch=4)
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = featfile.read_feats(str(tmp_path / "k1_feats.pkl"))
+    assert list(got) == list(single)
+    for k in single:
+        assert np.array_equal(got[k], single[k])
