@@ -25,7 +25,7 @@ struct ConvK {
     const char* res;
     char* y;
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, sh, sw, ph, pw, dh, dw, relu;
-    int M, HoWo, CPT, SPT, taps, nsteps, n_tiles;
+    int M, HoWo, CPT, SPT, taps, nsteps, n_tiles, total_tiles;
     long long x_img_bytes;  // H*W*Cin*esize
     int w_row_bytes;        // nsteps*128
 };
@@ -49,7 +49,11 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
     const int r16 = lane & 15, q = lane >> 4;
 
-    // ---- block -> tile, XCD-contiguous (bijective for any grid size)
+    // ---- block -> tile, XCD-contiguous (bijective for any grid size), channel tile fastest: the column tiles of a
+    // pixel tile run at the same time on ONE XCD, so activations are fetched from HBM once and shared through L2.
+    // One tile per workgroup: a persistent variant (workgroups walking several tiles, next tile's first K-step and
+    // residual rows prefetched across the epilogue) measured SLOWER on every ResNet-50 layer -- its extra live
+    // registers cost a wave per SIMD; hardware workgroup turnover already provides that overlap.
     int bid = blockIdx.x;
     {
         const int nb = gridDim.x;
@@ -73,13 +77,19 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
         const int m = m0 + ld_row + 32 * i;
         px_ok[i] = m < a.M;
         const int mm = px_ok[i] ? m : 0;
-        const int b = mm / a.HoWo;
-        const int rem = mm - b * a.HoWo;
-        const int ho = rem / a.Wo;
-        const int wo = rem - ho * a.Wo;
-        px_hi0[i] = ho * a.sh - a.ph;
-        px_wi0[i] = wo * a.sw - a.pw;
-        px_base[i] = a.x + (long long)b * a.x_img_bytes;
+        if (a.HoWo == 1) {  // pure GEMM (1x1, stride 1, no padding): pixel m is row m, no index decode
+            px_hi0[i] = 0;
+            px_wi0[i] = 0;
+            px_base[i] = a.x + (long long)mm * a.x_img_bytes;
+        } else {
+            const int b = mm / a.HoWo;
+            const int rem = mm - b * a.HoWo;
+            const int ho = rem / a.Wo;
+            const int wo = rem - ho * a.Wo;
+            px_hi0[i] = ho * a.sh - a.ph;
+            px_wi0[i] = wo * a.sw - a.pw;
+            px_base[i] = a.x + (long long)b * a.x_img_bytes;
+        }
     }
     const char* w_ptr[NLD_W];
     bool w_ok[NLD_W];
@@ -188,8 +198,87 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
         __syncthreads();
     }
 
-    // ---- fused epilogue: bias + residual + relu, 4 consecutive channels per lane
-    const bool vec_ok = (a.Cout & 3) == 0;
+    // ---- fused epilogue: bias + residual + relu
+    // Staged path (Cout % CH == 0): the fp32 accumulators (+bias) go through LDS as [pixel][channel] rows so that every
+    // lane adds the residual and stores the result as ONE 16-byte vector and a wave-instruction covers whole rows
+    // (BN*osize contiguous bytes per pixel) instead of 16 scattered 8/16-byte pieces.
+    constexpr int OS = OUT_F32 ? 4 : 2;
+    constexpr int CH = 16 / OS;        // channels per 16-byte output vector
+    constexpr int ROWB = BN * 4 + 16;  // fp32 row + 16 B pad: conflict-free ds_write_b128 per 8 lanes
+    constexpr int PASSES = (BM * ROWB > 2 * STAGE_BYTES) ? 2 : 1;
+    static_assert(BM / PASSES * ROWB <= 2 * STAGE_BYTES, "epilogue staging fits the main-loop LDS");
+    static_assert(MT % PASSES == 0, "passes split the m-tiles of a wave");
+    constexpr int MTP = MT / PASSES;  // m-tiles per wave per pass
+    constexpr int WMP = WM / PASSES;  // rows per wave_m group per pass
+    constexpr int BMP = BM / PASSES;
+    constexpr int TPR = BN / CH;      // threads per row on read-back
+    constexpr int RPI = 256 / TPR;    // rows per read-back iteration
+    constexpr int ITERS = (BMP + RPI - 1) / RPI;
+    constexpr int RB = (sizeof(T) == 2 && CH == 4) ? 8 : 16;  // residual bytes per output vector
+    if ((a.Cout % CH) == 0) {
+        // (the K loop ended with a barrier: every wave is done reading the operand stages)
+        const int rc = tid % TPR, rr = tid / TPR;
+        const int n = n0 + rc * CH;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            if (p) __syncthreads();
+#pragma unroll
+            for (int jj = 0; jj < MTP; ++jj) {
+                const int lrow = wave_m * WMP + jj * 16 + r16;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int nl = wave_n * WN + i * 16 + q * 4;
+                    f32x4 v = acc[i][p * MTP + jj];
+                    if (a.bias && n0 + nl < a.Cout) {
+                        const float4 bb = *(const float4*)(a.bias + n0 + nl);
+                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                    }
+                    *(f32x4*)(smem + lrow * ROWB + nl * 4) = v;
+                }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int it = 0; it < ITERS; ++it) {
+                const int lrow = rr + it * RPI;
+                if (lrow >= BMP) break;
+                const int trow = (lrow / WMP) * WM + p * WMP + (lrow % WMP);
+                const int m = m0 + trow;
+                if (m >= a.M || n >= a.Cout) continue;
+                float v[CH];
+                *(float4*)&v[0] = *(const float4*)(smem + lrow * ROWB + rc * CH * 4);
+                if constexpr (CH == 8) *(float4*)&v[4] = *(const float4*)(smem + lrow * ROWB + rc * CH * 4 + 16);
+                const long long o = (long long)m * a.Cout + n;
+                if (a.res) {
+                    uint4 rv;
+                    if constexpr (RB == 16) rv = *(const uint4*)(a.res + o * ES);
+                    else { const uint2 r2 = *(const uint2*)(a.res + o * ES); rv = make_uint4(r2.x, r2.y, 0, 0); }
+                    if constexpr (sizeof(T) == 2) {
+                        const uint32_t u[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                        for (int e = 0; e < CH / 2; ++e) {
+                            v[2 * e] += bf16_to_f32((u16)(u[e] & 0xffff));
+                            v[2 * e + 1] += bf16_to_f32((u16)(u[e] >> 16));
+                        }
+                    } else {
+                        v[0] += __uint_as_float(rv.x); v[1] += __uint_as_float(rv.y);
+                        v[2] += __uint_as_float(rv.z); v[3] += __uint_as_float(rv.w);
+                    }
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if constexpr (OUT_F32) {
+                    *(float4*)(a.y + o * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    *(uint4*)(a.y + o * 2) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                        pack_bf16x2(v[6], v[7]));
+                }
+            }
+        }
+        return;
+    }
+    // Direct path (ragged Cout, e.g. the 131-wide concatenated heads): per-element guards
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int m = m0 + wave_m * WM + j * 16 + r16;
@@ -198,45 +287,20 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
         for (int i = 0; i < NT; ++i) {
             const int n = n0 + wave_n * WN + i * 16 + q * 4;
             if (n >= a.Cout) continue;
-            f32x4 v = acc[i][j];
+            const f32x4 v = acc[i][j];
             const long long o = (long long)m * a.Cout + n;
-            if (vec_ok) {
-                if (a.bias) {
-                    const float4 bb = *(const float4*)(a.bias + n);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                }
-                if (a.res) {
-                    if constexpr (sizeof(T) == 2) {
-                        const uint2 rr = *(const uint2*)(a.res + o * 2);
-                        v[0] += bf16_to_f32((u16)(rr.x & 0xffff)); v[1] += bf16_to_f32((u16)(rr.x >> 16));
-                        v[2] += bf16_to_f32((u16)(rr.y & 0xffff)); v[3] += bf16_to_f32((u16)(rr.y >> 16));
-                    } else {
-                        const float4 rr = *(const float4*)(a.res + o * 4);
-                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-                    }
-                }
-                if (a.relu) {
-                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                }
-                if constexpr (OUT_F32) {
-                    *(float4*)(a.y + o * 4) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    *(uint2*)(a.y + o * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                }
-            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (n + e >= a.Cout) break;
-                    float f = v[e];
-                    if (a.bias) f += a.bias[n + e];
-                    if (a.res) {
-                        if constexpr (sizeof(T) == 2) f += bf16_to_f32(*(const u16*)(a.res + (o + e) * 2));
-                        else f += *(const float*)(a.res + (o + e) * 4);
-                    }
-                    if (a.relu) f = fmaxf(f, 0.f);
-                    if constexpr (OUT_F32) *(float*)(a.y + (o + e) * 4) = f;
-                    else *(u16*)(a.y + (o + e) * 2) = f32_to_bf16(f);
+            for (int e = 0; e < 4; ++e) {
+                if (n + e >= a.Cout) break;
+                float f = v[e];
+                if (a.bias) f += a.bias[n + e];
+                if (a.res) {
+                    if constexpr (sizeof(T) == 2) f += bf16_to_f32(*(const u16*)(a.res + (o + e) * 2));
+                    else f += *(const float*)(a.res + (o + e) * 4);
                 }
+                if (a.relu) f = fmaxf(f, 0.f);
+                if constexpr (OUT_F32) *(float*)(a.y + (o + e) * 4) = f;
+                else *(u16*)(a.y + (o + e) * 2) = f32_to_bf16(f);
             }
         }
     }
@@ -257,8 +321,9 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     const int m_tiles = cdiv(k.M, BM);
     ConvK kk = k;
     kk.n_tiles = cdiv(k.Cout, BN);
-    const int grid = m_tiles * kk.n_tiles;
+    kk.total_tiles = m_tiles * kk.n_tiles;
     constexpr int lds = 2 * (BM + BN) * 128;
+    const int grid = kk.total_tiles;  // one tile per workgroup (see PERSIST in the kernel)
     if (fast) {
         auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, true, OUT_F32>;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, kk);
@@ -282,24 +347,29 @@ int launch_dtype(const ConvK& k, int tile, bool fast, hipStream_t s) {
     return MT4_EINVAL;
 }
 
-int auto_tile(int M, int N) {
-    // largest tile that still gives >= ~2 blocks per CU; fall back to the smallest
-    const long long want = 512;
-    int best = kNumTiles;
-    for (int t = 0; t < kNumTiles; ++t) {
-        const int bm = kTiles[t].bm, bn = kTiles[t].bn;
-        if (bn > 64 && N <= 64) continue;
-        if (bn > 32 && N <= 32) continue;
-        const long long tiles = (long long)cdiv(M, bm) * cdiv(N, bn);
-        if (tiles >= want) return t + 1;
+int auto_tile(int M, int N, int nsteps) {
+    // Measured on MI355X over the ResNet-50 layer set (tools/tune_conv.py, profiles/r01_tile_tuning.txt):
+    // long-K layers want the 128x128 tile (most MFMA per LDS byte); short-K (memory-bound) layers want the
+    // smaller 64x128 / 128x64 footprints (more workgroups per CU -> more loads and stores in flight).
+    auto tiles = [&](int t) { return (long long)cdiv(M, kTiles[t - 1].bm) * cdiv(N, kTiles[t - 1].bn); };
+    const long long fill = 256;  // one workgroup per CU
+    if (N > 64) {
+        if (nsteps >= 16 && tiles(1) >= fill) return 1;
+        if (tiles(4) >= fill) return 4;
+        if (tiles(1) >= fill) return 1;
+    } else if (N > 32) {
+        if (tiles(2) >= fill) return 2;
+        if (tiles(3) >= fill) return 3;
     }
-    // not enough work to fill the chip: take the tile with the most blocks that wastes least
+    // not enough work to fill the chip: take the tile with the most blocks
+    int best = kNumTiles;
     long long best_tiles = -1;
-    for (int t = 0; t < kNumTiles; ++t) {
-        const long long tiles = (long long)cdiv(M, kTiles[t].bm) * cdiv(N, kTiles[t].bn);
-        if (tiles > best_tiles) {
-            best_tiles = tiles;
-            best = t + 1;
+    for (int t = 1; t <= kNumTiles; ++t) {
+        if (kTiles[t - 1].bn > 64 && N <= 64) continue;
+        if (kTiles[t - 1].bn > 32 && N <= 32) continue;
+        if (tiles(t) > best_tiles) {
+            best_tiles = tiles(t);
+            best = t;
         }
     }
     return best;
@@ -344,16 +414,20 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     k.KH = d->KH; k.KW = d->KW; k.sh = d->stride_h; k.sw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w;
     k.dh = d->dil_h; k.dw = d->dil_w; k.relu = d->relu;
     k.M = (int)M; k.HoWo = d->Ho * d->Wo;
+    if (d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0) {
+        // pure GEMM: every pixel is its own "image" (skips the per-row index decode in the kernel)
+        k.B = (int)M; k.H = k.W = k.Ho = k.Wo = 1; k.HoWo = 1;
+    }
     k.CPT = (d->Cin * es) / 16;
     k.taps = d->KH * d->KW;
     k.nsteps = cdiv(k.taps * k.CPT, 8);
     k.w_row_bytes = k.nsteps * 128;
-    k.x_img_bytes = (long long)d->H * d->W * d->Cin * es;
+    k.x_img_bytes = (long long)k.H * k.W * d->Cin * es;
     const bool fast = (k.CPT % 8) == 0;
     k.SPT = fast ? k.CPT / 8 : 1;
     int tile = d->tile;
     if (tile < 0 || tile > kNumTiles) return MT4_EINVAL;
-    if (tile == 0) tile = auto_tile(k.M, k.Cout);
+    if (tile == 0) tile = auto_tile(k.M, k.Cout, k.nsteps);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MT4_F32) return launch_dtype<float, true>(k, tile, fast, s);
     if (d->out_dtype == MT4_F32) return launch_dtype<u16, true>(k, tile, fast, s);

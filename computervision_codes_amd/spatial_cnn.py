@@ -95,7 +95,8 @@ class VideoNas:
                 bs.append(self._sd[f"classifier_{task}.fc.bias"].float())
                 self._head_slices[task] = (o, o + k)
                 o += k
-        p["heads.w"] = torch.cat(ws, 0).to(self.device).contiguous()
+        # the heads run as one fp32 GEMM (exact fp32 MFMA) through the 1x1 mode of the conv kernel
+        p["heads.w"] = ops.pack_conv_weight(torch.cat(ws, 0).to(self.device)[:, :, None, None], None, torch.float32)
         p["heads.b"] = torch.cat(bs, 0).to(self.device).contiguous()
         self._p = p
 
@@ -158,7 +159,7 @@ class VideoNas:
 
     def _finish(self, feat: torch.Tensor):
         b = feat.shape[0]
-        logits = ops.linear_f32(feat, self._p["heads.w"], self._p["heads.b"])
+        logits = ops.conv_nhwc(feat.view(b, 1, 1, -1), self._p["heads.w"], self._p["heads.b"], kh=1, kw=1).view(b, -1)
         outs = {}
         for task, k in _HEADS:
             if task in self._head_slices:
