@@ -24,6 +24,7 @@ class ConvDesc(C.Structure):
     """mirror of `mt4_conv_desc` (include/mt4hip.h)"""
     _fields_ = [
         ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
+        ("out_row_map", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32),
@@ -31,6 +32,7 @@ class ConvDesc(C.Structure):
         ("pad_h", C.c_int32), ("pad_w", C.c_int32),
         ("dil_h", C.c_int32), ("dil_w", C.c_int32),
         ("relu", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile", C.c_int32),
+        ("out_row_map_len", C.c_int32), ("y_ld", C.c_int32), ("res_ld", C.c_int32),
     ]
 
 
@@ -52,6 +54,14 @@ SIGNATURES = {
     "mt4_maxpool3x3s2_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mt4_global_avgpool_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_linear_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "mt4_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, C.c_float, _i32, _vp]),
+    "mt4_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                C.c_float, _i32, _vp]),
+    "mt4_patchify": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _FLOAT3, _FLOAT3, _i32, _vp]),
+    "mt4_add_rowbcast": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i32, _i32, _i32, _vp]),
+    "mt4_groupwise_linear": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_dwconv1d_k3": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_kd_mix": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
 }
 
 

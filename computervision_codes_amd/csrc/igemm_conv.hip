@@ -24,7 +24,10 @@ struct ConvK {
     const float* bias;
     const char* res;
     char* y;
-    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, sh, sw, ph, pw, dh, dw, relu;
+    const int* row_map;  // optional: output/residual row of pixel m = (m / map_len) * map_len + row_map[m % map_len]
+    int map_len;
+    int y_ld, res_ld;    // row pitch (elements) of y / residual; Cout when dense
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, sh, sw, ph, pw, dh, dw, relu;  // relu: 0 none, 1 ReLU, 2 GELU(erf)
     int M, HoWo, CPT, SPT, taps, nsteps, n_tiles, total_tiles;
     long long x_img_bytes;  // H*W*Cin*esize
     int w_row_bytes;        // nsteps*128
@@ -242,16 +245,18 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
                 const int lrow = rr + it * RPI;
                 if (lrow >= BMP) break;
                 const int trow = (lrow / WMP) * WM + p * WMP + (lrow % WMP);
-                const int m = m0 + trow;
+                int m = m0 + trow;
                 if (m >= a.M || n >= a.Cout) continue;
+                if (a.row_map) m = (m / a.map_len) * a.map_len + a.row_map[m % a.map_len];
                 float v[CH];
                 *(float4*)&v[0] = *(const float4*)(smem + lrow * ROWB + rc * CH * 4);
                 if constexpr (CH == 8) *(float4*)&v[4] = *(const float4*)(smem + lrow * ROWB + rc * CH * 4 + 16);
-                const long long o = (long long)m * a.Cout + n;
+                const long long o = (long long)m * a.y_ld + n;
                 if (a.res) {
+                    const long long ro = (long long)m * a.res_ld + n;
                     uint4 rv;
-                    if constexpr (RB == 16) rv = *(const uint4*)(a.res + o * ES);
-                    else { const uint2 r2 = *(const uint2*)(a.res + o * ES); rv = make_uint4(r2.x, r2.y, 0, 0); }
+                    if constexpr (RB == 16) rv = *(const uint4*)(a.res + ro * ES);
+                    else { const uint2 r2 = *(const uint2*)(a.res + ro * ES); rv = make_uint4(r2.x, r2.y, 0, 0); }
                     if constexpr (sizeof(T) == 2) {
                         const uint32_t u[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
@@ -264,9 +269,12 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
                         v[2] += __uint_as_float(rv.z); v[3] += __uint_as_float(rv.w);
                     }
                 }
-                if (a.relu) {
+                if (a.relu == 1) {
 #pragma unroll
                     for (int e = 0; e < CH; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (a.relu == 2) {
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) v[e] = gelu_erf(v[e]);
                 }
                 if constexpr (OUT_F32) {
                     *(float4*)(a.y + o * 4) = make_float4(v[0], v[1], v[2], v[3]);
@@ -281,24 +289,27 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
     // Direct path (ragged Cout, e.g. the 131-wide concatenated heads): per-element guards
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const int m = m0 + wave_m * WM + j * 16 + r16;
+        int m = m0 + wave_m * WM + j * 16 + r16;
         if (m >= a.M) continue;
+        if (a.row_map) m = (m / a.map_len) * a.map_len + a.row_map[m % a.map_len];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int n = n0 + wave_n * WN + i * 16 + q * 4;
             if (n >= a.Cout) continue;
             const f32x4 v = acc[i][j];
-            const long long o = (long long)m * a.Cout + n;
+            const long long o = (long long)m * a.y_ld + n;
+            const long long ro = (long long)m * a.res_ld + n;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (n + e >= a.Cout) break;
                 float f = v[e];
                 if (a.bias) f += a.bias[n + e];
                 if (a.res) {
-                    if constexpr (sizeof(T) == 2) f += bf16_to_f32(*(const u16*)(a.res + (o + e) * 2));
-                    else f += *(const float*)(a.res + (o + e) * 4);
+                    if constexpr (sizeof(T) == 2) f += bf16_to_f32(*(const u16*)(a.res + (ro + e) * 2));
+                    else f += *(const float*)(a.res + (ro + e) * 4);
                 }
-                if (a.relu) f = fmaxf(f, 0.f);
+                if (a.relu == 1) f = fmaxf(f, 0.f);
+                else if (a.relu == 2) f = gelu_erf(f);
                 if constexpr (OUT_F32) *(float*)(a.y + (o + e) * 4) = f;
                 else *(u16*)(a.y + (o + e) * 2) = f32_to_bf16(f);
             }
@@ -413,6 +424,16 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     k.B = d->B; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
     k.KH = d->KH; k.KW = d->KW; k.sh = d->stride_h; k.sw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w;
     k.dh = d->dil_h; k.dw = d->dil_w; k.relu = d->relu;
+    if (d->relu < 0 || d->relu > 2) return MT4_EINVAL;
+    k.row_map = d->out_row_map; k.map_len = d->out_row_map_len;
+    k.y_ld = d->y_ld > 0 ? d->y_ld : d->Cout;
+    k.res_ld = d->res_ld > 0 ? d->res_ld : d->Cout;
+    if (k.y_ld < d->Cout || k.res_ld < d->Cout) return MT4_EINVAL;
+    {
+        const int oes = d->out_dtype == MT4_BF16 ? 2 : 4;
+        if ((d->Cout * oes) % 16 == 0 && ((k.y_ld * oes) % 16 != 0 || (d->residual && (k.res_ld * es) % 16 != 0))) return MT4_EALIGN;
+    }
+    if (d->out_row_map && d->out_row_map_len <= 0) return MT4_EINVAL;
     k.M = (int)M; k.HoWo = d->Ho * d->Wo;
     if (d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0) {
         // pure GEMM: every pixel is its own "image" (skips the per-row index decode in the kernel)

@@ -38,4 +38,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
+// exact GELU (nn.GELU default, approximate='none'): 0.5 x (1 + erf(x / sqrt(2)))
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,472 @@
+// Kernels around the GEMMs of the transformer-shaped stages (Swin + Query2Label, MS-TCT): LayerNorm with
+// row gather, multi-head attention core, patch extraction, small element-wise pieces.  All HBM-bound or tiny.
+#include "mt4_common.h"
+
+// ------------------------------------------------------------------------------------------------ vector helpers
+template <typename T> struct Vec;  // one 16-byte global vector <-> floats
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec<u16> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const u16* p, float* v) {
+        const uint4 t = *(const uint4*)p;
+        const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = bf16_to_f32((u16)(u[e] & 0xffff)); v[2 * e + 1] = bf16_to_f32((u16)(u[e] >> 16)); }
+    }
+    static __device__ __forceinline__ void store(u16* p, const float* v) {
+        *(uint4*)p = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    }
+};
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<u16>(const u16* p) { return bf16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<u16>(u16* p, float v) { *p = f32_to_bf16(v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm (+ row gather)
+// y[m][0..G*C) = LN( concat_g x[src(m,g)][0..C) ), src(m,g) = (m / L_out) * L_in + map[(m % L_out) * G + g]  (map NULL:
+// identity, G = 1).  One wave per output row, values kept in registers (two-pass mean / variance in fp32).
+template <typename T, int MAXCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ y, int M_out, int C, int G,
+                                                        const int* __restrict__ map, int L_out, int L_in, float eps) {
+    constexpr int V = Vec<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M_out) return;
+    const int N = G * C;
+    const int nch = N / V;
+    const int b = map ? m / L_out : 0, l = map ? m - b * L_out : 0;
+    float v[MAXCH][V];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nch) {
+            const int e = j * V;
+            const int g = e / C;
+            const long long src = map ? (long long)b * L_in + map[l * G + g] : m;
+            Vec<T>::load(x + src * C + (e - g * C), v[i]);
+#pragma unroll
+            for (int k = 0; k < V; ++k) sum += v[i][k];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)N;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        if (lane + 64 * i < nch) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) { const float d = v[i][k] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)N + eps);
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nch) {
+            const int e = j * V;
+            float o[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) o[k] = (v[i][k] - mean) * rstd * gamma[e + k] + beta[e + k];
+            Vec<T>::store(y + (long long)m * N + e, o);
+        }
+    }
+}
+
+extern "C" int mt4_layernorm(const void* x, const float* gamma, const float* beta, void* y, int32_t M_out, int32_t C, int32_t G,
+                             const int32_t* map, int32_t L_out, int32_t L_in, float eps, int32_t dtype, void* stream) {
+    mt4_clear_error();
+    if (!x || !gamma || !beta || !y || M_out <= 0 || C <= 0 || G <= 0) return MT4_EINVAL;
+    if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    if (map && (L_out <= 0 || L_in <= 0 || M_out % L_out != 0)) return MT4_EINVAL;
+    if (!map && G != 1) return MT4_EINVAL;
+    const int V = dtype == MT4_BF16 ? 8 : 4;
+    if (C % V != 0 || (((uintptr_t)x | (uintptr_t)y) & 15)) return MT4_EALIGN;
+    const int nch = G * C / V;
+    if (nch > 64 * 16) return MT4_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(cdiv(M_out, 4)), block(256);
+#define LN_LAUNCH(TT, MC) hipLaunchKernelGGL((layernorm_kernel<TT, MC>), grid, block, 0, s, (const TT*)x, gamma, beta, (TT*)y, M_out, C, G, map, L_out, L_in, eps)
+    const int need = cdiv(nch, 64);
+    if (dtype == MT4_BF16) {
+        if (need <= 2) LN_LAUNCH(u16, 2); else if (need <= 4) LN_LAUNCH(u16, 4); else if (need <= 8) LN_LAUNCH(u16, 8); else LN_LAUNCH(u16, 16);
+    } else {
+        if (need <= 2) LN_LAUNCH(float, 2); else if (need <= 4) LN_LAUNCH(float, 4); else if (need <= 8) LN_LAUNCH(float, 8); else LN_LAUNCH(float, 16);
+    }
+#undef LN_LAUNCH
+    return mt4_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ attention core
+// out[b,i,h,:] = softmax_j( scale * q[b,i,h,:].k[b,j,h,:] + bias[h,i,j] + mask[b % nW,i,j] ) v[b,j,h,:]
+// One query per LPQ lanes (each lane owns DPL head dims), keys/values staged in LDS as fp32 in chunks of KC keys,
+// online softmax in fp32.  Covers Swin windows (hd 32, N 49/144, bias + shift mask), nn.MultiheadAttention of the
+// Q2L transformer (hd 256) and the MS-TCT global block (hd 32..108, T 256).
+template <typename T, int DPL, int LPQ>
+__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                        T* __restrict__ out, const float* __restrict__ bias,
+                                                        const float* __restrict__ mask, int Nq, int Nk, int hd, int q_stride,
+                                                        int k_stride, int v_stride, int o_stride, int nW, float scale, int KC, int vec_ok) {
+    constexpr int SL = DPL + 4;        // slice stride in LDS (floats): staggers the LPQ slices over banks
+    constexpr int ROW = LPQ * SL;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ks = lds;
+    float* Vs = lds + (size_t)KC * ROW;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int qpb = blockDim.x / LPQ;
+    const int qi = blockIdx.x * qpb + tid / LPQ;
+    const int sl = tid % LPQ;
+    const bool q_ok = qi < Nq;
+    const int d0 = sl * DPL;
+
+    float qr[DPL], o[DPL];
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) {
+        o[d] = 0.f;
+        qr[d] = (q_ok && d0 + d < hd) ? ld1<T>(q + ((long long)b * Nq + qi) * q_stride + h * hd + d0 + d) * scale : 0.f;
+    }
+    float mrun = -INFINITY, lrun = 0.f;
+    const float* brow = (bias && q_ok) ? bias + ((long long)h * Nq + qi) * Nk : nullptr;
+    const float* mrow = (mask && q_ok) ? mask + ((long long)(b % nW) * Nq + qi) * Nk : nullptr;
+
+    const int hd4 = hd >> 2;  // hd % 4 == 0 (checked on the host)
+    for (int j0 = 0; j0 < Nk; j0 += KC) {
+        const int kc = min(KC, Nk - j0);
+        __syncthreads();  // previous chunk fully consumed
+        if ((hd & 3) == 0 && vec_ok) {
+            for (int e = tid; e < kc * hd4; e += blockDim.x) {
+                const int j = e / hd4, d = (e - j * hd4) * 4;
+                const int s_ = d / DPL, dd = d - s_ * DPL;  // DPL % 4 == 0: a 4-vector never straddles slices
+                const long long kr = ((long long)b * Nk + j0 + j);
+                float4 kv, vv;
+                if constexpr (sizeof(T) == 2) {
+                    const uint2 a = *(const uint2*)(k + kr * k_stride + h * hd + d);
+                    const uint2 c = *(const uint2*)(v + kr * v_stride + h * hd + d);
+                    kv = make_float4(bf16_to_f32((u16)(a.x & 0xffff)), bf16_to_f32((u16)(a.x >> 16)), bf16_to_f32((u16)(a.y & 0xffff)), bf16_to_f32((u16)(a.y >> 16)));
+                    vv = make_float4(bf16_to_f32((u16)(c.x & 0xffff)), bf16_to_f32((u16)(c.x >> 16)), bf16_to_f32((u16)(c.y & 0xffff)), bf16_to_f32((u16)(c.y >> 16)));
+                } else {
+                    kv = *(const float4*)(k + kr * k_stride + h * hd + d);
+                    vv = *(const float4*)(v + kr * v_stride + h * hd + d);
+                }
+                *(float4*)(Ks + j * ROW + s_ * SL + dd) = kv;
+                *(float4*)(Vs + j * ROW + s_ * SL + dd) = vv;
+            }
+        } else {  // odd head dims / unaligned strides: element-wise staging
+            for (int e = tid; e < kc * hd; e += blockDim.x) {
+                const int j = e / hd, d = e - j * hd;
+                const long long kr = ((long long)b * Nk + j0 + j);
+                Ks[j * ROW + (d / DPL) * SL + d % DPL] = ld1<T>(k + kr * k_stride + h * hd + d);
+                Vs[j * ROW + (d / DPL) * SL + d % DPL] = ld1<T>(v + kr * v_stride + h * hd + d);
+            }
+        }
+        // zero the padded head dims of this thread's slices once per chunk (qr is 0 there, V must not be NaN)
+        if (LPQ * DPL > hd) {
+            for (int e = tid; e < kc * (LPQ * DPL - hd); e += blockDim.x) {
+                const int j = e / (LPQ * DPL - hd), d = hd + (e - j * (LPQ * DPL - hd));
+                Ks[j * ROW + (d / DPL) * SL + d % DPL] = 0.f;
+                Vs[j * ROW + (d / DPL) * SL + d % DPL] = 0.f;
+            }
+        }
+        __syncthreads();
+        for (int j = 0; j < kc; j += 4) {
+            float sc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float acc = 0.f;
+                if (j + u < kc) {
+                    const float* kp = Ks + (j + u) * ROW + sl * SL;
+#pragma unroll
+                    for (int d = 0; d < DPL; d += 4) {
+                        const float4 kk = *(const float4*)(kp + d);
+                        acc += qr[d] * kk.x + qr[d + 1] * kk.y + qr[d + 2] * kk.z + qr[d + 3] * kk.w;
+                    }
+                }
+                sc[u] = acc;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int x_ = 1; x_ < LPQ; x_ <<= 1) sc[u] += __shfl_xor(sc[u], x_);
+                if (j + u < kc) {
+                    if (brow) sc[u] += brow[j0 + j + u];
+                    if (mrow) sc[u] += mrow[j0 + j + u];
+                } else {
+                    sc[u] = -INFINITY;
+                }
+            }
+            const float mnew = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), mrun);
+            const float corr = __expf(mrun - mnew);  // exp(-inf) = 0 on the first group
+            float p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = __expf(sc[u] - mnew);
+            lrun = lrun * corr + (p[0] + p[1]) + (p[2] + p[3]);
+            mrun = mnew;
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) o[d] *= corr;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j + u < kc) {
+                    const float* vp = Vs + (j + u) * ROW + sl * SL;
+#pragma unroll
+                    for (int d = 0; d < DPL; d += 4) {
+                        const float4 vv = *(const float4*)(vp + d);
+                        o[d] += p[u] * vv.x; o[d + 1] += p[u] * vv.y; o[d + 2] += p[u] * vv.z; o[d + 3] += p[u] * vv.w;
+                    }
+                }
+            }
+        }
+    }
+    if (q_ok) {
+        const float inv = 1.0f / lrun;
+        T* op = out + ((long long)b * Nq + qi) * o_stride + h * hd + d0;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d)
+            if (d0 + d < hd) st1<T>(op + d, o[d] * inv);
+    }
+}
+
+extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* out, const float* bias, const float* mask,
+                             int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t hd, int32_t q_stride, int32_t k_stride,
+                             int32_t v_stride, int32_t o_stride, int32_t nW, float scale, int32_t dtype, void* stream) {
+    mt4_clear_error();
+    if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || hd <= 0) return MT4_EINVAL;
+    if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    if (mask && nW <= 0) return MT4_EINVAL;
+    if (hd > 256 || B > 65535 || H > 65535) return MT4_EUNSUPPORTED;
+    const int es = dtype == MT4_BF16 ? 2 : 4;
+    // 4-element vector staging needs every (row, head) start 4-element aligned
+    const int vec_ok = (hd % 4 == 0) && (k_stride * es) % (4 * es) == 0 && (v_stride * es) % (4 * es) == 0 &&
+                       (((uintptr_t)k | (uintptr_t)v) & (4 * es - 1)) == 0;
+    hipStream_t s = (hipStream_t)stream;
+    // (DPL, LPQ) with DPL*LPQ >= hd, fewest lanes per query first
+    static const int cfgs[][2] = {{32, 1}, {24, 2}, {32, 2}, {20, 4}, {28, 4}, {32, 4}, {32, 8}};
+    int ci = -1;
+    for (int i = 0; i < 7; ++i)
+        if (cfgs[i][0] * cfgs[i][1] >= hd) { ci = i; break; }
+    if (ci < 0) return MT4_EUNSUPPORTED;
+    const int DPL = cfgs[ci][0], LPQ = cfgs[ci][1];
+    const int row = LPQ * (DPL + 4);
+    int KC = 8192 / row;             // 2 * KC * row * 4 bytes <= 64 KiB
+    KC = (KC / 4) * 4;
+    if (KC > ((Nk + 3) / 4) * 4) KC = ((Nk + 3) / 4) * 4;
+    const size_t lds = (size_t)2 * KC * row * sizeof(float);
+    int threads = ((Nq * LPQ + 63) / 64) * 64;
+    if (threads > 256) threads = 256;
+    const int qpb = threads / LPQ;
+    const dim3 grid(cdiv(Nq, qpb), H, B), block(threads);
+#define ATT_LAUNCH(TT, D, L) hipLaunchKernelGGL((attention_kernel<TT, D, L>), grid, block, lds, s, (const TT*)q, (const TT*)k, (const TT*)v, (TT*)out, bias, mask, Nq, Nk, hd, q_stride, k_stride, v_stride, o_stride, nW, scale, KC, vec_ok)
+#define ATT_DISPATCH(TT) switch (ci) { case 0: ATT_LAUNCH(TT, 32, 1); break; case 1: ATT_LAUNCH(TT, 24, 2); break; case 2: ATT_LAUNCH(TT, 32, 2); break; \
+        case 3: ATT_LAUNCH(TT, 20, 4); break; case 4: ATT_LAUNCH(TT, 28, 4); break; case 5: ATT_LAUNCH(TT, 32, 4); break; default: ATT_LAUNCH(TT, 32, 8); }
+    if (dtype == MT4_BF16) { ATT_DISPATCH(u16) } else { ATT_DISPATCH(float) }
+#undef ATT_DISPATCH
+#undef ATT_LAUNCH
+    return mt4_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ patch extraction
+// out[(b*Ph + ph)*Pw + pw][c*P*P + kh*P + kw] = img(b, c, P*ph + kh, P*pw + kw): the Conv2d(3, E, P, stride P) of
+// PatchEmbed becomes a GEMM with K = 3*P*P in the weight's own (c, kh, kw) order.
+template <typename T, bool FROM_U8>
+__global__ void patchify_kernel(const void* __restrict__ in, T* __restrict__ out, int B, int H, int W, int P, float m0, float m1,
+                                float m2, float s0, float s1, float s2) {
+    const int Ph = H / P, Pw = W / P, K = 3 * P * P;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * Ph * Pw * K) return;
+    const int kk = (int)(idx % K);
+    long long t = idx / K;
+    const int pw = (int)(t % Pw); t /= Pw;
+    const int ph = (int)(t % Ph);
+    const int b = (int)(t / Ph);
+    const int c = kk / (P * P), r = kk - c * P * P, kh = r / P, kw = r - kh * P;
+    const int y = ph * P + kh, x = pw * P + kw;
+    float v;
+    if (FROM_U8) {
+        const uint8_t px = ((const uint8_t*)in)[(((long long)b * H + y) * W + x) * 3 + c];
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        v = ((float)px / 255.0f - mean) / sd;
+    } else {
+        v = ((const float*)in)[(((long long)b * 3 + c) * H + y) * W + x];
+    }
+    st1<T>(out + idx, v);
+}
+
+extern "C" int mt4_patchify(const void* in, void* out, int32_t B, int32_t H, int32_t W, int32_t P, int32_t from_u8,
+                            const float mean[3], const float std[3], int32_t dtype, void* stream) {
+    mt4_clear_error();
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || P <= 0 || H % P || W % P) return MT4_EINVAL;
+    if (from_u8 && (!mean || !std)) return MT4_EINVAL;
+    if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    const long long total = (long long)B * (H / P) * (W / P) * 3 * P * P;
+    const int grid = (int)((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    const float m0 = from_u8 ? mean[0] : 0, m1 = from_u8 ? mean[1] : 0, m2 = from_u8 ? mean[2] : 0;
+    const float s0 = from_u8 ? std[0] : 1, s1 = from_u8 ? std[1] : 1, s2 = from_u8 ? std[2] : 1;
+    if (dtype == MT4_BF16) {
+        if (from_u8) hipLaunchKernelGGL((patchify_kernel<u16, true>), dim3(grid), dim3(256), 0, s, in, (u16*)out, B, H, W, P, m0, m1, m2, s0, s1, s2);
+        else hipLaunchKernelGGL((patchify_kernel<u16, false>), dim3(grid), dim3(256), 0, s, in, (u16*)out, B, H, W, P, m0, m1, m2, s0, s1, s2);
+    } else {
+        if (from_u8) hipLaunchKernelGGL((patchify_kernel<float, true>), dim3(grid), dim3(256), 0, s, in, (float*)out, B, H, W, P, m0, m1, m2, s0, s1, s2);
+        else hipLaunchKernelGGL((patchify_kernel<float, false>), dim3(grid), dim3(256), 0, s, in, (float*)out, B, H, W, P, m0, m1, m2, s0, s1, s2);
+    }
+    return mt4_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ y = x + p[row % L]
+template <typename T>
+__global__ void add_rowbcast_kernel(const T* __restrict__ x, const T* __restrict__ p, T* __restrict__ y, long long M, int L, int C) {
+    constexpr int V = Vec<T>::N;
+    const int cv = C / V;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * cv) return;
+    const long long m = idx / cv;
+    const int e = (int)(idx - m * cv) * V;
+    float a[V], b[V];
+    Vec<T>::load(x + m * C + e, a);
+    Vec<T>::load(p + (m % L) * C + e, b);
+#pragma unroll
+    for (int k = 0; k < V; ++k) a[k] += b[k];
+    Vec<T>::store(y + m * C + e, a);
+}
+
+extern "C" int mt4_add_rowbcast(const void* x, const void* p, void* y, int64_t M, int32_t L, int32_t C, int32_t dtype, void* stream) {
+    mt4_clear_error();
+    if (!x || !p || !y || M <= 0 || L <= 0 || C <= 0) return MT4_EINVAL;
+    if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    const int V = dtype == MT4_BF16 ? 8 : 4;
+    if (C % V || (((uintptr_t)x | (uintptr_t)p | (uintptr_t)y) & 15)) return MT4_EALIGN;
+    const long long total = M * (C / V);
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == MT4_BF16) hipLaunchKernelGGL(add_rowbcast_kernel<u16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u16*)x, (const u16*)p, (u16*)y, (long long)M, L, C);
+    else hipLaunchKernelGGL(add_rowbcast_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)p, (float*)y, (long long)M, L, C);
+    return mt4_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ GroupWiseLinear
+// out[b][k] = sum_d W[k][d] * hs[b][k][d] + bias[k]   (one wave per (b,k))
+template <typename T>
+__global__ void groupwise_linear_kernel(const T* __restrict__ hs, const float* __restrict__ w, const float* __restrict__ bias,
+                                        float* __restrict__ out, int BK, int K, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= BK) return;
+    const int kcls = r % K;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += ld1<T>(hs + (long long)r * D + d) * w[(long long)kcls * D + d];
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s + (bias ? bias[kcls] : 0.f);
+}
+
+extern "C" int mt4_groupwise_linear(const void* hs, const float* w, const float* bias, float* out, int32_t B, int32_t K, int32_t D,
+                                    int32_t dtype, void* stream) {
+    mt4_clear_error();
+    if (!hs || !w || !out || B <= 0 || K <= 0 || D <= 0) return MT4_EINVAL;
+    if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    const int grid = cdiv(B * K, 4);
+    if (dtype == MT4_BF16) hipLaunchKernelGGL(groupwise_linear_kernel<u16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u16*)hs, w, bias, out, B * K, K, D);
+    else hipLaunchKernelGGL(groupwise_linear_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)hs, w, bias, out, B * K, K, D);
+    return mt4_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise conv1d k3 (+GELU)
+// y[b][t][c] = act( w[c][0] x[b][t-1][c] + w[c][1] x[b][t][c] + w[c][2] x[b][t+1][c] + bias[c] ), zero padded in t
+template <typename T>
+__global__ void dwconv1d_k3_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                   T* __restrict__ y, int B, int Tn, int C, int act) {
+    constexpr int V = Vec<T>::N;
+    const int cv = C / V;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * Tn * cv) return;
+    const int e = (int)(idx % cv) * V;
+    const long long bt = idx / cv;
+    const int t = (int)(bt % Tn);
+    float xm[V], x0[V], xp[V], o[V];
+    Vec<T>::load(x + bt * C + e, x0);
+    if (t > 0) Vec<T>::load(x + (bt - 1) * C + e, xm);
+    else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) xm[k] = 0.f;
+    }
+    if (t + 1 < Tn) Vec<T>::load(x + (bt + 1) * C + e, xp);
+    else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) xp[k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const float* wc = w + (long long)(e + k) * 3;
+        float r = wc[0] * xm[k] + wc[1] * x0[k] + wc[2] * xp[k] + (bias ? bias[e + k] : 0.f);
+        if (act == 1) r = fmaxf(r, 0.f);
+        else if (act == 2) r = gelu_erf(r);
+        o[k] = r;
+    }
+    Vec<T>::store(y + bt * C + e, o);
+}
+
+extern "C" int mt4_dwconv1d_k3(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t T, int32_t C, int32_t act,
+                               int32_t dtype, void* stream) {
+    mt4_clear_error();
+    if (!x || !w || !y || B <= 0 || T <= 0 || C <= 0 || act < 0 || act > 2) return MT4_EINVAL;
+    if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    const int V = dtype == MT4_BF16 ? 8 : 4;
+    if (C % V || (((uintptr_t)x | (uintptr_t)y) & 15)) return MT4_EALIGN;
+    const long long total = (long long)B * T * (C / V);
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == MT4_BF16) hipLaunchKernelGGL(dwconv1d_k3_kernel<u16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u16*)x, w, bias, (u16*)y, B, T, C, act);
+    else hipLaunchKernelGGL(dwconv1d_k3_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, w, bias, (float*)y, B, T, C, act);
+    return mt4_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ KD teacher mixing
+// Spatial_cnn/network.py:56-62 in reduced form: the reference's [B,C,C] stack contracts to
+//   attn[b,c,n] = softmax_n( s[b,c] / sqrt(C) * sum_d tea_n[b,d] ),   out_n[b,c] = s[b,c] * attn[b,c,n]
+__global__ void kd_mix_kernel(const float* __restrict__ s, const float* __restrict__ t0, const float* __restrict__ t1,
+                              const float* __restrict__ t2, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2, int C) {
+    __shared__ float red[3][4];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        a0 += t0[(long long)b * C + c]; a1 += t1[(long long)b * C + c]; a2 += t2[(long long)b * C + c];
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) { red[0][wave] = a0; red[1][wave] = a1; red[2][wave] = a2; }
+    __syncthreads();
+    const float ts0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const float ts1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const float ts2 = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    const float inv = rsqrtf((float)C);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float sv = s[(long long)b * C + c];
+        const float z = sv * inv;
+        const float l0 = z * ts0, l1 = z * ts1, l2 = z * ts2;
+        const float mx = fmaxf(l0, fmaxf(l1, l2));
+        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = expf(l2 - mx);
+        const float r = 1.0f / (e0 + e1 + e2);
+        o0[(long long)b * C + c] = sv * e0 * r;
+        o1[(long long)b * C + c] = sv * e1 * r;
+        o2[(long long)b * C + c] = sv * e2 * r;
+    }
+}
+
+extern "C" int mt4_kd_mix(const float* s, const float* tea_i, const float* tea_v, const float* tea_t, float* out_i, float* out_v,
+                          float* out_t, int32_t B, int32_t C, void* stream) {
+    mt4_clear_error();
+    if (!s || !tea_i || !tea_v || !tea_t || !out_i || !out_v || !out_t || B <= 0 || C <= 0) return MT4_EINVAL;
+    hipLaunchKernelGGL(kd_mix_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, s, tea_i, tea_v, tea_t, out_i, out_v, out_t, C);
+    return mt4_check_launch();
+}

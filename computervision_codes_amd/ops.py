@@ -64,7 +64,8 @@ def conv_out_size(h: int, k: int, stride: int, pad: int, dil: int) -> int:
 def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, kh: int, kw: int,
               stride: Tuple[int, int] = (1, 1), pad: Tuple[int, int] = (0, 0), dil: Tuple[int, int] = (1, 1),
               residual: Optional[torch.Tensor] = None, relu: bool = False, out_dtype: Optional[torch.dtype] = None,
-              out: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, tile: int = 0, act: Optional[str] = None,
+              out_row_map: Optional[torch.Tensor] = None, y_ld: int = 0, res_ld: int = 0) -> torch.Tensor:
     """y = act(conv(x, w) + bias [+ residual]); x [B,H,W,Cin] contiguous channels-last storage."""
     _need_cuda(x, w_packed, bias, residual)
     assert x.dim() == 4 and x.is_contiguous()
@@ -74,18 +75,28 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     wo = conv_out_size(w_, kw, stride[1], pad[1], dil[1])
     od = out_dtype or x.dtype
     if out is None:
+        assert y_ld == 0
         out = torch.empty((b, ho, wo, cout), dtype=od, device=x.device)
-    else:
+    elif y_ld == 0:
         assert out.is_contiguous() and out.numel() == b * ho * wo * cout and out.dtype == od
+    else:  # `out` is a column-slice view of a [rows, y_ld] buffer: its data_ptr is the slice start
+        assert out.dtype == od and out.stride(-1) == 1
     if residual is not None:
-        assert residual.is_contiguous() and residual.dtype == x.dtype and residual.numel() == out.numel()
+        assert residual.dtype == x.dtype and residual.stride(-1) == 1
+        if res_ld == 0:
+            assert residual.is_contiguous() and residual.numel() == b * ho * wo * cout
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == cout
     assert w_packed.dtype == x.dtype and w_packed.shape[1] == packed_k(cin, kh, kw, x.dtype)
+    act_code = {None: 1 if relu else 0, "none": 0, "relu": 1, "gelu": 2}[act]
+    if out_row_map is not None:
+        assert out_row_map.dtype == torch.int32 and out_row_map.is_cuda and out_row_map.is_contiguous()
+        assert (b * ho * wo) % out_row_map.numel() == 0
     d = ConvDesc(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
                  residual.data_ptr() if residual is not None else None, out.data_ptr(),
+                 out_row_map.data_ptr() if out_row_map is not None else None,
                  b, h, w_, cin, ho, wo, cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1],
-                 1 if relu else 0, dt_code(x.dtype), dt_code(od), tile)
+                 act_code, dt_code(x.dtype), dt_code(od), tile, out_row_map.numel() if out_row_map is not None else 0, y_ld, res_ld)
     check(lib.mt4_conv_nhwc(C.byref(d), _stream()), "mt4_conv_nhwc")
     return out
 
@@ -146,3 +157,112 @@ def linear_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -
     check(lib.mt4_linear_f32(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), b, k, n,
                              _stream()), "mt4_linear_f32")
     return y
+
+
+# ----------------------------------------------------------------------------------------- transformer-stage pieces
+def linear(x2d: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, act: Optional[str] = None,
+           residual: Optional[torch.Tensor] = None, out_row_map: Optional[torch.Tensor] = None,
+           out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Linear / 1x1 conv on rows: y[M,N] = act(x[M,K] @ W^T + b [+ residual]) through the conv kernel's GEMM mode.
+    `out` / `residual` may be column slices ([:, a:b]) of wider row-major buffers."""
+    m, k = x2d.shape
+    y_ld = 0 if out is None or out.is_contiguous() else out.stride(0)
+    res_ld = 0 if residual is None or residual.is_contiguous() else residual.stride(0)
+    y = conv_nhwc(x2d.view(m, 1, 1, k), w_packed, bias, kh=1, kw=1, residual=residual, act=act, out_row_map=out_row_map,
+                  out_dtype=out_dtype, out=out, y_ld=y_ld, res_ld=res_ld)
+    return y if out is not None else y.view(m, -1)
+
+
+def pack_linear_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[N,K] (or Conv1d/2d 1x1 [N,K,1(,1)]) float32 -> packed GEMM weight"""
+    w = w.reshape(w.shape[0], -1)
+    return pack_conv_weight(w[:, :, None, None], None, dtype)
+
+
+def layernorm(x2d: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, row_map: Optional[torch.Tensor] = None, group: int = 1,
+              l_out: int = 0, l_in: int = 0, m_out: Optional[int] = None, eps: float = 1e-5) -> torch.Tensor:
+    _need_cuda(x2d, gamma, beta, row_map)
+    assert x2d.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    m_in, c = x2d.shape
+    m_out = m_in if m_out is None else m_out
+    assert gamma.numel() == group * c
+    y = torch.empty((m_out, group * c), dtype=x2d.dtype, device=x2d.device)
+    check(lib.mt4_layernorm(x2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), m_out, c, group,
+                            row_map.data_ptr() if row_map is not None else None, l_out, l_in, eps, dt_code(x2d.dtype), _stream()),
+          "mt4_layernorm")
+    return y
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, batch: int, heads: int, nq: int, nk: int, hd: int,
+              q_stride: int, k_stride: int, v_stride: int, scale: float, bias: Optional[torch.Tensor] = None,
+              mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q/k/v may be views into one packed projection buffer (pointer + row stride addressing)."""
+    _need_cuda(q, k, v, bias, mask)
+    out = torch.empty((batch * nq, heads * hd), dtype=q.dtype, device=q.device)
+    nw = mask.shape[0] if mask is not None else 1
+    if bias is not None:
+        assert bias.dtype == torch.float32 and tuple(bias.shape) == (heads, nq, nk) and bias.is_contiguous()
+    if mask is not None:
+        assert mask.dtype == torch.float32 and tuple(mask.shape[1:]) == (nq, nk) and mask.is_contiguous() and batch % nw == 0
+    check(lib.mt4_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), bias.data_ptr() if bias is not None else None,
+                            mask.data_ptr() if mask is not None else None, batch, heads, nq, nk, hd, q_stride, k_stride, v_stride,
+                            heads * hd, nw, scale, dt_code(q.dtype), _stream()), "mt4_attention")
+    return out
+
+
+def patchify(img: torch.Tensor, patch: int, dtype: torch.dtype, mean=None, std=None) -> torch.Tensor:
+    """float32 NCHW [B,3,H,W] (normalised) or uint8 NHWC [B,H,W,3] -> [B*H/P*W/P, 3*P*P] rows"""
+    _need_cuda(img)
+    img = img.contiguous()
+    from_u8 = img.dtype == torch.uint8
+    if from_u8:
+        b, h, w, _ = img.shape
+    else:
+        assert img.dtype == torch.float32
+        b, _, h, w = img.shape
+    out = torch.empty((b * (h // patch) * (w // patch), 3 * patch * patch), dtype=dtype, device=img.device)
+    z = _lib._FLOAT3(0, 0, 0)
+    check(lib.mt4_patchify(img.data_ptr(), out.data_ptr(), b, h, w, patch, 1 if from_u8 else 0,
+                           _lib._FLOAT3(*mean) if from_u8 else z, _lib._FLOAT3(*std) if from_u8 else z, dt_code(dtype), _stream()),
+          "mt4_patchify")
+    return out
+
+
+def add_rowbcast(x2d: torch.Tensor, p2d: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x2d, p2d)
+    assert x2d.is_contiguous() and p2d.is_contiguous() and x2d.dtype == p2d.dtype and x2d.shape[1] == p2d.shape[1]
+    y = torch.empty_like(x2d)
+    check(lib.mt4_add_rowbcast(x2d.data_ptr(), p2d.data_ptr(), y.data_ptr(), x2d.shape[0], p2d.shape[0], x2d.shape[1],
+                               dt_code(x2d.dtype), _stream()), "mt4_add_rowbcast")
+    return y
+
+
+def groupwise_linear(hs: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], batch: int, k: int) -> torch.Tensor:
+    _need_cuda(hs, w, bias)
+    assert hs.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
+    d = hs.shape[-1]
+    out = torch.empty((batch, k), dtype=torch.float32, device=hs.device)
+    check(lib.mt4_groupwise_linear(hs.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), batch, k, d,
+                                   dt_code(hs.dtype), _stream()), "mt4_groupwise_linear")
+    return out
+
+
+def dwconv1d_k3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: str = "none") -> torch.Tensor:
+    """x [B,T,C]; w float32 [C,3]"""
+    _need_cuda(x, w, bias)
+    assert x.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
+    b, t, c = x.shape
+    y = torch.empty_like(x)
+    check(lib.mt4_dwconv1d_k3(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), b, t, c,
+                              {"none": 0, "relu": 1, "gelu": 2}[act], dt_code(x.dtype), _stream()), "mt4_dwconv1d_k3")
+    return y
+
+
+def kd_mix(s: torch.Tensor, ti: torch.Tensor, tv: torch.Tensor, tt: torch.Tensor):
+    _need_cuda(s, ti, tv, tt)
+    for t in (s, ti, tv, tt):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == s.shape
+    outs = [torch.empty_like(s) for _ in range(3)]
+    check(lib.mt4_kd_mix(s.data_ptr(), ti.data_ptr(), tv.data_ptr(), tt.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(),
+                         outs[2].data_ptr(), s.shape[0], s.shape[1], _stream()), "mt4_kd_mix")
+    return tuple(outs)

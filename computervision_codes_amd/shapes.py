@@ -113,3 +113,125 @@ def spatial_cnn_shapes(network: str = "resnet50", student_dim: int | None = None
             t.append((f"classifier_{task}.fc.weight", (k, c)))
             t.append((f"classifier_{task}.fc.bias", (k,)))
     return t
+
+
+# --------------------------------------------------------------------------- Swin + Q2L (parameters only)
+SWIN_CFG = {  # `Spatial_transformer/models/swin_transformer.py:596-631`
+    "swin_T_224_1k": dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window_size=7),
+    "swin_B_224_22k": dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), window_size=7),
+    "swin_B_384_22k": dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), window_size=12),
+    "swin_L_224_22k": dict(embed_dim=192, depths=(2, 2, 18, 2), num_heads=(6, 12, 24, 48), window_size=7),
+    "swin_L_384_22k": dict(embed_dim=192, depths=(2, 2, 18, 2), num_heads=(6, 12, 24, 48), window_size=12),
+}
+# non-parameter state-dict entries (recomputed, never filled): `attn.relative_position_index`, `attn_mask`, `backbone.1.pe`
+SWIN_BUFFER_SUFFIXES = ("relative_position_index", "attn_mask", ".pe")
+
+
+def swin_window(name: str, img_size: int, stage: int):
+    """effective (window, resolution) of a stage (`swin_transformer.py:193-196`)"""
+    cfg = SWIN_CFG[name]
+    res = img_size // 4 // (2 ** stage)
+    ws = cfg["window_size"]
+    return (min(ws, res), res)
+
+
+def swin_param_shapes(name: str, img_size: int, prefix: str = "") -> Table:
+    """Parameters of `SwinTransformer` without avgpool/head (`backbone.py:198-201`), registration order."""
+    cfg = SWIN_CFG[name]
+    e = cfg["embed_dim"]
+    t: Table = [(prefix + "patch_embed.proj.weight", (e, 3, 4, 4)), (prefix + "patch_embed.proj.bias", (e,)),
+                (prefix + "patch_embed.norm.weight", (e,)), (prefix + "patch_embed.norm.bias", (e,))]
+    for s, (depth, nh) in enumerate(zip(cfg["depths"], cfg["num_heads"])):
+        c = e * 2 ** s
+        ws, _ = swin_window(name, img_size, s)
+        for b in range(depth):
+            p = f"{prefix}layers.{s}.blocks.{b}."
+            t += [(p + "norm1.weight", (c,)), (p + "norm1.bias", (c,)),
+                  (p + "attn.relative_position_bias_table", ((2 * ws - 1) ** 2, nh)),
+                  (p + "attn.qkv.weight", (3 * c, c)), (p + "attn.qkv.bias", (3 * c,)),
+                  (p + "attn.proj.weight", (c, c)), (p + "attn.proj.bias", (c,)),
+                  (p + "norm2.weight", (c,)), (p + "norm2.bias", (c,)),
+                  (p + "mlp.fc1.weight", (4 * c, c)), (p + "mlp.fc1.bias", (4 * c,)),
+                  (p + "mlp.fc2.weight", (c, 4 * c)), (p + "mlp.fc2.bias", (c,))]
+        if s < 3:
+            p = f"{prefix}layers.{s}.downsample."
+            t += [(p + "reduction.weight", (2 * c, 4 * c)), (p + "norm.weight", (4 * c,)), (p + "norm.bias", (4 * c,))]
+    t += [(prefix + "norm.weight", (8 * e,)), (prefix + "norm.bias", (8 * e,))]
+    return t
+
+
+def q2l_transformer_shapes(prefix: str, d: int, ffn: int = 8192) -> Table:
+    """`build_transformer` (`transformer.py:347-359`): 1 encoder layer, 2 decoder layers without self-attn."""
+    t: Table = []
+
+    def mha(p):
+        t.extend([(p + ".in_proj_weight", (3 * d, d)), (p + ".in_proj_bias", (3 * d,)), (p + ".out_proj.weight", (d, d)),
+                  (p + ".out_proj.bias", (d,))])
+
+    def ffn_(p):
+        t.extend([(p + ".linear1.weight", (ffn, d)), (p + ".linear1.bias", (ffn,)), (p + ".linear2.weight", (d, ffn)),
+                  (p + ".linear2.bias", (d,))])
+
+    def ln(p):
+        t.extend([(p + ".weight", (d,)), (p + ".bias", (d,))])
+
+    e = prefix + "encoder.layers.0"
+    mha(e + ".self_attn"); ffn_(e); ln(e + ".norm1"); ln(e + ".norm2")
+    for i in range(2):
+        q = f"{prefix}decoder.layers.{i}"
+        mha(q + ".multihead_attn"); ffn_(q); ln(q + ".norm2"); ln(q + ".norm3")
+    ln(prefix + "decoder.norm")
+    return t
+
+
+def q2l_param_shapes(backbone: str, img_size: int, hidden_dim: int, loss_type: str) -> Table:
+    """`Qeruy2Label` (`Spatial_transformer/network.py:48-80`) for a single-task loss_type: backbone.0.* + one Decoder."""
+    assert loss_type in ("i", "v", "t")
+    k = {"i": 6, "v": 10, "t": 15}[loss_type]
+    c = SWIN_CFG[backbone]["embed_dim"] * 8
+    t = swin_param_shapes(backbone, img_size, prefix="backbone.0.")
+    p = f"decoder_{loss_type}."
+    t += q2l_transformer_shapes(p + "transformer.", hidden_dim)
+    t += [(p + "input_proj.weight", (hidden_dim, c, 1, 1)), (p + "input_proj.bias", (hidden_dim,)),
+          (p + "query_embed.weight", (k, hidden_dim)), (p + "fc.W", (1, k, hidden_dim)), (p + "fc.b", (1, k))]
+    return t
+
+
+# --------------------------------------------------------------------------- MS-TCT
+def mstct_shapes(in_feat_dim: int = 2048, inter_channels=(256, 384, 576, 864), num_block: int = 2, mlp_ratio: int = 8,
+                 final_dim: int = 512, loss_type: str = "ivt") -> Table:
+    """`Temporal_mstct/network.py:48-73` VideoNas (TemporalEncoder, Temporal_Mixer, one Classifier)."""
+    t: Table = []
+
+    def lin(p, o, i):
+        t.extend([(p + ".weight", (o, i)), (p + ".bias", (o,))])
+
+    def ln(p, c):
+        t.extend([(p + ".weight", (c,)), (p + ".bias", (c,))])
+
+    cin = in_feat_dim
+    for s, c in enumerate(inter_channels, start=1):
+        m = f"TemporalEncoder.Temporal_Merging_Block{s}"
+        t.extend([(m + ".proj.weight", (c, cin, 3)), (m + ".proj.bias", (c,))])
+        ln(m + ".norm", c)
+        for b in range(num_block):
+            q = f"TemporalEncoder.block{s}.{b}"
+            ln(q + ".norm1", c)
+            g = q + ".Global_Relational_Block"
+            lin(g + ".q", c, c); lin(g + ".kv", 2 * c, c); lin(g + ".proj", c, c)
+            ln(q + ".norm2", c)
+            l = q + ".Local_Relational_Block"
+            lin(l + ".linear1", mlp_ratio * c, c)
+            t.extend([(l + ".TC.weight", (mlp_ratio * c, 1, 3)), (l + ".TC.bias", (mlp_ratio * c,))])
+            lin(l + ".linear2", c, mlp_ratio * c)
+        ln(f"TemporalEncoder.norm{s}", c)
+        cin = c
+    for i, c in zip((4, 3, 2, 1), reversed(inter_channels)):
+        lin(f"Temporal_Mixer.linear_f{i}.proj", final_dim, c)
+    for i in range(1, 10):
+        t.extend([(f"Temporal_Mixer.linear{i}.weight", (final_dim, final_dim, 1)), (f"Temporal_Mixer.linear{i}.bias", (final_dim,))])
+    k = {"i": 6, "v": 10, "t": 15, "ivt": 100}[loss_type]
+    q = f"classifier_{loss_type}"
+    t.extend([(q + ".linear_fuse.weight", (final_dim, 4 * final_dim, 1)), (q + ".linear_fuse.bias", (final_dim,)),
+              (q + ".linear_pred.weight", (k, final_dim, 1)), (q + ".linear_pred.bias", (k,))])
+    return t

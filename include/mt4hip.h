@@ -57,16 +57,23 @@ typedef struct mt4_conv_desc {
     const float* bias;
     const void* residual;
     void* y;
+    const int32_t* out_row_map; /* optional [out_row_map_len]: result (and residual) row of pixel m is
+                                   (m / len) * len + map[m % len] -- Swin window-reverse + roll-back folded into
+                                   the projection's epilogue (swin_transformer.py:255-265); NULL = identity */
     int32_t B, H, W, Cin;
     int32_t Ho, Wo, Cout;
     int32_t KH, KW;
     int32_t stride_h, stride_w;
     int32_t pad_h, pad_w;
     int32_t dil_h, dil_w;
-    int32_t relu;       /* 0 / 1 */
+    int32_t relu;       /* activation: 0 none, 1 ReLU, 2 GELU (erf form, nn.GELU default) */
     int32_t dtype;      /* MT4_F32 / MT4_BF16 : x, w, residual */
     int32_t out_dtype;  /* MT4_F32 / MT4_BF16 : y */
     int32_t tile;       /* 0 = auto; else a tile id from mt4_conv_tile_count() (for tuning/tests) */
+    int32_t out_row_map_len;
+    int32_t y_ld;       /* row pitch of y in elements (0 = Cout): lets a GEMM write a column slice of a wider buffer
+                           (Temporal_Mixer's channel concat, TS_Mixer.py:83) */
+    int32_t res_ld;     /* row pitch of residual in elements (0 = Cout) */
 } mt4_conv_desc;
 
 int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream);
@@ -80,15 +87,15 @@ int mt4_pack_conv_weight(const float* w_oihw, const float* scale, void* w_packed
                          int32_t KH, int32_t KW, int32_t dtype, void* stream);
 
 /* ResNet stem 7x7/2 pad 3, Cin=3 (resnet.py:145): the frame is stored padded as
- * [B][H+7][W+8][4] (3 rows/cols of zeros before, 4 rows / 5 cols after; 4th channel zero) so that a
+ * [B][H+6][Wp][4], Wp = round_up(W+6, 2) (3 rows/cols of zeros around, 4th channel zero) so that a
  * kernel row is one contiguous 32-element run; the stem then runs through mt4_conv_nhwc on the
- * view [B][H+7][(W+8)/2][8] with KH=7, KW=4, stride (2,1), pad 0.  This packs its weights:
+ * pixel-pair view [B][H+6][Wp/2][8] with KH=7, KW=4, stride (2,1), pad 0.  This packs its weights:
  * w_oihw [64][3][7][7] -> [Cout][Kpad(8,7,4)] with taps (kh, kw/2), channel slot (kw%2)*4 + c. */
 int mt4_pack_stem_weight(const float* w_oihw, const float* scale, void* w_packed, int32_t Cout, int32_t dtype,
                          void* stream);
 
-/* uint8 frames [B][H][W][3] -> normalised, zero-padded [B][H+7][W+8][4] of dtype
- * ((v/255 - mean[c]) / std[c]; ToTensor+Normalize of Spatial_cnn/dataloader.py:153-162). W % 2 == 0. */
+/* uint8 frames [B][H][W][3] -> normalised, zero-padded [B][H+6][Wp][4] of dtype
+ * ((v/255 - mean[c]) / std[c]; ToTensor+Normalize of Spatial_cnn/dataloader.py:153-162). */
 int mt4_preprocess_u8(const uint8_t* frames, void* out, int32_t B, int32_t H, int32_t W, const float mean[3],
                       const float std[3], int32_t dtype, void* stream);
 /* same from already-normalised float32 NCHW [B][3][H][W] (the reference's module-call boundary) */
@@ -104,6 +111,55 @@ int mt4_global_avgpool_nhwc(const void* x, float* y, int32_t B, int32_t HW, int3
  * the four heads concatenated along N). */
 int mt4_linear_f32(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t K, int32_t N,
                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Transformer-shaped stages (Swin + Query2Label under Spatial_transformer/, MS-TCT under Temporal_mstct/).
+ * Every nn.Linear / 1x1 conv of those stages runs through mt4_conv_nhwc (KH=KW=1, act = GELU where the
+ * reference applies nn.GELU); the entry points below are the pieces between the GEMMs.
+ */
+
+/* LayerNorm over the last dimension with an optional row gather in front:
+ *   y[m][0..G*C) = LN( concat_{g<G} x[src(m,g)][0..C) ) * gamma + beta,
+ *   src(m,g) = (m / L_out) * L_in + map[(m % L_out) * G + g]      (map NULL: src = m, G must be 1)
+ * G=1 + map: norm1 + cyclic shift + window partition of a Swin block (swin_transformer.py:241-252);
+ * G=4 + map: PatchMerging's 2x2 gather + norm (swin_transformer.py:320-326); no map: plain nn.LayerNorm.
+ * x, y: dtype; gamma, beta: float32 [G*C]. C*esize % 16 == 0. */
+int mt4_layernorm(const void* x, const float* gamma, const float* beta, void* y, int32_t M_out, int32_t C, int32_t G,
+                  const int32_t* map, int32_t L_out, int32_t L_in, float eps, int32_t dtype, void* stream);
+
+/* Multi-head attention core (no projections):
+ *   out[b,i,h,:] = softmax_j( scale * <q[b,i,h,:], k[b,j,h,:]> + bias[h,i,j] + mask[b % nW,i,j] ) . v[b,j,h,:]
+ * q/k/v/out row (b*N + i) starts at ptr + row*stride (elements), head h at +h*hd.  bias [H][Nq][Nk] and
+ * mask [nW][Nq][Nk] are float32 or NULL.  Replaces WindowAttention's core (swin_transformer.py:120-141, with the
+ * relative-position bias gathered to dense form at load time and the -100 shift mask), nn.MultiheadAttention's
+ * core in the Q2L transformer (transformer.py:186-189,275-283) and Global_Relational_Block (Temporal_Encoder.py:
+ * 80-86).  hd <= 256. */
+int mt4_attention(const void* q, const void* k, const void* v, void* out, const float* bias, const float* mask, int32_t B,
+                  int32_t H, int32_t Nq, int32_t Nk, int32_t hd, int32_t q_stride, int32_t k_stride, int32_t v_stride,
+                  int32_t o_stride, int32_t nW, float scale, int32_t dtype, void* stream);
+
+/* Non-overlapping PxP patches as GEMM rows: out[(b*H/P + ph)*W/P + pw][c*P*P + kh*P + kw] (PatchEmbed.proj,
+ * swin_transformer.py:435,446).  in: normalised float32 NCHW, or (from_u8) uint8 NHWC frames normalised on the fly. */
+int mt4_patchify(const void* in, void* out, int32_t B, int32_t H, int32_t W, int32_t P, int32_t from_u8, const float mean[3],
+                 const float std[3], int32_t dtype, void* stream);
+
+/* y[m][:] = x[m][:] + p[m % L][:]   (with_pos_embed, transformer.py:176-178: the sine position code / query
+ * embedding is the same for every batch element) */
+int mt4_add_rowbcast(const void* x, const void* p, void* y, int64_t M, int32_t L, int32_t C, int32_t dtype, void* stream);
+
+/* GroupWiseLinear (Spatial_transformer/network.py:40-45): out[b][k] = sum_d W[k][d]*hs[b][k][d] + bias[k], float32 out */
+int mt4_groupwise_linear(const void* hs, const float* w, const float* bias, float* out, int32_t B, int32_t K, int32_t D,
+                         int32_t dtype, void* stream);
+
+/* Depthwise Conv1d(k=3, pad=1, groups=C) over time on [B][T][C] + bias + activation (0 none / 1 ReLU / 2 GELU):
+ * Local_Relational_Block.TC followed by its GELU (Temporal_Encoder.py:36-40).  w float32 [C][3]. */
+int mt4_dwconv1d_k3(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t T, int32_t C, int32_t act,
+                    int32_t dtype, void* stream);
+
+/* Train-time teacher mixing of the KD branch (Spatial_cnn/network.py:56-62) in its reduced form, float32:
+ * out_n[b][c] = s[b][c] * softmax_n( s[b][c]/sqrt(C) * sum_d tea_n[b][d] ), n in {i,v,t}. */
+int mt4_kd_mix(const float* s, const float* tea_i, const float* tea_v, const float* tea_t, float* out_i, float* out_v,
+               float* out_t, int32_t B, int32_t C, void* stream);
 
 #ifdef __cplusplus
 }

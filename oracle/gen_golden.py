@@ -170,9 +170,161 @@ def gen_cnn(name):
     print(name, "ok: feat", tuple(feat.shape), "absmean", float(feat.abs().mean()), "logit_ivt absmax", float(livt.abs().max()))
 
 
+# ------------------------------------------------------------------------------------------ swin + q2l, ms-tct
+def _install_timm_stub():
+    """`swin_transformer.py:10`, `Temporal_Encoder.py:1` import 3 symbols from timm (absent here)."""
+    if "timm" in sys.modules:
+        return
+    timm = types.ModuleType("timm"); models = types.ModuleType("timm.models"); layers = types.ModuleType("timm.models.layers")
+
+    class DropPath(torch.nn.Module):  # eval-mode identity (drop_prob only acts in training)
+        def __init__(self, drop_prob=0.0):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            return x
+
+    layers.DropPath = DropPath
+    layers.to_2tuple = lambda x: tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+    layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    timm.models = models; models.layers = layers
+    sys.modules["timm"] = timm; sys.modules["timm.models"] = models; sys.modules["timm.models.layers"] = layers
+
+
+def _check_params(table, module, what, buffers_ok=()):
+    params = dict(module.named_parameters())
+    names = [k for k, _ in table]
+    assert names == list(params.keys()), f"{what}: parameter name/order mismatch {set(names) ^ set(params.keys())}"
+    for k, shp in table:
+        assert tuple(params[k].shape) == tuple(shp), f"{what}: {k} {tuple(params[k].shape)} != {shp}"
+    for k in module.state_dict():
+        assert k in params or k.endswith(tuple(buffers_ok)), f"{what}: unexpected non-parameter entry {k}"
+
+
+class _RefQ2L(torch.nn.Module):
+    """Assembles the reference's own classes the way `build_q2l`/`build_backbone` do (`network.py:187-204`,
+    `backbone.py:188-201,218-220`) without importing `models/__init__.py`/`utils.misc` (they pull torchvision)."""
+
+    def __init__(self, backbone, img_size, hidden_dim, loss_type):
+        super().__init__()
+        _install_timm_stub()
+        sm = _load_by_path("ref_swin", os.path.join(REF, "Spatial_transformer", "models", "swin_transformer.py"))
+        tm = _load_by_path("ref_q2l_transformer", os.path.join(REF, "Spatial_transformer", "models", "transformer.py"))
+        pm = _load_by_path("ref_posenc", os.path.join(REF, "Spatial_transformer", "models", "position_encoding.py"))
+        cfg = shapes.SWIN_CFG[backbone]
+        # build_swin_transformer asserts a name list that excludes swin_B_224_22k although its config exists
+        # (swin_transformer.py:597): construct SwinTransformer directly with the table's parameters
+        bb = sm.SwinTransformer(img_size=img_size, num_classes=1000, embed_dim=cfg["embed_dim"], depths=list(cfg["depths"]),
+                                num_heads=list(cfg["num_heads"]), window_size=cfg["window_size"])
+        bb.forward = bb.forward_features
+        del bb.avgpool
+        del bb.head
+        pe = pm.PositionEmbeddingSine(hidden_dim // 2, normalize=True, maxH=img_size // 32, maxW=img_size // 32)
+        self.backbone = torch.nn.Sequential(bb, pe)
+        a = types.SimpleNamespace(hidden_dim=hidden_dim)
+        self.transformer_obj = [tm.build_transformer(a)]
+        # Decoder / GroupWiseLinear live in network.py, whose imports need torchvision: load it with stub modules
+        for name in ("models", "models.backbone", "models.transformer", "utils", "utils.misc"):
+            if name not in sys.modules:
+                sys.modules[name] = types.ModuleType(name)
+        sys.modules["models.backbone"].build_backbone = None
+        sys.modules["models.transformer"].build_transformer = tm.build_transformer
+        sys.modules["utils.misc"].clean_state_dict = None
+        nm = _load_by_path("ref_q2l_network", os.path.join(REF, "Spatial_transformer", "network.py"))
+        k = {"i": 6, "v": 10, "t": 15}[loss_type]
+        setattr(self, f"decoder_{loss_type}", nm.Decoder(cfg["embed_dim"] * 8, self.transformer_obj[0], k))
+        self.loss_type = loss_type
+
+    def forward(self, x):
+        src = self.backbone[0](x)
+        pos = self.backbone[1](src).to(src.dtype)
+        return getattr(self, f"decoder_{self.loss_type}")([src], [pos])
+
+
+Q2L_CASES = {
+    "q2l_swinT_224_i": dict(backbone="swin_T_224_1k", img=224, hidden=768, loss_type="i", B=2, seed=301),
+    "q2l_swinB_224_v": dict(backbone="swin_B_224_22k", img=224, hidden=1024, loss_type="v", B=1, seed=302),
+    "q2l_swinB_384_t": dict(backbone="swin_B_384_22k", img=384, hidden=1024, loss_type="t", B=1, seed=303),
+}
+
+
+def gen_q2l(name):
+    from oracle import swin_q2l as o_q2l
+    cfg = Q2L_CASES[name]
+    m = _RefQ2L(cfg["backbone"], cfg["img"], cfg["hidden"], cfg["loss_type"]).eval()
+    table = shapes.q2l_param_shapes(cfg["backbone"], cfg["img"], cfg["hidden"], cfg["loss_type"])
+    _check_params(table, m, name, buffers_ok=shapes.SWIN_BUFFER_SUFFIXES)
+    sd = synth.fill_from_shapes(table, seed=cfg["seed"])
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith(shapes.SWIN_BUFFER_SUFFIXES) for k in missing.missing_keys), missing
+    img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["img"], cfg["img"], seed=cfg["seed"]))
+    feat, y = m(img)
+    src = m.backbone[0](img)
+    out = o_q2l.q2l_forward(sd, img, cfg["backbone"], cfg["img"], cfg["hidden"], cfg["loss_type"])
+    ofeat = out[3][0]
+    oy = {"i": out[0][1], "v": out[1][1], "t": out[2][1]}[cfg["loss_type"]]
+    osrc = o_q2l.swin_forward_features(sd, img, cfg["backbone"], cfg["img"], prefix="backbone.0.")
+    assert _rel(osrc, src) < 2e-5, (name, "src", _rel(osrc, src))
+    assert _rel(oy, y) < 2e-5 and _rel(ofeat, feat) < 2e-5, (name, _rel(oy, y), _rel(ofeat, feat))
+    flat = src.flatten()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), logits=y.numpy(), feat=feat.numpy(),
+                        src_sample=flat[:: max(1, flat.numel() // 8192)].numpy(),
+                        src_stats=np.array([flat.mean(), flat.abs().mean(), flat.norm()], dtype=np.float64), cfg=np.array(repr(cfg)))
+    print(name, "ok: logits", y.shape, "absmax", float(y.abs().max()), "src absmean", float(src.abs().mean()))
+
+
+def _ref_mstct(cfg):
+    _install_timm_stub()
+    import sklearn.manifold  # `Temporal_mstct/network.py:35-38` builds a TSNE at import with a removed kwarg
+    _orig = sklearn.manifold.TSNE
+    sklearn.manifold.TSNE = lambda *a, **k: None
+    torch.Tensor.cuda = lambda self, *a, **k: self  # `network.py:85-88`
+    sys.path.insert(0, os.path.join(REF, "Temporal_mstct"))
+    try:
+        for n in [k for k in sys.modules if k == "MSTCT" or k.startswith("MSTCT.")]:
+            del sys.modules[n]
+        mod = _load_by_path("ref_mstct_network", os.path.join(REF, "Temporal_mstct", "network.py"))
+    finally:
+        sys.path.pop(0)
+        sklearn.manifold.TSNE = _orig
+    args = types.SimpleNamespace(loss_type=cfg["loss_type"])
+    return mod.VideoNas(args, list(cfg["inter"]), 2, 8, 8, cfg["D"], cfg["final"]).eval()
+
+
+MSTCT_CASES = {
+    "mstct_tiny": dict(D=64, inter=(32, 48, 64, 96), final=32, T=40, B=2, loss_type="ivt", seed=401),
+    "mstct_full_i": dict(D=1024, inter=(256, 384, 576, 864), final=512, T=256, B=1, loss_type="i", seed=402),
+    "mstct_full_ivt_ragged": dict(D=2048, inter=(256, 384, 576, 864), final=512, T=101, B=2, loss_type="ivt", seed=403),
+}
+
+
+def gen_mstct(name):
+    from oracle import mstct as o_mstct
+    cfg = MSTCT_CASES[name]
+    m = _ref_mstct(cfg)
+    table = shapes.mstct_shapes(cfg["D"], cfg["inter"], 2, 8, cfg["final"], cfg["loss_type"])
+    _check_table(table, m.state_dict(), name)
+    sd = synth.fill_from_shapes(table, seed=cfg["seed"])
+    m.load_state_dict(sd, strict=True)
+    x = torch.cat([synth.synthetic_features(cfg["T"], cfg["D"], seed=cfg["seed"] + b) for b in range(cfg["B"])], 0).permute(0, 2, 1).contiguous()
+    ref = m(x)
+    ora = o_mstct.mstct_forward(sd, x, cfg["loss_type"])
+    gi = {"i": 0, "v": 1, "t": 2, "ivt": 3}[cfg["loss_type"]]
+    y, concat = ref[gi][0], ref[3][1]
+    assert _rel(ora[gi][0], y) < 2e-5 and _rel(ora[3][1], concat) < 2e-5, (name, _rel(ora[gi][0], y), _rel(ora[3][1], concat))
+    flat = concat.flatten()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), logits=y.numpy(),
+                        concat_sample=flat[:: max(1, flat.numel() // 8192)].numpy(),
+                        concat_stats=np.array([flat.mean(), flat.abs().mean(), flat.norm()], dtype=np.float64), cfg=np.array(repr(cfg)))
+    print(name, "ok: logits", y.shape, "absmax", float(y.abs().max()), "concat absmean", float(concat.abs().mean()))
+
+
 GENERATORS = {}
 GENERATORS.update({k: gen_tenco for k in TENCO_CASES})
 GENERATORS.update({k: gen_cnn for k in CNN_CASES})
+GENERATORS.update({k: gen_q2l for k in Q2L_CASES})
+GENERATORS.update({k: gen_mstct for k in MSTCT_CASES})
 
 
 def main(argv):

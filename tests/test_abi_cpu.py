@@ -26,7 +26,7 @@ def test_header_symbols_all_exported_and_bound():
 
 def test_abi_version_and_error_strings():
     from computervision_codes_amd import _lib
-    assert _lib.lib.mt4_abi_version() == 1
+    assert _lib.lib.mt4_abi_version() == 2
     assert _lib.lib.mt4_strerror(0) == b"ok"
     assert b"invalid" in _lib.lib.mt4_strerror(-1)
 
@@ -53,5 +53,5 @@ def test_ops_refuse_cpu_tensors():
 
 def test_struct_layout_matches_header():
     from computervision_codes_amd import _lib
-    # 5 pointers + 19 int32
-    assert ctypes.sizeof(_lib.ConvDesc) == 5 * 8 + 19 * 4 + 4  # padded to 8
+    # 6 pointers + 22 int32
+    assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 22 * 4
