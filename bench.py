@@ -85,10 +85,25 @@ def time_conv_kernels(model, frames, iters=3):
     return per_launch_ms
 
 
+def host_cores():
+    """cores this process may actually use: cgroup quota, else affinity, else cpu_count"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(float(q) / float(p) + 0.5))
+    except Exception:
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline_spatial(network, h, w, seed):
     """CPU oracle (port of the reference arithmetic) on the host cores, bounded sample."""
     from computervision_codes_amd import shapes, synth
     from oracle import spatial_cnn as o_cnn
+    torch.set_num_threads(min(host_cores(), 64))
     sd = synth.fill_from_shapes(shapes.spatial_cnn_shapes(network), seed=seed)
     bs = 8
     img = synth.normalize_frames(synth.synthetic_frames(bs, h, w, seed=seed))
@@ -106,9 +121,28 @@ def cpu_baseline_spatial(network, h, w, seed):
                 sample=f"{n} batches of {bs} frames {h}x{w}, torch-CPU fp32 oracle, eval, no_grad")
 
 
+def _time_call(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
 def temporal_bench(dev, do_cpu):
-    """per-video latency of the 4-stage Temporal_tenco head (D=512) at T=256 and T=2000, and config 1."""
+    """per-video latency of the Temporal_tenco head (4-stage D=512 at T=256 / T=2000, BASELINE config 1) and of the
+    MS-TCT teacher on one 256-frame window; eager launches and hipGraph replay."""
     from computervision_codes_amd import shapes, synth
+    from computervision_codes_amd.graph import GraphedForward
+    from computervision_codes_amd.temporal_mstct import VideoNas as MstctNas
     from computervision_codes_amd.temporal_tenco import VideoNas
     out = {}
     cases = [("tenco4_T256", dict(num_R=3, dim=512, fpn=True, T=256)), ("tenco4_T2000", dict(num_R=3, dim=512, fpn=True, T=2000)),
@@ -119,25 +153,15 @@ def temporal_bench(dev, do_cpu):
         sd = synth.fill_from_shapes(table, seed=47)
         m = VideoNas(args, 11, 10, c["num_R"], 512, c["dim"], 100).eval().load_state_dict(sd)
         x = synth.synthetic_features(c["T"], c["dim"], seed=47).to(dev)
-        for _ in range(3):
-            m(x, False)
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(10):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            m(x, False)
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        ts.sort()
-        lat = ts[len(ts) // 2]
+        eager = _time_call(lambda: m(x, False))
+        g = GraphedForward(lambda xx: m(xx, False), [x])
+        lat = _time_call(lambda: g(x))
         nparam = sum(v.numel() for v in sd.values())
         L = 11 + 10 * c["num_R"]
         nlev = 4 if c["fpn"] else 1
         alg_bytes = 4 * (nparam + c["T"] * (c["dim"] + 2 * 512 * L + nlev * (131 if c["fpn"] else 100)))
         flops = 2 * c["T"] * (c["dim"] * 512 + L * (512 * 1536 + 512 * 512) + (3 * 512 * 512 + nlev * 131 * 512 if c["fpn"] else 100 * 512))
-        rec = dict(ms_per_video=round(lat, 4), T=c["T"], algorithmic_MB=round(alg_bytes / 1e6, 1),
+        rec = dict(ms_per_video=round(lat, 4), ms_per_video_eager=round(eager, 4), T=c["T"], algorithmic_MB=round(alg_bytes / 1e6, 1),
                    hbm_frac=round(alg_bytes / (lat * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                    f32_mfma_frac=round(flops / (lat * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
         if do_cpu:
@@ -152,6 +176,44 @@ def temporal_bench(dev, do_cpu):
                     n += 1
                 rec["cpu_ms_per_video"] = round((time.perf_counter() - t0) / n * 1e3, 2)
         out[name] = rec
+    # MS-TCT teacher, one 256-frame window, D=2048 (Temporal_mstct/run.py:306-313)
+    a = types.SimpleNamespace(loss_type="ivt")
+    sd = synth.fill_from_shapes(shapes.mstct_shapes(2048, (256, 384, 576, 864), 2, 8, 512, "ivt"), seed=47)
+    m = MstctNas(a, [256, 384, 576, 864], 2, 8, 8, 2048, 512).eval().load_state_dict(sd)
+    x = synth.synthetic_features(256, 2048, seed=47).to(dev)
+    eager = _time_call(lambda: m.forward_btd(x))
+    g = GraphedForward(lambda xx: m.forward_btd(xx), [x])
+    rec = dict(ms_per_window=round(_time_call(lambda: g(x)), 4), ms_per_window_eager=round(eager, 4), T=256, gflop=31.4)
+    if do_cpu:
+        from oracle import mstct as o_mstct
+        xc = x.cpu().permute(0, 2, 1).contiguous()
+        with torch.no_grad():
+            o_mstct.mstct_forward(sd, xc, "ivt")
+            t0 = time.perf_counter()
+            n = 0
+            while n < 5 and time.perf_counter() - t0 < 4.0:
+                o_mstct.mstct_forward(sd, xc, "ivt")
+                n += 1
+            rec["cpu_ms_per_window"] = round((time.perf_counter() - t0) / n * 1e3, 2)
+    out["mstct_T256"] = rec
+    return out
+
+
+def swin_bench(dev, batch=32):
+    """BASELINE configs[2]: Swin-B + Q2L head, bf16, frames/s at 384x384 (reference-legal swin_B_384_22k) and 224x224."""
+    from computervision_codes_amd import shapes, synth
+    from computervision_codes_amd.spatial_transformer import build_q2l
+    out = {}
+    for name, img in (("swin_B_384_22k", 384), ("swin_B_224_22k", 224)):
+        args = types.SimpleNamespace(backbone=name, img_size=img, hidden_dim=1024, loss_type="i")
+        m = build_q2l(args, dtype=torch.bfloat16, device=str(dev)).eval()
+        m.load_state_dict(synth.fill_from_shapes(shapes.q2l_param_shapes(name, img, 1024, "i"), seed=7))
+        frames = synth.synthetic_frames(batch, img, img, seed=7).to(dev)
+        ms = _time_call(lambda: m(frames), iters=5)
+        gf = (94.2 + 15.3) if img == 384 else (30.9 + 10.2)
+        out[f"{name}"] = dict(frames_per_s=round(batch / ms * 1e3, 1), ms_per_batch=round(ms, 3), batch=batch,
+                              mfma_frac=round(gf * 1e9 * batch / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
+        del m
     return out
 
 
@@ -241,6 +303,7 @@ def main():
         }
         if world == 1 and not a.no_temporal:
             res["temporal"] = temporal_bench(dev, do_cpu=not a.no_cpu_baseline)
+            res["swin_q2l"] = swin_bench(dev)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_spatial(a.network, a.height, a.width, 1234)
             res["gpu_over_cpu"] = round(fps / res["cpu_baseline"]["value"], 1)

@@ -1,0 +1,74 @@
+"""CholecT45/T50 on-disk layout (SURVEY 8(b) "Labels"): `<data_dir>/data/VIDnn/%06d.png`,
+`<data_dir>/{triplet,instrument,verb,target}/VIDnn.txt` (CSV int: col 0 frame id, cols 1.. multi-hot).
+Split tables as in `Spatial_cnn/dataloader.py:112-148`; the extraction variant lists ALL videos
+(`dataloader_test.py:87-88`).  CPU side only (PNG decode + resize): the normalisation runs on the GPU."""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+# official cross-validation folds / fixed splits (dataset metadata)
+_SPLITS = {
+    "cholect45-crossval": {1: [79, 2, 51, 6, 25, 14, 66, 23, 50], 2: [80, 32, 5, 15, 40, 47, 26, 48, 70],
+                           3: [31, 57, 36, 18, 52, 68, 10, 8, 73], 4: [42, 29, 60, 27, 65, 75, 22, 49, 12],
+                           5: [78, 43, 62, 35, 74, 1, 56, 4, 13]},
+    "cholect50-crossval": {1: [79, 2, 51, 6, 25, 14, 66, 23, 50, 111], 2: [80, 32, 5, 15, 40, 47, 26, 48, 70, 96],
+                           3: [31, 57, 36, 18, 52, 68, 10, 8, 73, 103], 4: [42, 29, 60, 27, 65, 75, 22, 49, 12, 110],
+                           5: [78, 43, 62, 35, 74, 1, 56, 4, 13, 92]},
+    "cholect50": {"train": [1, 15, 26, 40, 52, 65, 79, 2, 18, 27, 43, 56, 66, 92, 4, 22, 31, 47, 57, 68, 96, 5, 23, 35, 48, 60, 70,
+                            103, 13, 25, 36, 49, 62, 75, 110], "val": [8, 12, 29, 50, 78], "test": [6, 51, 10, 73, 14, 74, 32, 80, 42, 111]},
+    "cholect50-challenge": {"train": [1, 15, 26, 40, 52, 79, 2, 27, 43, 56, 66, 4, 22, 31, 47, 57, 68, 23, 35, 48, 60, 70, 13, 25, 49, 62,
+                                      75, 8, 12, 29, 50, 78, 6, 51, 10, 73, 14, 32, 80, 42], "val": [5, 18, 36, 65, 74],
+                            "test": [92, 96, 103, 110, 111]},
+    "cholect45-challenge": {"train": [1, 15, 26, 40, 52, 79, 2, 27, 43, 56, 66, 4, 22, 31, 47, 57, 5, 23, 35, 48, 60, 18, 13, 25, 49, 62,
+                                      65, 8, 12, 29, 50, 78, 6, 51, 10, 36, 14, 32, 80, 42], "val": [68, 70, 73, 74, 75],
+                            "test": [92, 96, 103, 110, 111]},
+}
+_SPLITS["cholect45"] = _SPLITS["cholect45-crossval"]
+
+
+def video_name(v: int) -> str:
+    return "VID{}".format(str(v).zfill(2))
+
+
+def split_videos(variant: str, test_fold: int) -> Tuple[List[str], List[str], List[str]]:
+    """(train, val, test) video names; crossval: val = last 5 train videos (`dataloader.py:77-84`)."""
+    if variant not in _SPLITS:
+        raise ValueError(f"{variant} is not a valid dataset variant")
+    sp = _SPLITS[variant]
+    if "crossval" in variant or variant == "cholect45":
+        train = [v for k in sp if k != test_fold for v in sp[k]]
+        test = list(sp[test_fold])
+        train, val = train[:-5], train[-5:]
+    else:
+        train, val, test = list(sp["train"]), list(sp["val"]), list(sp["test"])
+    return [video_name(v) for v in train], [video_name(v) for v in val], [video_name(v) for v in test]
+
+
+def extraction_videos(variant: str, test_fold: int) -> List[str]:
+    """all videos in the order train + test + val (`dataloader_test.py:88`)"""
+    tr, va, te = split_videos(variant, test_fold)
+    return tr + te + va
+
+
+def load_labels(data_dir: str, video: str) -> Dict[str, np.ndarray]:
+    out = {}
+    for key, sub in (("ivt", "triplet"), ("i", "instrument"), ("v", "verb"), ("t", "target")):
+        a = np.loadtxt(os.path.join(data_dir, sub, f"{video}.txt"), dtype=np.int64, delimiter=",", ndmin=2)
+        out[key] = a
+    return out
+
+
+def load_frames_u8(data_dir: str, video: str, frame_ids, height: int = 256, width: int = 448) -> np.ndarray:
+    """decode + `Resize((height,width))` (bilinear, as torchvision does on PIL images; `dataloader.py:155-159`) -> uint8 [N,H,W,3]"""
+    from PIL import Image
+    out = np.empty((len(frame_ids), height, width, 3), np.uint8)
+    for i, fid in enumerate(frame_ids):
+        with Image.open(os.path.join(data_dir, "data", video, "{}.png".format(str(int(fid)).zfill(6)))) as im:
+            im = im.convert("RGB")
+            if im.size != (width, height):
+                im = im.resize((width, height), Image.BILINEAR)
+            out[i] = np.asarray(im)
+    return out

@@ -1,0 +1,205 @@
+"""Stage drivers behind the reference's `Scripts/` entry points (SURVEY 8(b) "CLI"): same flag names, relative paths
+(`./__checkpoint__/run_<version>/`, `../0-5fold/data_feats/run_<version>/`), checkpoint names and feature-file layout
+as `Spatial_cnn/test.py`, `Spatial_transformer/test.py`, `Temporal_mstct/test.py` and `Temporal_tenco/run.py -e`.
+Unknown flags are ignored like the reference's `parse_known_args`.  Two additions: `--dtype {fp32,bf16}` and, when
+torch.distributed is initialised (torchrun), whole videos are sharded over ranks (extract.shard_videos)."""
+from __future__ import annotations
+
+import argparse
+import os
+import pickle
+import time
+import types
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from . import cholect, extract, featfile
+from .metrics import Recognition
+
+
+def _common(p: argparse.ArgumentParser):
+    p.add_argument("--model", type=str, default="rendezvous")
+    p.add_argument("--version", type=str, default="")
+    p.add_argument("--version1", type=str, default="")
+    p.add_argument("-t", "--train", action="store_true")
+    p.add_argument("-e", "--test", action="store_true")
+    p.add_argument("--data_dir", type=str, default="/home/shuangchun/Data/Video/CholecT45/CholecT45")
+    p.add_argument("--dataset_variant", type=str, default="cholect45-crossval")
+    p.add_argument("-k", "--kfold", type=int, default=1)
+    p.add_argument("--image_width", type=int, default=448)
+    p.add_argument("--image_height", type=int, default=256)
+    p.add_argument("-b", "--batch", type=int, default=32)
+    p.add_argument("--loss_type", type=str, default="all")
+    p.add_argument("--test_ckpt", type=str, default=None)
+    p.add_argument("--gpu", type=str, default="0")
+    p.add_argument("--seed", type=int, default=47)
+    p.add_argument("--dtype", type=str, default="fp32", choices=["fp32", "bf16"])
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _log(path: str, msg: str):
+    print(msg)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "a+") as f:
+        print(msg, file=f)
+
+
+def _sigmoid(x: torch.Tensor) -> np.ndarray:
+    return torch.sigmoid(x.float()).cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ Spatial_cnn/test.py
+def spatial_cnn_test(argv=None) -> Dict[str, np.ndarray]:
+    from .spatial_cnn import VideoNas
+    p = argparse.ArgumentParser()
+    _common(p)
+    p.add_argument("--network", type=str, default="resnet18")
+    p.add_argument("--student_dim", type=int, default=512)
+    p.add_argument("--teacher_dim", type=int, default=1536)
+    F, _ = p.parse_known_args(argv)
+    F.train = False
+    rank, world = _dist()
+    modelname = f"{F.model}_l{F.dataset_variant}_cholect{F.kfold}"   # `test.py:126-128`
+    model_dir = f"./__checkpoint__/run_{F.version}"
+    logfile = os.path.join(model_dir, modelname + ".log")
+    ckpt = F.test_ckpt or f"./__checkpoint__/run_{F.version}/rendezvous_l{F.dataset_variant}_cholect{F.kfold}.pth"
+    model = VideoNas(args=F, dtype=torch.float32 if F.dtype == "fp32" else torch.bfloat16).eval()
+    model.load_state_dict(torch.load(ckpt, map_location="cpu"))
+    videos = cholect.extraction_videos(F.dataset_variant, F.kfold)
+    labels = {v: cholect.load_labels(F.data_dir, v) for v in videos}
+    mine = extract.shard_videos(videos, [len(labels[v]["ivt"]) for v in videos], rank, world)
+    t0 = time.time()
+    m = {k: Recognition(n) for k, n in (("i", 6), ("v", 10), ("t", 15), ("ivt", 100))}
+    feats_local: Dict[str, np.ndarray] = {}
+    for vi in mine:
+        v = videos[vi]
+        lab = labels[v]
+        chunks = []
+        for s in range(0, len(lab["ivt"]), F.batch):           # file order, no shuffle, drop_last False
+            ids = lab["ivt"][s:s + F.batch, 0]
+            fr = torch.from_numpy(cholect.load_frames_u8(F.data_dir, v, ids, F.image_height, F.image_width)).cuda()
+            (_, li), (_, lv), (_, lt), (feat, livt) = model.extract_u8(fr)
+            chunks.append(feat.float().cpu())
+            for key, lg in (("i", li), ("v", lv), ("t", lt), ("ivt", livt)):
+                m[key].update(lab[key][s:s + F.batch, 1:], _sigmoid(lg))
+        for r in m.values():
+            r.video_end()
+        feats_local[featfile.video_key(v)] = torch.vstack(chunks).numpy()
+    merged = extract.gather_feats(feats_local)
+    all_feats = {featfile.video_key(v): merged[featfile.video_key(v)] for v in videos}
+    if rank == 0:
+        featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type), all_feats)
+        _log(logfile, f"save time:::::: : {time.time() - t0:.4f} secs")
+        _log(logfile, " ".join(f"AP_{k}={m[k].compute_video_AP()['mAP']:.4f}" for k in m) + f" (rank-0 videos, world={world})")
+    return all_feats
+
+
+# ------------------------------------------------------------------------------------------------ Temporal_tenco/run.py -e
+def tenco_eval(argv=None) -> Dict[str, float]:
+    from .temporal_tenco import VideoNas
+    p = argparse.ArgumentParser()
+    _common(p)
+    p.add_argument("--num_layers_PG", default=11, type=int)
+    p.add_argument("--num_layers_R", default=10, type=int)
+    p.add_argument("--num_R", default=3, type=int)
+    p.add_argument("--fpn", action="store_true")
+    p.add_argument("--mask", action="store_true")
+    p.add_argument("--output", default=False, type=bool)
+    p.add_argument("--hier", default=False, type=bool)
+    p.add_argument("--input_dim", type=int, default=512)
+    F, _ = p.parse_known_args(argv)
+    if F.train:
+        raise NotImplementedError("training (-t) is not built yet; use -e")
+    modelname = f"{F.model}_l8_cholect{F.dataset_variant}_k{F.kfold}_batchnorm_lowres"   # `run.py:137-142`
+    model_dir = f"./__checkpoint__/run_{F.version}"
+    logfile = os.path.join(model_dir, modelname + ".log")
+    ckpt = F.test_ckpt or os.path.join(model_dir, modelname + ".pth")
+    model = VideoNas(F, F.num_layers_PG, F.num_layers_R, F.num_R, 512, F.input_dim, 100).eval()
+    sd = torch.load(ckpt, map_location="cpu")
+    model.load_state_dict({k: v for k, v in sd.items() if k in dict(model._table)}, strict=False)   # `run.py:520`
+    _, _, test_videos = cholect.split_videos(F.dataset_variant, F.kfold)
+    feats = featfile.read_feats(featfile.feats_path("..", F.version1, F.kfold, "all"))
+    m = {k: Recognition(n) for k, n in (("i", 6), ("v", 10), ("t", 15), ("ivt", 100))}
+    t0 = time.time()
+    for v in test_videos:
+        lab = cholect.load_labels(F.data_dir, v)
+        x = torch.from_numpy(feats[featfile.video_key(v)]).unsqueeze(0).cuda()
+        out, out_i, out_v, out_t, _, _ = model(x, False)
+        for key, lg in (("ivt", out), ("i", out_i), ("v", out_v), ("t", out_t)):   # finest FPN level, [K,T] -> [T,K]
+            m[key].update(lab[key][:, 1:], _sigmoid(lg[0][0].transpose(0, 1)))
+            m[key].video_end()
+    res = {f"AP_{k}": m[k].compute_video_AP()["mAP"] for k in m}
+    _log(logfile, f"eta {time.time() - t0:.3f} secs " + " ".join(f"{k}={v:.4f}" for k, v in res.items()))
+    with open(os.path.join(model_dir, modelname + "_test_mAP.pkl"), "wb") as f:
+        pickle.dump({k: {"targets": m[k].global_targets, "predictions": m[k].global_predictions} for k in m}, f)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ Spatial_transformer/test.py
+def spatial_transformer_test(argv=None) -> Dict[str, np.ndarray]:
+    from .spatial_transformer import build_q2l
+    p = argparse.ArgumentParser()
+    _common(p)
+    p.add_argument("--backbone", type=str, default="swin_L_384_22k")
+    p.add_argument("--img_size", type=int, default=384)
+    p.add_argument("--hidden_dim", type=int, default=1536)
+    F, _ = p.parse_known_args(argv)
+    version = F.version + ("_" + F.loss_type if F.loss_type != "all" else "")          # `test.py:94-95`
+    ckpt = F.test_ckpt or f"./__checkpoint__/run_{version}/rendezvous_l{F.dataset_variant}_cholect{F.kfold}.pth"
+    model = build_q2l(F, dtype=torch.float32 if F.dtype == "fp32" else torch.bfloat16).eval()
+    model.load_state_dict(torch.load(ckpt, map_location="cpu"), strict=True)
+    rank, world = _dist()
+    videos = cholect.extraction_videos(F.dataset_variant, F.kfold)
+    labels = {v: cholect.load_labels(F.data_dir, v) for v in videos}
+    mine = extract.shard_videos(videos, [len(labels[v]["ivt"]) for v in videos], rank, world)
+    feats_local = {}
+    for vi in mine:
+        v, chunks = videos[vi], []
+        ids_all = labels[v]["ivt"][:, 0]
+        for s in range(0, len(ids_all), F.batch):
+            fr = torch.from_numpy(cholect.load_frames_u8(F.data_dir, v, ids_all[s:s + F.batch], F.img_size, F.img_size)).cuda()
+            chunks.append(model(fr)[3][0].float().cpu())
+        feats_local[featfile.video_key(v, "transformer")] = torch.vstack(chunks).numpy()
+    merged = extract.gather_feats(feats_local)
+    if rank == 0:
+        featfile.write_feats(featfile.feats_path("..", version, F.kfold, F.loss_type), merged)
+    return merged
+
+
+# ------------------------------------------------------------------------------------------------ Temporal_mstct/test.py
+def mstct_test(argv=None):
+    from .temporal_mstct import VideoNas
+    p = argparse.ArgumentParser()
+    _common(p)
+    p.add_argument("--input_dim", type=int, default=1536)
+    p.add_argument("--final_embedding_dim", type=int, default=512)
+    F, _ = p.parse_known_args(argv)
+    F.in_feat_dim = F.input_dim
+    model_dir = f"./__checkpoint__/run_{F.version}"
+    modelname = f"{F.model}_l8_cholect{F.dataset_variant}_k{F.kfold}_batchnorm_lowres"
+    ckpt = F.test_ckpt or os.path.join(model_dir, modelname + "latest.pth")              # no underscore (`run.py:268`)
+    model = VideoNas(F, [256, 384, 576, 864], 2, 8, 8, F.input_dim, F.final_embedding_dim,
+                     dtype=torch.float32 if F.dtype == "fp32" else torch.bfloat16).eval()
+    model.load_state_dict(torch.load(ckpt, map_location="cpu"))
+    feats = featfile.read_feats(featfile.feats_path("..", F.version1 + ("_" + F.loss_type if F.loss_type != "all" else ""), F.kfold, F.loss_type))
+    out_feats, out_preds = {}, {}
+    gi = {"i": 0, "v": 1, "t": 2, "ivt": 3}[F.loss_type]
+    for key, f in feats.items():
+        fs, ps = [], []
+        for s in range(0, f.shape[0], 256):                                                # non-overlapping 256-frame chunks
+            x = torch.from_numpy(f[s:s + 256]).unsqueeze(0).cuda()
+            o = model.forward_btd(x)
+            ps.append(o[gi][0][0].float().cpu())                                           # raw logits [T,K]
+            fs.append(o[3][1][0].transpose(0, 1).float().cpu())                            # concat feature [T,2048]
+        out_feats[key], out_preds[key] = torch.vstack(fs).numpy(), torch.vstack(ps).numpy()
+    featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type, "feats"), out_feats)
+    featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type, "pred"), out_preds)
+    return out_feats, out_preds

@@ -1,0 +1,58 @@
+"""CPU: dataset layout reader, metric restatement and feature-file plumbing used by the Scripts/ entry points."""
+import os
+
+import numpy as np
+import pytest
+
+from computervision_codes_amd import cholect, metrics
+
+
+def test_split_tables_shape():
+    for fold in range(1, 6):
+        tr, va, te = cholect.split_videos("cholect45-crossval", fold)
+        assert len(tr) == 31 and len(va) == 5 and len(te) == 9
+        assert len(set(tr + va + te)) == 45
+    assert cholect.split_videos("cholect45-crossval", 1)[2][0] == "VID79"
+    allv = cholect.extraction_videos("cholect45-crossval", 2)
+    assert len(allv) == 45 and allv[-5:] == cholect.split_videos("cholect45-crossval", 2)[1]
+    tr, va, te = cholect.split_videos("cholect50", 1)
+    assert (len(tr), len(va), len(te)) == (35, 5, 10)
+    with pytest.raises(ValueError):
+        cholect.split_videos("nope", 1)
+
+
+def test_labels_and_frames_roundtrip(tmp_path):
+    from PIL import Image
+    d = tmp_path
+    for sub in ("triplet", "instrument", "verb", "target", "data/VID01"):
+        os.makedirs(d / sub)
+    rng = np.random.default_rng(0)
+    for sub, k in (("triplet", 100), ("instrument", 6), ("verb", 10), ("target", 15)):
+        lab = np.concatenate([np.arange(4)[:, None], (rng.random((4, k)) < 0.2).astype(int)], 1)
+        np.savetxt(d / sub / "VID01.txt", lab, fmt="%d", delimiter=",")
+    imgs = rng.integers(0, 255, (4, 20, 30, 3), dtype=np.uint8)
+    for i in range(4):
+        Image.fromarray(imgs[i]).save(d / "data" / "VID01" / f"{i:06d}.png")
+    lab = cholect.load_labels(str(d), "VID01")
+    assert lab["ivt"].shape == (4, 101) and lab["i"].shape == (4, 7)
+    fr = cholect.load_frames_u8(str(d), "VID01", lab["ivt"][:, 0], 20, 30)
+    assert np.array_equal(fr, imgs)                       # same size: no resampling
+    assert cholect.load_frames_u8(str(d), "VID01", [0], 10, 16).shape == (1, 10, 16, 3)
+
+
+def test_recognition_ap_matches_sklearn():
+    from sklearn.metrics import average_precision_score
+    rng = np.random.default_rng(1)
+    r = metrics.Recognition(6)
+    aps = []
+    for _ in range(3):                                     # 3 videos
+        t = (rng.random((50, 6)) < 0.3).astype(float)
+        t[:, 5] = 0                                        # a class without positives -> NaN, skipped
+        p = rng.random((50, 6))
+        r.update(t[:20], p[:20]); r.update(t[20:], p[20:]); r.video_end()
+        aps.append([average_precision_score(t[:, c], p[:, c]) if t[:, c].sum() else np.nan for c in range(6)])
+    res = r.compute_video_AP()
+    want = np.nanmean(np.array(aps), 0)
+    assert np.allclose(res["AP"][:5], want[:5]) and np.isnan(res["AP"][5])
+    assert abs(res["mAP"] - np.nanmean(want)) < 1e-12
+    assert 0.0 <= r.topK(5) <= 1.0
