@@ -17,6 +17,33 @@
 #include "mt4_common.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor (stride 0, num_records = bytes, gfx9 data-format word) from wave-uniform values
+__device__ __forceinline__ v4u make_srd(const void* p, unsigned bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    v4u r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)u);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+
+// one LDS-DMA piece: 64 lanes x 16 B from buffer offset `voff` (per lane) to LDS [lds_addr + lane*16); out-of-range
+// lanes write zeros.  M0 (the DMA's LDS base) is compiler-reserved: saved, set and restored inside the statement.
+__device__ __forceinline__ void lds_dma16(v4u srd, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(srd), "s"(lds_addr)
+        : "memory");
+}
 
 struct ConvK {
     const char* x;
@@ -30,6 +57,7 @@ struct ConvK {
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, sh, sw, ph, pw, dh, dw, relu;  // relu: 0 none, 1 ReLU, 2 GELU(erf)
     int M, HoWo, CPT, SPT, taps, nsteps, n_tiles, total_tiles;
     long long x_img_bytes;  // H*W*Cin*esize
+    unsigned x_bytes, w_bytes;  // buffer sizes for the LDS-DMA range check (FAST path; < 2 GiB)
     int w_row_bytes;        // nsteps*128
 };
 
@@ -71,105 +99,29 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
     const int ld_row = tid >> 3, ld_chunk = tid & 7;
     const int st_off = ld_row * 128 + ((ld_chunk ^ (ld_row & 7)) << 4);
 
-    // ---- per-thread staging rows: NLD_X pixel rows, then NLD_W weight rows
-    const char* px_base[NLD_X];
-    int px_hi0[NLD_X], px_wi0[NLD_X];
-    bool px_ok[NLD_X];
-#pragma unroll
-    for (int i = 0; i < NLD_X; ++i) {
-        const int m = m0 + ld_row + 32 * i;
-        px_ok[i] = m < a.M;
-        const int mm = px_ok[i] ? m : 0;
-        if (a.HoWo == 1) {  // pure GEMM (1x1, stride 1, no padding): pixel m is row m, no index decode
-            px_hi0[i] = 0;
-            px_wi0[i] = 0;
-            px_base[i] = a.x + (long long)mm * a.x_img_bytes;
-        } else {
-            const int b = mm / a.HoWo;
-            const int rem = mm - b * a.HoWo;
-            const int ho = rem / a.Wo;
-            const int wo = rem - ho * a.Wo;
-            px_hi0[i] = ho * a.sh - a.ph;
-            px_wi0[i] = wo * a.sw - a.pw;
-            px_base[i] = a.x + (long long)b * a.x_img_bytes;
-        }
-    }
-    const char* w_ptr[NLD_W];
-    bool w_ok[NLD_W];
-#pragma unroll
-    for (int i = 0; i < NLD_W; ++i) {
-        const int n = n0 + ld_row + 32 * i;
-        w_ok[i] = n < a.Cout;
-        w_ptr[i] = a.w + (long long)(w_ok[i] ? n : 0) * a.w_row_bytes + ld_chunk * 16;
-    }
-
-    uint4 stg[NLD];
-    int f_kh = 0, f_kw = 0, f_cs = 0;  // FAST-mode K position of the NEXT step to load
-
-    auto load_step = [&](int step) {
-        int kh, kw, choff;
-        bool tap_ok = true;
-        if (FAST) {
-            kh = f_kh;
-            kw = f_kw;
-            choff = (f_cs * 8 + ld_chunk) * 16;
-            if (++f_cs == a.SPT) {
-                f_cs = 0;
-                if (++f_kw == a.KW) {
-                    f_kw = 0;
-                    ++f_kh;
-                }
-            }
-        } else {
-            const int g = step * 8 + ld_chunk;
-            const int tap = g / a.CPT;
-            const int cc = g - tap * a.CPT;
-            kh = tap / a.KW;
-            kw = tap - kh * a.KW;
-            choff = cc * 16;
-            tap_ok = tap < a.taps;
-        }
-        const int dhi = kh * a.dh, dwi = kw * a.dw;
-#pragma unroll
-        for (int i = 0; i < NLD_X; ++i) {
-            const int hi = px_hi0[i] + dhi, wi = px_wi0[i] + dwi;
-            const bool ok = tap_ok && px_ok[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *(const uint4*)(px_base[i] + (long long)(hi * a.W + wi) * (a.Cin * ES) + choff);
-            stg[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < NLD_W; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (w_ok[i]) v = *(const uint4*)(w_ptr[i] + (long long)step * 128);
-            stg[NLD_X + i] = v;
-        }
-    };
-    auto store_stage = [&](int stage) {
-        char* base = smem + stage * STAGE_BYTES + st_off;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) *(uint4*)(base + i * 32 * 128) = stg[i];
-    };
-
+    // the accumulators start at the bias of their 4 channels: no bias add in the epilogue
     f32x4 acc[NT][MT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i) {
+        const int n = n0 + wave_n * WN + i * 16 + q * 4;
+        f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+            if ((a.Cout & 3) == 0) {
+                if (n < a.Cout) { const float4 t = *(const float4*)(a.bias + n); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+            } else {
 #pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int e = 0; e < 4; ++e) if (n + e < a.Cout) b4[e] = a.bias[n + e];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = b4;
+    }
 
     const int rd_x = (wave_m * WM + r16) * 128;
     const int rd_w = (BM + wave_n * WN + r16) * 128;
-
-    load_step(0);
-    store_stage(0);
-    __syncthreads();
-
     const int nsteps = a.nsteps;
-    for (int step = 0; step < nsteps; ++step) {
-        const int cur = step & 1;
-        const bool more = step + 1 < nsteps;
-        if (more) load_step(step + 1);
-        const char* sb = smem + cur * STAGE_BYTES;
+
+    auto compute = [&](const char* sb) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int sw_off = ((kk * 4 + q) ^ (r16 & 7)) << 4;
@@ -197,8 +149,159 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
                     }
                 }
         }
-        if (more) store_stage(cur ^ 1);
+    };
+
+    if constexpr (FAST) {
+        // ================= LDS-DMA staging (`buffer_load_dwordx4 ... lds`) =================
+        // No staging registers and no ds_write: each wave-instruction drops 8 rows x 128 B straight into the stage.  The
+        // DMA destination is lane-linear, so the XOR swizzle sits on the SOURCE side: the lane at LDS position
+        // (row, c') fetches global chunk c' ^ (row & 7).  Out-of-image taps, rows >= M and channels >= Cout use an
+        // out-of-range buffer offset: the hardware range check writes ZEROS to LDS for them (probed on gfx950,
+        // tools/probe_lds_dma.hip), so padding costs no branch.  Tap validity per staged row is a 64-bit mask built
+        // once; per K-step a load costs one add + one select.
+        // The DMA is issued from inline asm: through the builtin, hipcc cannot tell the stage being filled from the
+        // stage being read and puts `s_waitcnt vmcnt(0)` in front of the first ds_read of every K-step (the load
+        // latency then serialises with the MFMAs).  Hidden in asm, the loads stay in flight across the compute phase
+        // and are drained by ONE explicit vmcnt(0) in front of the barrier.
+        const v4u rsx = make_srd(a.x, a.x_bytes);
+        const v4u rsw = make_srd(a.w, a.w_bytes);
+        constexpr unsigned OOB = 0x80000000u;
+        const int gch = ld_chunk ^ (ld_row & 7);
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        int xoff[NLD_X];
+        // tap validity is separable: byte i of hmask/wmask holds, for staged row i, one bit per kh / kw (KH, KW <= 8)
+        unsigned hmask = 0, wmask = 0;
+        static_assert(NLD_X <= 4, "one mask byte per staged pixel row");
+#pragma unroll
+        for (int i = 0; i < NLD_X; ++i) {
+            const int m = m0 + ld_row + 32 * i;
+            const bool ok = m < a.M;
+            const int mm = ok ? m : 0;
+            int hi0 = 0, wi0 = 0;
+            long long base;
+            if (a.HoWo == 1) {
+                base = (long long)mm * a.x_img_bytes;
+            } else {
+                const int b = mm / a.HoWo;
+                const int rem = mm - b * a.HoWo;
+                const int ho = rem / a.Wo;
+                const int wo = rem - ho * a.Wo;
+                hi0 = ho * a.sh - a.ph;
+                wi0 = wo * a.sw - a.pw;
+                base = (long long)b * a.x_img_bytes + (long long)(hi0 * a.W + wi0) * (a.Cin * ES);
+            }
+            xoff[i] = (int)base + gch * 16;   // may be "negative" for a padded corner: only used with a valid tap
+            if (ok) {
+                for (int kh = 0; kh < a.KH; ++kh)
+                    if ((unsigned)(hi0 + kh * a.dh) < (unsigned)a.H) hmask |= 1u << (8 * i + kh);
+                for (int kw = 0; kw < a.KW; ++kw)
+                    if ((unsigned)(wi0 + kw * a.dw) < (unsigned)a.W) wmask |= 1u << (8 * i + kw);
+            }
+        }
+        unsigned woff[NLD_W];
+#pragma unroll
+        for (int i = 0; i < NLD_W; ++i) {
+            const int n = n0 + ld_row + 32 * i;
+            woff[i] = n < a.Cout ? (unsigned)(n * a.w_row_bytes + gch * 16) : OOB;
+        }
+        int f_kh = 0, f_kw = 0, f_cs = 0;
+        auto issue = [&](int step, int stage) {
+            const int delta = (f_kh * a.dh * a.W + f_kw * a.dw) * (a.Cin * ES) + f_cs * 128;   // wave-uniform
+            const unsigned bits = (hmask >> f_kh) & (wmask >> f_kw);   // bit 8*i: row i valid for this tap
+            if (++f_cs == a.SPT) {
+                f_cs = 0;
+                if (++f_kw == a.KW) { f_kw = 0; ++f_kh; }
+            }
+            const unsigned dst = lds_base + stage * STAGE_BYTES + wave_u * 1024;   // wave-uniform LDS byte address
+#pragma unroll
+            for (int i = 0; i < NLD_X; ++i) {
+                const unsigned off = ((bits >> (8 * i)) & 1u) ? (unsigned)(xoff[i] + delta) : OOB;
+                lds_dma16(rsx, off, dst + i * 4096);
+            }
+#pragma unroll
+            for (int i = 0; i < NLD_W; ++i) {
+                const unsigned off = woff[i] == OOB ? OOB : woff[i] + (unsigned)step * 128u;
+                lds_dma16(rsw, off, dst + (NLD_X + i) * 4096);
+            }
+        };
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int step = 0; step < nsteps; ++step) {
+            const int cur = step & 1;
+            if (step + 1 < nsteps) issue(step + 1, cur ^ 1);
+            compute(smem + cur * STAGE_BYTES);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage landed (this wave's pieces) ...
+            __syncthreads();                                    // ... and everyone's; all reads of `cur` are done
+        }
+    } else {
+        // ================= register staging (generic geometry: chunk-granular tap decode, e.g. the stem) =================
+        const char* px_base[NLD_X];
+        int px_hi0[NLD_X], px_wi0[NLD_X];
+        bool px_ok[NLD_X];
+#pragma unroll
+        for (int i = 0; i < NLD_X; ++i) {
+            const int m = m0 + ld_row + 32 * i;
+            px_ok[i] = m < a.M;
+            const int mm = px_ok[i] ? m : 0;
+            const int b = mm / a.HoWo;
+            const int rem = mm - b * a.HoWo;
+            const int ho = rem / a.Wo;
+            const int wo = rem - ho * a.Wo;
+            px_hi0[i] = ho * a.sh - a.ph;
+            px_wi0[i] = wo * a.sw - a.pw;
+            px_base[i] = a.x + (long long)b * a.x_img_bytes;
+        }
+        const char* w_ptr[NLD_W];
+        bool w_ok[NLD_W];
+#pragma unroll
+        for (int i = 0; i < NLD_W; ++i) {
+            const int n = n0 + ld_row + 32 * i;
+            w_ok[i] = n < a.Cout;
+            w_ptr[i] = a.w + (long long)(w_ok[i] ? n : 0) * a.w_row_bytes + ld_chunk * 16;
+        }
+        uint4 stg[NLD];
+        auto load_step = [&](int step) {
+            const int g = step * 8 + ld_chunk;
+            const int tap = g / a.CPT;
+            const int cc = g - tap * a.CPT;
+            const int kh = tap / a.KW;
+            const int kw = tap - kh * a.KW;
+            const int choff = cc * 16;
+            const bool tap_ok = tap < a.taps;
+            const int dhi = kh * a.dh, dwi = kw * a.dw;
+#pragma unroll
+            for (int i = 0; i < NLD_X; ++i) {
+                const int hi = px_hi0[i] + dhi, wi = px_wi0[i] + dwi;
+                const bool ok = tap_ok && px_ok[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ok) v = *(const uint4*)(px_base[i] + (long long)(hi * a.W + wi) * (a.Cin * ES) + choff);
+                stg[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < NLD_W; ++i) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (w_ok[i]) v = *(const uint4*)(w_ptr[i] + (long long)step * 128);
+                stg[NLD_X + i] = v;
+            }
+        };
+        auto store_stage = [&](int stage) {
+            char* base = smem + stage * STAGE_BYTES + st_off;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) *(uint4*)(base + i * 32 * 128) = stg[i];
+        };
+        load_step(0);
+        store_stage(0);
+        __syncthreads();
+        for (int step = 0; step < nsteps; ++step) {
+            const int cur = step & 1;
+            const bool more = step + 1 < nsteps;
+            if (more) load_step(step + 1);
+            compute(smem + cur * STAGE_BYTES);
+            if (more) store_stage(cur ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- fused epilogue: bias + residual + relu
@@ -224,6 +327,27 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
         const int n = n0 + rc * CH;
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
+            // residual rows of this pass go in flight BEFORE the LDS hand-off, all at once: issued inside the read-back
+            // loop each load was waited for on the spot (one full HBM latency per row group, serialised)
+            long long orow[ITERS];
+            uint4 rres[ITERS];
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int lrow = rr + it * RPI;
+                const int trow = (lrow / WMP) * WM + p * WMP + (lrow % WMP);
+                int m = m0 + trow;
+                orow[it] = -1;
+                rres[it] = make_uint4(0, 0, 0, 0);
+                if (lrow < BMP && m < a.M && n < a.Cout) {
+                    if (a.row_map) m = (m / a.map_len) * a.map_len + a.row_map[m % a.map_len];
+                    orow[it] = m;
+                    if (a.res) {
+                        const char* rp = a.res + ((long long)m * a.res_ld + n) * ES;
+                        if constexpr (RB == 16) rres[it] = *(const uint4*)rp;
+                        else { const uint2 r2 = *(const uint2*)rp; rres[it] = make_uint4(r2.x, r2.y, 0, 0); }
+                    }
+                }
+            }
             if (p) __syncthreads();
 #pragma unroll
             for (int jj = 0; jj < MTP; ++jj) {
@@ -231,38 +355,26 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
                     const int nl = wave_n * WN + i * 16 + q * 4;
-                    f32x4 v = acc[i][p * MTP + jj];
-                    if (a.bias && n0 + nl < a.Cout) {
-                        const float4 bb = *(const float4*)(a.bias + n0 + nl);
-                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                    }
-                    *(f32x4*)(smem + lrow * ROWB + nl * 4) = v;
+                    *(f32x4*)(smem + lrow * ROWB + nl * 4) = acc[i][p * MTP + jj];
                 }
             }
             __syncthreads();
-#pragma unroll 1
+#pragma unroll
             for (int it = 0; it < ITERS; ++it) {
+                if (orow[it] < 0) continue;
                 const int lrow = rr + it * RPI;
-                if (lrow >= BMP) break;
-                const int trow = (lrow / WMP) * WM + p * WMP + (lrow % WMP);
-                int m = m0 + trow;
-                if (m >= a.M || n >= a.Cout) continue;
-                if (a.row_map) m = (m / a.map_len) * a.map_len + a.row_map[m % a.map_len];
                 float v[CH];
                 *(float4*)&v[0] = *(const float4*)(smem + lrow * ROWB + rc * CH * 4);
                 if constexpr (CH == 8) *(float4*)&v[4] = *(const float4*)(smem + lrow * ROWB + rc * CH * 4 + 16);
-                const long long o = (long long)m * a.y_ld + n;
+                const long long o = orow[it] * a.y_ld + n;
                 if (a.res) {
-                    const long long ro = (long long)m * a.res_ld + n;
-                    uint4 rv;
-                    if constexpr (RB == 16) rv = *(const uint4*)(a.res + ro * ES);
-                    else { const uint2 r2 = *(const uint2*)(a.res + ro * ES); rv = make_uint4(r2.x, r2.y, 0, 0); }
+                    const uint4 rv = rres[it];
                     if constexpr (sizeof(T) == 2) {
                         const uint32_t u[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                         for (int e = 0; e < CH / 2; ++e) {
-                            v[2 * e] += bf16_to_f32((u16)(u[e] & 0xffff));
-                            v[2 * e + 1] += bf16_to_f32((u16)(u[e] >> 16));
+                            v[2 * e] += __uint_as_float(u[e] << 16);
+                            v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u);
                         }
                     } else {
                         v[0] += __uint_as_float(rv.x); v[1] += __uint_as_float(rv.y);
@@ -303,7 +415,6 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
             for (int e = 0; e < 4; ++e) {
                 if (n + e >= a.Cout) break;
                 float f = v[e];
-                if (a.bias) f += a.bias[n + e];
                 if (a.res) {
                     if constexpr (sizeof(T) == 2) f += bf16_to_f32(*(const u16*)(a.res + (ro + e) * 2));
                     else f += *(const float*)(a.res + (ro + e) * 4);
@@ -444,7 +555,11 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     k.nsteps = cdiv(k.taps * k.CPT, 8);
     k.w_row_bytes = k.nsteps * 128;
     k.x_img_bytes = (long long)k.H * k.W * d->Cin * es;
-    const bool fast = (k.CPT % 8) == 0;
+    const long long xb = (long long)d->B * d->H * d->W * d->Cin * es, wb = (long long)d->Cout * k.w_row_bytes;
+    // FAST = LDS-DMA staging: whole 128-byte K-steps per tap, 32-bit buffer offsets, one validity bit per kh / kw
+    const bool fast = (k.CPT % 8) == 0 && xb < 0x7fffffffLL && wb < 0x7fffffffLL && d->KH <= 8 && d->KW <= 8;
+    k.x_bytes = (unsigned)(xb < 0x7fffffffLL ? xb : 0);
+    k.w_bytes = (unsigned)(wb < 0x7fffffffLL ? wb : 0);
     k.SPT = fast ? k.CPT / 8 : 1;
     int tile = d->tile;
     if (tile < 0 || tile > kNumTiles) return MT4_EINVAL;

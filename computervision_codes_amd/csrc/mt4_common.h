@@ -26,16 +26,20 @@ static inline int mt4_check_launch() {
 
 __device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even f32 -> bf16 (NaN stays NaN: plain cast semantics via the hardware convert)
+// f32 -> bf16, round-to-nearest-even: a plain cast, which hipcc lowers to the gfx950 hardware convert
+// (v_cvt_pk_bf16_f32, NaN stays NaN) -- an integer-arithmetic rounding costs ~6 VALU ops per element and made the
+// conv epilogue VALU-issue-bound (SQ_ACTIVE_INST_ANY 41 % of wave cycles on the K=64 layers).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ u16 f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (u16)(u >> 16);
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(u16, b);
 }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // exact GELU (nn.GELU default, approximate='none'): 0.5 x (1 + erf(x / sqrt(2)))
