@@ -444,7 +444,15 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     ConvK kk = k;
     kk.n_tiles = cdiv(k.Cout, BN);
     kk.total_tiles = m_tiles * kk.n_tiles;
-    constexpr int lds = 2 * (BM + BN) * 128;
+    // LDS: two operand stages, or ONE when the whole K fits a single step (then only the epilogue staging may need
+    // more than a stage): the short-K layers are memory-bound and want as many workgroups per CU as possible
+    constexpr int stage = (BM + BN) * 128;
+    constexpr int os = OUT_F32 ? 4 : 2;
+    constexpr int rowb = BN * 4 + 16;
+    constexpr int passes = (BM * rowb > 2 * stage) ? 2 : 1;
+    constexpr int epi = BM / passes * rowb;
+    (void)os;
+    const int lds = k.nsteps > 1 ? 2 * stage : (stage > epi ? stage : epi);
     const int grid = kk.total_tiles;  // one tile per workgroup (see PERSIST in the kernel)
     if (fast) {
         auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, true, OUT_F32>;
@@ -475,8 +483,9 @@ int auto_tile(int M, int N, int nsteps) {
     // smaller 64x128 / 128x64 footprints (more workgroups per CU -> more loads and stores in flight).
     auto tiles = [&](int t) { return (long long)cdiv(M, kTiles[t - 1].bm) * cdiv(N, kTiles[t - 1].bn); };
     const long long fill = 256;  // one workgroup per CU
+    if (nsteps == 1 && tiles(3) >= 4 * fill) return 3;   // single K-step: smallest footprint, most workgroups per CU
     if (N > 64) {
-        if (nsteps >= 16 && tiles(1) >= fill) return 1;
+        if (nsteps >= 4 && tiles(1) >= fill) return 1;
         if (tiles(4) >= fill) return 4;
         if (tiles(1) >= fill) return 1;
     } else if (N > 32) {

@@ -470,3 +470,145 @@ extern "C" int mt4_kd_mix(const float* s, const float* tea_i, const float* tea_v
     hipLaunchKernelGGL(kd_mix_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, s, tea_i, tea_v, tea_t, out_i, out_v, out_t, C);
     return mt4_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------ MFMA window attention (bf16, hd = 32)
+// One workgroup (4 waves) per (window, head); N <= 256 tokens, head dim 32 -- every Swin stage (heads of 32 dims,
+// N = 144 or 49) and MS-TCT stage 1.  Q (pre-scaled), K live in LDS as [token][32] rows (80-byte pitch: conflict-free
+// b128 fragment reads), V transposed as [32][token].  Per 16-query tile a wave computes S^T = K Q^T with ONE
+// v_mfma_f32_16x16x32_bf16 per 16-key tile (contraction over the 32 head dims), so a lane owns one query column and
+// 4 consecutive keys per tile: the softmax row lives in 4 lanes (2 xor-shuffles), and the probabilities are already in
+// B-operand layout for O^T = V^T P^T (k-slot (q,e) of a 32-key block = key 16*kt + 4q + e for e < 4, the next tile's
+// for e >= 4; the V^T fragment is read in the same order), so P never touches LDS.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+template <int NT>  // key/query tiles of 16
+__global__ __launch_bounds__(256) void window_attention_mfma_kernel(const u16* __restrict__ q, const u16* __restrict__ k,
+                                                                    const u16* __restrict__ v, u16* __restrict__ out,
+                                                                    const float* __restrict__ bias, const float* __restrict__ mask, int N,
+                                                                    int q_stride, int k_stride, int v_stride, int o_stride, int nW,
+                                                                    float scale) {
+    constexpr int NP = NT * 16;
+    constexpr int NP2 = ((NT + 1) / 2) * 32;  // keys padded to whole 32-key MFMA blocks
+    constexpr int QK_PITCH = 80;              // bytes per Q/K row (64 used)
+    constexpr int VT_PITCH = (NP2 + 8) * 2;   // bytes per V^T row; (NP2+8)/2 dwords is = 12 mod 16 style stagger for b64 reads
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* Ks = smem + NP * QK_PITCH;
+    char* Vt = smem + 2 * NP * QK_PITCH;
+    const int b = blockIdx.y, h = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, qd = lane >> 4;
+
+    // ---- stage Q (scaled), K rows and V^T
+    for (int e = tid; e < NP * 4; e += 256) {
+        const int row = e >> 2, pc = e & 3;
+        uint4 qv = make_uint4(0, 0, 0, 0), kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (row < N) {
+            const long long r = (long long)b * N + row;
+            qv = *(const uint4*)(q + r * q_stride + h * 32 + pc * 8);
+            kv = *(const uint4*)(k + r * k_stride + h * 32 + pc * 8);
+            vv = *(const uint4*)(v + r * v_stride + h * 32 + pc * 8);
+            uint32_t* qu = (uint32_t*)&qv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                qu[i] = pack_bf16x2(__uint_as_float(qu[i] << 16) * scale, __uint_as_float(qu[i] & 0xffff0000u) * scale);
+        }
+        *(uint4*)(Qs + row * QK_PITCH + pc * 16) = qv;
+        *(uint4*)(Ks + row * QK_PITCH + pc * 16) = kv;
+        const u16* ve = (const u16*)&vv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(u16*)(Vt + (pc * 8 + i) * VT_PITCH + row * 2) = ve[i];
+    }
+    if (NP2 > NP) {  // zero the V^T columns of the padding half-block
+        for (int e = tid; e < 32 * (NP2 - NP); e += 256) {
+            const int d = e / (NP2 - NP), c = NP + e % (NP2 - NP);
+            *(u16*)(Vt + d * VT_PITCH + c * 2) = 0;
+        }
+    }
+    __syncthreads();
+
+    for (int qt = wave; qt < NT; qt += 4) {
+        const bf16x8_t qf = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Qs + (qt * 16 + r16) * QK_PITCH + qd * 16));
+        const int query = qt * 16 + r16;
+        f32x4 s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Ks + (kt * 16 + r16) * QK_PITCH + qd * 16));
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        // bias (+ mask) rows are padded to [NP][NP] on the host: padded keys hold -1e30
+        const float* brow = bias + ((long long)h * NP + query) * NP + qd * 4;
+        const float* mrow = mask ? mask + ((long long)(b % nW) * NP + query) * NP + qd * 4 : nullptr;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const float4 bb = *(const float4*)(brow + kt * 16);
+            s[kt][0] += bb.x; s[kt][1] += bb.y; s[kt][2] += bb.z; s[kt][3] += bb.w;
+            if (mrow) {
+                const float4 mm = *(const float4*)(mrow + kt * 16);
+                s[kt][0] += mm.x; s[kt][1] += mm.y; s[kt][2] += mm.z; s[kt][3] += mm.w;
+            }
+            mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[kt][e] = __expf(s[kt][e] - mx); sum += s[kt][e]; }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kb = 0; kb < (NT + 1) / 2; ++kb) {
+            const int k0 = 2 * kb, k1 = 2 * kb + 1;
+            uint4 pf;
+            pf.x = pack_bf16x2(s[k0][0], s[k0][1]);
+            pf.y = pack_bf16x2(s[k0][2], s[k0][3]);
+            if (k1 < NT) { pf.z = pack_bf16x2(s[k1][0], s[k1][1]); pf.w = pack_bf16x2(s[k1][2], s[k1][3]); }
+            else { pf.z = 0; pf.w = 0; }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const char* vr = Vt + (dt * 16 + r16) * VT_PITCH + (kb * 32 + qd * 4) * 2;
+                const uint2 v0 = *(const uint2*)vr;          // keys 32kb + 4q .. +3
+                const uint2 v1 = *(const uint2*)(vr + 32);   // keys 32kb + 16 + 4q .. +3
+                const uint4 vf = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf), o[dt], 0, 0, 0);
+            }
+        }
+        if (query < N) {
+            u16* op = out + ((long long)b * N + query) * o_stride + h * 32 + qd * 4;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                *(uint2*)(op + dt * 16) = make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+        }
+    }
+}
+
+extern "C" int mt4_window_attention_bf16(const void* q, const void* k, const void* v, void* out, const float* bias_padded,
+                                         const float* mask_padded, int32_t B, int32_t H, int32_t N, int32_t q_stride, int32_t k_stride,
+                                         int32_t v_stride, int32_t o_stride, int32_t nW, float scale, void* stream) {
+    mt4_clear_error();
+    if (!q || !k || !v || !out || !bias_padded || B <= 0 || H <= 0 || N <= 0 || N > 256) return MT4_EINVAL;
+    if (mask_padded && nW <= 0) return MT4_EINVAL;
+    if (B > 65535) return MT4_EUNSUPPORTED;
+    if ((q_stride | k_stride | v_stride) % 8 || o_stride % 4 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) || ((uintptr_t)out & 7))
+        return MT4_EALIGN;
+    const int NT = (N + 15) / 16;
+    const int NP = NT * 16, NP2 = ((NT + 1) / 2) * 32;
+    const size_t lds = (size_t)2 * NP * 80 + (size_t)32 * (NP2 + 8) * 2;
+    const dim3 grid(H, B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define WA(NTV) hipLaunchKernelGGL((window_attention_mfma_kernel<NTV>), grid, block, lds, s, (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, bias_padded, mask_padded, N, q_stride, k_stride, v_stride, o_stride, nW, scale)
+    switch (NT) {
+        case 1: WA(1); break; case 2: WA(2); break; case 3: WA(3); break; case 4: WA(4); break;
+        case 5: WA(5); break; case 6: WA(6); break; case 7: WA(7); break; case 8: WA(8); break;
+        case 9: WA(9); break; case 10: WA(10); break; case 11: WA(11); break; case 12: WA(12); break;
+        case 13: WA(13); break; case 14: WA(14); break; case 15: WA(15); break; default: WA(16); break;
+    }
+#undef WA
+    return mt4_check_launch();
+}

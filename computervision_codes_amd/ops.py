@@ -210,6 +210,35 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, batch: int, 
     return out
 
 
+def pad_attention_bias(bias: torch.Tensor, key_pad_value: float = -1e30) -> torch.Tensor:
+    """[H|nW, N, N] float32 -> [.., NP, NP] (NP = round_up(N,16)); padded key columns get `key_pad_value`, padded query rows 0"""
+    g, n, _ = bias.shape
+    np_ = (n + 15) // 16 * 16
+    out = torch.zeros((g, np_, np_), dtype=torch.float32, device=bias.device)
+    out[:, :, n:] = key_pad_value
+    out[:, :n, :n] = bias
+    return out.contiguous()
+
+
+def window_attention_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, batch: int, heads: int, n: int, q_stride: int,
+                          k_stride: int, v_stride: int, scale: float, bias_padded: torch.Tensor,
+                          mask_padded: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """MFMA attention core for head dim 32 (see mt4_window_attention_bf16); bias/mask padded by `pad_attention_bias`."""
+    _need_cuda(q, k, v, bias_padded, mask_padded)
+    assert q.dtype == torch.bfloat16 and bias_padded.dtype == torch.float32
+    np_ = (n + 15) // 16 * 16
+    assert tuple(bias_padded.shape) == (heads, np_, np_)
+    nw = 1
+    if mask_padded is not None:
+        assert tuple(mask_padded.shape[1:]) == (np_, np_) and batch % mask_padded.shape[0] == 0
+        nw = mask_padded.shape[0]
+    out = torch.empty((batch * n, heads * 32), dtype=torch.bfloat16, device=q.device)
+    check(lib.mt4_window_attention_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), bias_padded.data_ptr(),
+                                        mask_padded.data_ptr() if mask_padded is not None else None, batch, heads, n, q_stride, k_stride,
+                                        v_stride, heads * 32, nw, scale, _stream()), "mt4_window_attention_bf16")
+    return out
+
+
 def patchify(img: torch.Tensor, patch: int, dtype: torch.dtype, mean=None, std=None) -> torch.Tensor:
     """float32 NCHW [B,3,H,W] (normalised) or uint8 NHWC [B,H,W,3] -> [B*H/P*W/P, 3*P*P] rows"""
     _need_cuda(img)

@@ -160,6 +160,9 @@ class Qeruy2Label:
                     qkv=self._lin(q + "attn.qkv.weight", q + "attn.qkv.bias"), proj=self._lin(q + "attn.proj.weight", q + "attn.proj.bias"),
                     fc1=self._lin(q + "mlp.fc1.weight", q + "mlp.fc1.bias"), fc2=self._lin(q + "mlp.fc2.weight", q + "mlp.fc2.bias"),
                     bias=bias, mask=_shift_mask(res, ws, shift).to(dev) if shift > 0 else None,
+                    # MFMA core (bf16, head dim 32): tables padded to 16-token tiles, padded keys masked out
+                    bias_p=ops.pad_attention_bias(bias) if self._mfma_attn(s) else None,
+                    mask_p=ops.pad_attention_bias(_shift_mask(res, ws, shift).to(dev), 0.0) if (shift > 0 and self._mfma_attn(s)) else None,
                     row_map=_window_row_map(res, ws, shift).to(dev)))
             st = dict(res=res, ws=ws, nh=nh, c=self.cfg["embed_dim"] * 2 ** s, blocks=blocks)
             if s < 3:
@@ -194,14 +197,23 @@ class Qeruy2Label:
         p["fc.b"] = self._sd[q + "fc.b"][0].to(dev).contiguous()
         self._p = p
 
+    def _mfma_attn(self, stage: int) -> bool:
+        c = self.cfg["embed_dim"] * 2 ** stage
+        return self.dtype == torch.bfloat16 and c // self.cfg["num_heads"][stage] == 32
+
     # ------------------------------------------------------------------ backbone
     def _block(self, x, st, blk, batch):
         c, nh, ws, res = st["c"], st["nh"], st["ws"], st["res"]
         L, n, nwin = res * res, ws * ws, (res // ws) ** 2
         xw = ops.layernorm(x, *blk["norm1"], row_map=blk["row_map"], group=1, l_out=L, l_in=L)
         qkv = ops.linear(xw, *blk["qkv"])
-        a = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch=batch * nwin, heads=nh, nq=n, nk=n, hd=c // nh,
-                          q_stride=3 * c, k_stride=3 * c, v_stride=3 * c, scale=(c // nh) ** -0.5, bias=blk["bias"], mask=blk["mask"])
+        if blk["bias_p"] is not None:
+            a = ops.window_attention_bf16(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch=batch * nwin, heads=nh, n=n, q_stride=3 * c,
+                                          k_stride=3 * c, v_stride=3 * c, scale=(c // nh) ** -0.5, bias_padded=blk["bias_p"],
+                                          mask_padded=blk["mask_p"])
+        else:
+            a = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch=batch * nwin, heads=nh, nq=n, nk=n, hd=c // nh,
+                              q_stride=3 * c, k_stride=3 * c, v_stride=3 * c, scale=(c // nh) ** -0.5, bias=blk["bias"], mask=blk["mask"])
         x = ops.linear(a, *blk["proj"], residual=x, out_row_map=blk["row_map"])
         y = ops.layernorm(x, *blk["norm2"])
         h = ops.linear(y, *blk["fc1"], act="gelu")

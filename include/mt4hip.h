@@ -138,6 +138,13 @@ int mt4_attention(const void* q, const void* k, const void* v, void* out, const 
                   int32_t H, int32_t Nq, int32_t Nk, int32_t hd, int32_t q_stride, int32_t k_stride, int32_t v_stride,
                   int32_t o_stride, int32_t nW, float scale, int32_t dtype, void* stream);
 
+/* Same core on the matrix units for the Swin shape: bf16, head dim 32, N <= 256 tokens per window (q, k, v from one
+ * packed qkv projection), one workgroup per (window, head).  bias_padded [H][NP][NP] / mask_padded [nW][NP][NP] float32
+ * with NP = round_up(N,16); padded KEY columns of bias hold -1e30 (they vanish in the softmax), everything else 0. */
+int mt4_window_attention_bf16(const void* q, const void* k, const void* v, void* out, const float* bias_padded,
+                              const float* mask_padded, int32_t B, int32_t H, int32_t N, int32_t q_stride, int32_t k_stride,
+                              int32_t v_stride, int32_t o_stride, int32_t nW, float scale, void* stream);
+
 /* Non-overlapping PxP patches as GEMM rows: out[(b*H/P + ph)*W/P + pw][c*P*P + kh*P + kw] (PatchEmbed.proj,
  * swin_transformer.py:435,446).  in: normalised float32 NCHW, or (from_u8) uint8 NHWC frames normalised on the fly. */
 int mt4_patchify(const void* in, void* out, int32_t B, int32_t H, int32_t W, int32_t P, int32_t from_u8, const float mean[3],
