@@ -15,6 +15,7 @@
 // Tiles are dealt to XCDs in contiguous ranges (n-tile fastest), so all column tiles of a pixel tile hit
 // one XCD's L2 and activations are fetched from HBM once.
 #include "mt4_common.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -28,6 +29,29 @@ __device__ __forceinline__ v4u make_srd(const void* p, unsigned bytes) {
     r.z = __builtin_amdgcn_readfirstlane(bytes);
     r.w = 0x00020000u;
     return r;
+}
+
+// N LDS-DMA pieces in ONE asm statement (one M0 save/restore): piece i goes to LDS [lds_addr + i*4096 + lane*16) from
+// buffer offset voff[i] (per lane, range-checked: out-of-range lanes write zeros) + soff (wave-uniform, NOT range-checked).
+template <int N>
+__device__ __forceinline__ void lds_dma16_group(v4u srd, const unsigned (&voff)[N], unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    if constexpr (N == 1) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[0]), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
+    } else if constexpr (N == 2) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "s"(srd), "s"(soff), "s"(lds_addr) : "memory", "scc");
+    } else {
+        static_assert(N == 4, "1, 2 or 4 pieces");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(srd), "s"(soff), "s"(lds_addr)
+                     : "memory", "scc");
+    }
 }
 
 // one LDS-DMA piece: 64 lanes x 16 B from buffer offset `voff` (per lane) to LDS [lds_addr + lane*16); out-of-range
@@ -58,10 +82,11 @@ struct ConvK {
     int M, HoWo, CPT, SPT, taps, nsteps, n_tiles, total_tiles;
     long long x_img_bytes;  // H*W*Cin*esize
     unsigned x_bytes, w_bytes;  // buffer sizes for the LDS-DMA range check (FAST path; < 2 GiB)
+    unsigned x_bias;            // (pad_h*W + pad_w)*Cin*esize: how far a padded corner reaches in front of x
     int w_row_bytes;        // nsteps*128
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool FAST, bool OUT_F32>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool FAST, bool OUT_F32>
 __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
     constexpr int ES = (int)sizeof(T);
     constexpr int ROWS = BM + BN;
@@ -163,7 +188,10 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
         // stage being read and puts `s_waitcnt vmcnt(0)` in front of the first ds_read of every K-step (the load
         // latency then serialises with the MFMAs).  Hidden in asm, the loads stay in flight across the compute phase
         // and are drained by ONE explicit vmcnt(0) in front of the barrier.
-        const v4u rsx = make_srd(a.x, a.x_bytes);
+        // The x descriptor starts x_bias bytes BEFORE the tensor, x_bias = the farthest a padded corner reaches back:
+        // per-lane offsets (pixel (hi0,wi0) + x_bias) are then never negative, and the wave-uniform tap/channel step rides in
+        // the instruction's soffset (not range-checked).  Bytes in front of x are never fetched: their taps are invalid.
+        const v4u rsx = make_srd(a.x - a.x_bias, a.x_bytes + a.x_bias);
         const v4u rsw = make_srd(a.w, a.w_bytes);
         constexpr unsigned OOB = 0x80000000u;
         const int gch = ld_chunk ^ (ld_row & 7);
@@ -191,7 +219,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
                 wi0 = wo * a.sw - a.pw;
                 base = (long long)b * a.x_img_bytes + (long long)(hi0 * a.W + wi0) * (a.Cin * ES);
             }
-            xoff[i] = (int)base + gch * 16;   // may be "negative" for a padded corner: only used with a valid tap
+            xoff[i] = (int)base + gch * 16 + (int)a.x_bias;   // >= 0
             if (ok) {
                 for (int kh = 0; kh < a.KH; ++kh)
                     if ((unsigned)(hi0 + kh * a.dh) < (unsigned)a.H) hmask |= 1u << (8 * i + kh);
@@ -213,27 +241,41 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
                 f_cs = 0;
                 if (++f_kw == a.KW) { f_kw = 0; ++f_kh; }
             }
+            // (keep the K position in SGPRs: without this hipcc carries it in VGPRs and multiplies with v_mul_lo_u32)
+            f_cs = __builtin_amdgcn_readfirstlane(f_cs);
+            f_kw = __builtin_amdgcn_readfirstlane(f_kw);
+            f_kh = __builtin_amdgcn_readfirstlane(f_kh);
             const unsigned dst = lds_base + stage * STAGE_BYTES + wave_u * 1024;   // wave-uniform LDS byte address
+            unsigned vx[NLD_X];
 #pragma unroll
-            for (int i = 0; i < NLD_X; ++i) {
-                const unsigned off = ((bits >> (8 * i)) & 1u) ? (unsigned)(xoff[i] + delta) : OOB;
-                lds_dma16(rsx, off, dst + i * 4096);
-            }
-#pragma unroll
-            for (int i = 0; i < NLD_W; ++i) {
-                const unsigned off = woff[i] == OOB ? OOB : woff[i] + (unsigned)step * 128u;
-                lds_dma16(rsw, off, dst + (NLD_X + i) * 4096);
-            }
+            for (int i = 0; i < NLD_X; ++i) vx[i] = ((bits >> (8 * i)) & 1u) ? (unsigned)xoff[i] : OOB;
+            lds_dma16_group<NLD_X>(rsx, vx, (unsigned)__builtin_amdgcn_readfirstlane(delta), dst);
+            lds_dma16_group<NLD_W>(rsw, woff, (unsigned)__builtin_amdgcn_readfirstlane(step * 128), dst + NLD_X * 4096);
         };
-        issue(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Ring of STAGES operand stages, DMA issued STAGES-1 K-steps ahead.  After computing step s the groups of steps
+        // s+1 .. s+STAGES-1 are outstanding (fewer at the tail); only the OLDEST must have landed, so the wait leaves the
+        // younger groups in flight: counted vmcnt (loads retire in issue order), then the barrier (everyone's pieces
+        // landed + all reads of the stage that the next iteration refills are done).
+        auto wait_keep = [&](int groups) {   // wait until at most `groups` K-step groups of this wave are outstanding
+            if (groups <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (groups == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+        };
+        static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 2) * NLD <= 63, "wait_keep covers up to 2 groups in flight");
+#pragma unroll
+        for (int s0 = 0; s0 < STAGES - 1; ++s0)
+            if (s0 < nsteps) issue(s0, s0);
+        wait_keep((nsteps < STAGES - 1 ? nsteps : STAGES - 1) - 1);
         __syncthreads();
+        int cur = 0, fill = STAGES - 1;   // stage being computed / stage the next issue refills
         for (int step = 0; step < nsteps; ++step) {
-            const int cur = step & 1;
-            if (step + 1 < nsteps) issue(step + 1, cur ^ 1);
+            if (step + STAGES - 1 < nsteps) issue(step + STAGES - 1, fill);
             compute(smem + cur * STAGE_BYTES);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage landed (this wave's pieces) ...
-            __syncthreads();                                    // ... and everyone's; all reads of `cur` are done
+            const int rem = nsteps - 1 - step;   // K-step groups still outstanding after this one
+            wait_keep((rem < STAGES - 1 ? rem : STAGES - 1) - 1);
+            __syncthreads();
+            cur = cur + 1 == STAGES ? 0 : cur + 1;
+            fill = fill + 1 == STAGES ? 0 : fill + 1;
         }
     } else {
         // ================= register staging (generic geometry: chunk-granular tap decode, e.g. the stem) =================
@@ -435,10 +477,12 @@ struct TileCfg {
     int bm, bn;
 };
 // tile ids are 1-based in the C-ABI
-constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {64, 128}, {32, 64}, {32, 32}};
+// ids 1-6: two operand stages; 7-12: deeper rings (3 for the 128-wide tiles, 4 for the small ones)
+constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {64, 128}, {32, 64}, {32, 32},
+                              {128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}, {128, 64}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <typename T, int BM, int BN, int WM_, int WN_, bool OUT_F32>
+template <typename T, int BM, int BN, int WM_, int WN_, int STAGES, bool OUT_F32>
 int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     const int m_tiles = cdiv(k.M, BM);
     ConvK kk = k;
@@ -452,13 +496,17 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     constexpr int passes = (BM * rowb > 2 * stage) ? 2 : 1;
     constexpr int epi = BM / passes * rowb;
     (void)os;
-    const int lds = k.nsteps > 1 ? 2 * stage : (stage > epi ? stage : epi);
+    const int lds = k.nsteps > 1 ? (fast ? STAGES : 2) * stage : (stage > epi ? stage : epi);
     const int grid = kk.total_tiles;  // one tile per workgroup (see PERSIST in the kernel)
     if (fast) {
-        auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, true, OUT_F32>;
+        auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, STAGES, true, OUT_F32>;
+        if (lds > 65536) {
+            static bool raised = false;   // per instantiation: allow > 64 KiB of dynamic LDS once
+            if (!raised) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+        }
         hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, kk);
     } else {
-        auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, false, OUT_F32>;
+        auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, 2, false, OUT_F32>;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, kk);
     }
     return mt4_check_launch();
@@ -467,12 +515,18 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
 template <typename T, bool OUT_F32>
 int launch_dtype(const ConvK& k, int tile, bool fast, hipStream_t s) {
     switch (tile) {
-        case 1: return launch_tile<T, 128, 128, 2, 2, OUT_F32>(k, fast, s);
-        case 2: return launch_tile<T, 128, 64, 2, 2, OUT_F32>(k, fast, s);
-        case 3: return launch_tile<T, 64, 64, 2, 2, OUT_F32>(k, fast, s);
-        case 4: return launch_tile<T, 64, 128, 2, 2, OUT_F32>(k, fast, s);
-        case 5: return launch_tile<T, 32, 64, 1, 4, OUT_F32>(k, fast, s);
-        case 6: return launch_tile<T, 32, 32, 2, 2, OUT_F32>(k, fast, s);
+        case 1: return launch_tile<T, 128, 128, 2, 2, 2, OUT_F32>(k, fast, s);
+        case 2: return launch_tile<T, 128, 64, 2, 2, 2, OUT_F32>(k, fast, s);
+        case 3: return launch_tile<T, 64, 64, 2, 2, 2, OUT_F32>(k, fast, s);
+        case 4: return launch_tile<T, 64, 128, 2, 2, 2, OUT_F32>(k, fast, s);
+        case 5: return launch_tile<T, 32, 64, 1, 4, 2, OUT_F32>(k, fast, s);
+        case 6: return launch_tile<T, 32, 32, 2, 2, 2, OUT_F32>(k, fast, s);
+        case 7: return launch_tile<T, 128, 128, 2, 2, 3, OUT_F32>(k, fast, s);
+        case 8: return launch_tile<T, 64, 128, 2, 2, 3, OUT_F32>(k, fast, s);
+        case 9: return launch_tile<T, 64, 64, 2, 2, 4, OUT_F32>(k, fast, s);
+        case 10: return launch_tile<T, 32, 64, 1, 4, 4, OUT_F32>(k, fast, s);
+        case 11: return launch_tile<T, 32, 32, 2, 2, 4, OUT_F32>(k, fast, s);
+        case 12: return launch_tile<T, 128, 64, 2, 2, 3, OUT_F32>(k, fast, s);
     }
     return MT4_EINVAL;
 }
@@ -493,15 +547,22 @@ int auto_tile(int M, int N, int nsteps) {
         if (tiles(3) >= fill) return 3;
     }
     // not enough work to fill the chip: take the tile with the most blocks
-    int best = kNumTiles;
+    int best = 6;
     long long best_tiles = -1;
-    for (int t = 1; t <= kNumTiles; ++t) {
+    for (int t = 1; t <= 6; ++t) {
         if (kTiles[t - 1].bn > 64 && N <= 64) continue;
         if (kTiles[t - 1].bn > 32 && N <= 32) continue;
         if (tiles(t) > best_tiles) {
             best_tiles = tiles(t);
             best = t;
         }
+    }
+    // few workgroups, long K (a TCN layer over one short video): nothing else hides the per-step DMA latency, so take
+    // the 4-stage ring of the same tile (slower than 2 stages whenever the chip is full: it halves workgroups per CU)
+    if (getenv("MT4_NO_DEEP_RING") == nullptr && nsteps >= 8) {
+        if (best == 5) return 10;
+        if (best == 6) return 11;
+        if (best == 3) return 9;
     }
     return best;
 }
@@ -566,7 +627,8 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     k.x_img_bytes = (long long)k.H * k.W * d->Cin * es;
     const long long xb = (long long)d->B * d->H * d->W * d->Cin * es, wb = (long long)d->Cout * k.w_row_bytes;
     // FAST = LDS-DMA staging: whole 128-byte K-steps per tap, 32-bit buffer offsets, one validity bit per kh / kw
-    const bool fast = (k.CPT % 8) == 0 && xb < 0x7fffffffLL && wb < 0x7fffffffLL && d->KH <= 8 && d->KW <= 8;
+    const bool fast = (k.CPT % 8) == 0 && xb < 0x70000000LL && wb < 0x7fffffffLL && d->KH <= 8 && d->KW <= 8;
+    k.x_bias = (unsigned)(((long long)d->pad_h * d->W + d->pad_w) * d->Cin * es);
     k.x_bytes = (unsigned)(xb < 0x7fffffffLL ? xb : 0);
     k.w_bytes = (unsigned)(wb < 0x7fffffffLL ? wb : 0);
     k.SPT = fast ? k.CPT / 8 : 1;
