@@ -409,7 +409,22 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
                 *(float4*)&v[0] = *(const float4*)(smem + lrow * ROWB + rc * CH * 4);
                 if constexpr (CH == 8) *(float4*)&v[4] = *(const float4*)(smem + lrow * ROWB + rc * CH * 4 + 16);
                 const long long o = orow[it] * a.y_ld + n;
-                if (a.res) {
+                if (a.res && a.relu == 3) {   // ReLU backward: pass the gradient where the forward activation was positive
+                    const uint4 rv = rres[it];
+                    if constexpr (sizeof(T) == 2) {
+                        const uint32_t u[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                        for (int e = 0; e < CH / 2; ++e) {
+                            if (!(__uint_as_float(u[e] << 16) > 0.f)) v[2 * e] = 0.f;
+                            if (!(__uint_as_float(u[e] & 0xffff0000u) > 0.f)) v[2 * e + 1] = 0.f;
+                        }
+                    } else {
+                        if (!(__uint_as_float(rv.x) > 0.f)) v[0] = 0.f;
+                        if (!(__uint_as_float(rv.y) > 0.f)) v[1] = 0.f;
+                        if (!(__uint_as_float(rv.z) > 0.f)) v[2] = 0.f;
+                        if (!(__uint_as_float(rv.w) > 0.f)) v[3] = 0.f;
+                    }
+                } else if (a.res) {
                     const uint4 rv = rres[it];
                     if constexpr (sizeof(T) == 2) {
                         const uint32_t u[4] = {rv.x, rv.y, rv.z, rv.w};
@@ -458,8 +473,11 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
                 if (n + e >= a.Cout) break;
                 float f = v[e];
                 if (a.res) {
-                    if constexpr (sizeof(T) == 2) f += bf16_to_f32(*(const u16*)(a.res + (ro + e) * 2));
-                    else f += *(const float*)(a.res + (ro + e) * 4);
+                    float rvv;
+                    if constexpr (sizeof(T) == 2) rvv = bf16_to_f32(*(const u16*)(a.res + (ro + e) * 2));
+                    else rvv = *(const float*)(a.res + (ro + e) * 4);
+                    if (a.relu == 3) f = rvv > 0.f ? f : 0.f;
+                    else f += rvv;
                 }
                 if (a.relu == 1) f = fmaxf(f, 0.f);
                 else if (a.relu == 2) f = gelu_erf(f);
@@ -605,7 +623,8 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     k.B = d->B; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
     k.KH = d->KH; k.KW = d->KW; k.sh = d->stride_h; k.sw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w;
     k.dh = d->dil_h; k.dw = d->dil_w; k.relu = d->relu;
-    if (d->relu < 0 || d->relu > 2) return MT4_EINVAL;
+    if (d->relu < 0 || d->relu > 3) return MT4_EINVAL;
+    if (d->relu == 3 && !d->residual) return MT4_EINVAL;
     k.row_map = d->out_row_map; k.map_len = d->out_row_map_len;
     k.y_ld = d->y_ld > 0 ? d->y_ld : d->Cout;
     k.res_ld = d->res_ld > 0 ? d->res_ld : d->Cout;

@@ -115,9 +115,18 @@ def tenco_eval(argv=None) -> Dict[str, float]:
     p.add_argument("--output", default=False, type=bool)
     p.add_argument("--hier", default=False, type=bool)
     p.add_argument("--input_dim", type=int, default=512)
+    p.add_argument("--epochs", type=int, default=100)
+    p.add_argument("-w", "--warmups", type=int, nargs="+", default=[9, 18, 58])
+    p.add_argument("-l", "--initial_learning_rates", type=float, nargs="+", default=[0.01, 0.01, 0.01])
+    p.add_argument("--weight_decay", type=float, default=1e-5)
+    p.add_argument("--decay_rate", type=float, default=0.99)
+    p.add_argument("--power", type=float, default=0.1)
+    p.add_argument("--val_interval", type=int, default=1)
     F, _ = p.parse_known_args(argv)
     if F.train:
-        raise NotImplementedError("training (-t) is not built yet; use -e")
+        _tenco_train(F)
+        if not F.test:
+            return {}
     modelname = f"{F.model}_l8_cholect{F.dataset_variant}_k{F.kfold}_batchnorm_lowres"   # `run.py:137-142`
     model_dir = f"./__checkpoint__/run_{F.version}"
     logfile = os.path.join(model_dir, modelname + ".log")
@@ -141,6 +150,50 @@ def tenco_eval(argv=None) -> Dict[str, float]:
     with open(os.path.join(model_dir, modelname + "_test_mAP.pkl"), "wb") as f:
         pickle.dump({k: {"targets": m[k].global_targets, "predictions": m[k].global_predictions} for k in m}, f)
     return res
+
+
+def _tenco_train(F):
+    """`Temporal_tenco/run.py -t` (:181-235, :341-348, :260-271): whole-video batch 1, SGD without momentum, LinearLR warm-up ->
+    ExponentialLR per epoch, `_latest.pth` after every epoch.  With torchrun the shuffled videos of an epoch are dealt round-robin
+    to the ranks (one video per rank per step) and the flat gradient buffer is all-reduced over RCCL each step."""
+    import random
+
+    from .tenco_train import TencoTrainer, lr_at_epoch
+    rank, world = _dist()
+    modelname = f"{F.model}_l8_cholect{F.dataset_variant}_k{F.kfold}_batchnorm_lowres"
+    model_dir = f"./__checkpoint__/run_{F.version}"
+    logfile = os.path.join(model_dir, modelname + ".log")
+    if not F.fpn:
+        raise NotImplementedError("training is built for the shipped recipe (--fpn, Scripts/train_fold1.sh:28)")
+    tr = TencoTrainer(F.num_layers_PG, F.num_layers_R, F.num_R, 512, F.input_dim, lr=F.initial_learning_rates[2], weight_decay=F.weight_decay)
+    from . import shapes, synth
+    init = os.path.join(model_dir, modelname + "_latest.pth")
+    if os.path.exists(init):
+        tr.load_state_dict(torch.load(init, map_location="cpu"))
+    else:   # no torch.nn init here: deterministic synthetic start (the reference starts from torch's default init)
+        tr.load_state_dict(synth.fill_from_shapes(shapes.tenco_shapes(F.num_layers_PG, F.num_layers_R, F.num_R, 512, F.input_dim, 100, fpn=True),
+                                                  seed=F.seed))
+    train_videos, _, _ = cholect.split_videos(F.dataset_variant, F.kfold)
+    feats = featfile.read_feats(featfile.feats_path("..", F.version1, F.kfold, "all"))
+    labels = {v: cholect.load_labels(F.data_dir, v) for v in train_videos}
+    rng = random.Random(F.seed)
+    gen = torch.Generator().manual_seed(F.seed + rank)
+    for epoch in range(F.epochs):
+        tr.lr = lr_at_epoch(epoch, F.initial_learning_rates[2], F.power, F.warmups[2], F.decay_rate)
+        order = list(train_videos)
+        rng.shuffle(order)                                         # same permutation on every rank
+        steps = (len(order) + world - 1) // world
+        t0, tot = time.time(), 0.0
+        for s in range(steps):
+            v = order[(s * world + rank) % len(order)]
+            x = torch.from_numpy(feats[featfile.video_key(v)]).unsqueeze(0).cuda()
+            lab = {k: torch.from_numpy(labels[v][n][:, 1:]) for k, n in (("", "ivt"), ("_i", "i"), ("_v", "v"), ("_t", "t"))}
+            masks = tr.draw_masks(x.shape[1], gen) if F.mask else None
+            loss, _ = tr.train_step(x, lab, masks=masks)
+            tot += loss
+        if rank == 0:
+            _log(logfile, f"Traning | lr: {tr.lr:.6f} | epoch {epoch} | loss {tot / steps:.4f} | {time.time() - t0:.2f} secs")
+            torch.save(tr.state_dict(), init)
 
 
 # ------------------------------------------------------------------------------------------------ Spatial_transformer/test.py

@@ -88,7 +88,7 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == cout
     assert w_packed.dtype == x.dtype and w_packed.shape[1] == packed_k(cin, kh, kw, x.dtype)
-    act_code = {None: 1 if relu else 0, "none": 0, "relu": 1, "gelu": 2}[act]
+    act_code = {None: 1 if relu else 0, "none": 0, "relu": 1, "gelu": 2, "relu_gate": 3}[act]
     if out_row_map is not None:
         assert out_row_map.dtype == torch.int32 and out_row_map.is_cuda and out_row_map.is_contiguous()
         assert (b * ho * wo) % out_row_map.numel() == 0
@@ -295,3 +295,53 @@ def kd_mix(s: torch.Tensor, ti: torch.Tensor, tv: torch.Tensor, tt: torch.Tensor
     check(lib.mt4_kd_mix(s.data_ptr(), ti.data_ptr(), tv.data_ptr(), tt.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(),
                          outs[2].data_ptr(), s.shape[0], s.shape[1], _stream()), "mt4_kd_mix")
     return tuple(outs)
+
+
+# ----------------------------------------------------------------------------------------- training pieces (fp32)
+def wgrad_conv1d(dy: torch.Tensor, x: torch.Tensor, dw_packed: torch.Tensor, *, batch: int, t: int, taps: int, dil: int, pad: int,
+                 accumulate: bool = False) -> None:
+    _need_cuda(dy, x, dw_packed)
+    assert dy.dtype == x.dtype == dw_packed.dtype == torch.float32 and dy.is_contiguous() and x.is_contiguous() and dw_packed.is_contiguous()
+    cout, cin = dy.shape[-1], x.shape[-1]
+    assert dw_packed.shape == (cout, packed_k(cin, 1, taps, torch.float32)) and dy.numel() == batch * t * cout
+    check(lib.mt4_wgrad_conv1d_f32(dy.data_ptr(), x.data_ptr(), dw_packed.data_ptr(), batch, t, cout, cin, taps, dil, pad,
+                                   1 if accumulate else 0, _stream()), "mt4_wgrad_conv1d_f32")
+
+
+def colsum(x2d: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> None:
+    _need_cuda(x2d, out)
+    assert x2d.dtype == out.dtype == torch.float32 and x2d.stride(-1) == 1
+    m, c = x2d.shape
+    check(lib.mt4_colsum_f32(x2d.data_ptr(), out.data_ptr(), m, out.numel(), x2d.stride(0), 1 if accumulate else 0, _stream()), "mt4_colsum_f32")
+
+
+def bce_logits(y: torch.Tensor, z: torch.Tensor, col_scale: torch.Tensor, dy: torch.Tensor, col_loss: torch.Tensor) -> None:
+    """y [M,N] (row pitch y.stride(0)), z [M,N] dense, dy [M,>=N] (row pitch dy.stride(0)); col_loss accumulates"""
+    _need_cuda(y, z, col_scale, dy, col_loss)
+    m, n = z.shape
+    assert z.is_contiguous() and y.stride(-1) == 1 and dy.stride(-1) == 1
+    check(lib.mt4_bce_logits_f32(y.data_ptr(), z.data_ptr(), col_scale.data_ptr(), dy.data_ptr(), col_loss.data_ptr(), m, n, y.stride(0),
+                                 dy.stride(0), _stream()), "mt4_bce_logits_f32")
+
+
+def sgd_step(p: torch.Tensor, g: torch.Tensor, lr: float, weight_decay: float, grad_scale: float = 1.0) -> None:
+    _need_cuda(p, g)
+    assert p.dtype == g.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous() and p.numel() == g.numel()
+    check(lib.mt4_sgd_step_f32(p.data_ptr(), g.data_ptr(), p.numel(), lr, weight_decay, grad_scale, _stream()), "mt4_sgd_step_f32")
+
+
+def mul_add(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_cuda(a, b, c)
+    assert a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float32 and a.numel() == b.numel()
+    y = torch.empty_like(a) if out is None else out
+    check(lib.mt4_mul_add_f32(a.data_ptr(), b.data_ptr(), c.data_ptr() if c is not None else None, y.data_ptr(), a.numel(), _stream()),
+          "mt4_mul_add_f32")
+    return y
+
+
+def transpose_pack_conv1d(w_packed: torch.Tensor, cout: int, cin: int, taps: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_cuda(w_packed)
+    kt = packed_k(cout, 1, taps, torch.float32)
+    wt = torch.empty((cin, kt), dtype=torch.float32, device=w_packed.device) if out is None else out
+    check(lib.mt4_transpose_pack_conv1d_f32(w_packed.data_ptr(), wt.data_ptr(), cout, cin, taps, _stream()), "mt4_transpose_pack_conv1d_f32")
+    return wt

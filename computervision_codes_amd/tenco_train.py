@@ -1,0 +1,276 @@
+"""One training step of the temporal head on MI355X: forward (train mode), BCE-with-logits over the 4 FPN levels,
+backward and SGD, as `Temporal_tenco/run.py:181-235` does with autograd -- here as explicit HIP launches.
+
+* forward: the inference kernels (`mt4_conv_nhwc`), keeping each layer's input and ReLU output;
+* data gradients: the SAME implicit-GEMM kernel with transposed / tap-reversed weights (`mt4_transpose_pack_conv1d_f32`),
+  the ReLU gate and the residual fan-in fused into its epilogue (act "relu_gate", `residual`);
+* weight gradients: `mt4_wgrad_conv1d_f32` (fp32 MFMA, contraction over time), bias gradients `mt4_colsum_f32`;
+* loss: `mt4_bce_logits_f32` on the concatenated [T][131] heads; optimizer: `mt4_sgd_step_f32` on ONE flat parameter
+  buffer (packed layouts), so DDP is ONE all-reduce of the flat gradient buffer over RCCL (videos shard over ranks).
+
+Randomness (75 % input mask, Dropout2d, per-layer Dropout; `network.py:43-48,123-127,194-196`) is drawn on the host side
+of this class (`draw_masks`) or passed in explicitly, so that parity tests feed the oracle the same draw.
+Parameters that the FPN configuration never reaches (PG.conv_out, Rs.*.conv_1x1, Rs.*.conv_out, fpn.latlayer2/3) get no
+gradient and, like torch.optim.SGD with `grad is None`, are left untouched.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .shapes import tenco_shapes
+
+HEADS = (("", 100, 1.0), ("_i", 6, 0.1), ("_v", 10, 0.1), ("_t", 15, 0.1))   # loss = 0.1 (i + v + t) + ivt (`run.py:212`)
+NH = 131
+NHP = 132  # padded to a multiple of 4 (16-byte rows for the gradient GEMMs)
+
+
+class _Conv:
+    __slots__ = ("name", "cout", "cin", "taps", "w", "b", "gw", "gb", "wt", "kpad")
+
+
+class TencoTrainer:
+    def __init__(self, num_layers_PG=11, num_layers_R=10, num_R=3, num_f_maps=512, dim=512, num_classes=100, lr=0.1, weight_decay=1e-5,
+                 device: str = "cuda", process_group=None):
+        assert num_classes == 100 and num_R == 3, "the FPN training recipe (Scripts/train_fold1.sh:28) has PG + 3 refinement stages"
+        self.LP, self.LR, self.R, self.C, self.D = num_layers_PG, num_layers_R, num_R, num_f_maps, dim
+        self.lr, self.wd = lr, weight_decay
+        self.dev = torch.device(device)
+        self.pg = process_group
+        self._table = tenco_shapes(num_layers_PG, num_layers_R, num_R, num_f_maps, dim, 100, fpn=True)
+        self._extra: Dict[str, torch.Tensor] = {}   # parameters outside the trained graph, kept verbatim
+        self.convs: Dict[str, _Conv] = {}
+
+    # ------------------------------------------------------------------ parameters
+    def _stages(self):
+        return [("PG", self.LP)] + [(f"Rs.{r}", self.LR) for r in range(self.R)]
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        names = [k for k, _ in self._table]
+        assert all(k in sd for k in names), "state dict incomplete"
+        C, D = self.C, self.D
+        specs = [("PG.conv_1x1", C, D, 1)]
+        for prefix, n in self._stages():
+            for i in range(n):
+                specs += [(f"{prefix}.layers.{i}.conv_dilated", C, C, 3), (f"{prefix}.layers.{i}.conv_1x1", C, C, 1)]
+        specs += [("fpn.latlayer1", C, C, 1), ("heads", NHP, C, 1)]
+        f32 = torch.float32
+        sizes = []
+        for name, cout, cin, taps in specs:
+            kp = ops.packed_k(cin, 1, taps, f32)
+            sizes.append(cout * kp + ((cout + 3) // 4) * 4)
+        total = sum(sizes)
+        self.P = torch.zeros(total, dtype=f32, device=self.dev)
+        self.G = torch.zeros(total, dtype=f32, device=self.dev)
+        wt_total = sum(cin * ops.packed_k(cout, 1, taps, f32) for _, cout, cin, taps in specs if _ != "PG.conv_1x1")
+        self.WT = torch.zeros(wt_total, dtype=f32, device=self.dev)
+        off = wo = 0
+        for name, cout, cin, taps in specs:
+            c = _Conv()
+            c.name, c.cout, c.cin, c.taps = name, cout, cin, taps
+            c.kpad = ops.packed_k(cin, 1, taps, f32)
+            nw = cout * c.kpad
+            c.w, c.gw = self.P[off:off + nw].view(cout, c.kpad), self.G[off:off + nw].view(cout, c.kpad)
+            c.b, c.gb = self.P[off + nw:off + nw + cout], self.G[off + nw:off + nw + cout]
+            off += nw + ((cout + 3) // 4) * 4
+            if name == "heads":
+                w = torch.cat([sd[f"conv_out{s}.weight"] for s, _, _ in HEADS], 0).float()
+                b = torch.cat([sd[f"conv_out{s}.bias"] for s, _, _ in HEADS], 0).float()
+                w = torch.cat([w, torch.zeros(NHP - NH, cin, 1)], 0)
+                b = torch.cat([b, torch.zeros(NHP - NH)], 0)
+            else:
+                w, b = sd[name + ".weight"].float(), sd[name + ".bias"].float()
+            c.w.copy_(ops.pack_conv_weight(w.to(self.dev).unsqueeze(2), None, f32))
+            c.b.copy_(b.to(self.dev))
+            if name != "PG.conv_1x1":   # the input projection needs no data gradient
+                kt = ops.packed_k(cout, 1, taps, f32)
+                c.wt = self.WT[wo:wo + cin * kt].view(cin, kt)
+                wo += cin * kt
+            else:
+                c.wt = None
+            self.convs[name] = c
+        trained = {n + suffix for n, *_ in specs for suffix in (".weight", ".bias")} | \
+                  {f"conv_out{s}.{p}" for s, _, _ in HEADS for p in ("weight", "bias")}
+        self._extra = {k: sd[k].detach().clone() for k in names if k not in trained}
+        self._refresh_transposed()
+        return self
+
+    def _refresh_transposed(self):
+        for c in self.convs.values():
+            if c.wt is not None:
+                ops.transpose_pack_conv1d(c.w, c.cout, c.cin, c.taps, out=c.wt)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """reference layout and key names (`Temporal_tenco/network.py`), on the CPU"""
+        out = dict(self._extra)
+        for name, c in self.convs.items():
+            w = c.w[:, :c.taps * c.cin].reshape(c.cout, c.taps, c.cin).permute(0, 2, 1).contiguous().cpu()
+            b = c.b.clone().cpu()
+            if name == "heads":
+                o = 0
+                for s, k, _ in HEADS:
+                    out[f"conv_out{s}.weight"], out[f"conv_out{s}.bias"] = w[o:o + k].clone(), b[o:o + k].clone()
+                    o += k
+            else:
+                out[name + ".weight"], out[name + ".bias"] = w, b
+        return {k: out[k] for k, _ in self._table}
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        """gradients of the last step in reference layout (trained parameters only), on the CPU"""
+        out = {}
+        for name, c in self.convs.items():
+            g = c.gw[:, :c.taps * c.cin].reshape(c.cout, c.taps, c.cin).permute(0, 2, 1).contiguous().cpu()
+            gb = c.gb.clone().cpu()
+            if name == "heads":
+                o = 0
+                for s, k, _ in HEADS:
+                    out[f"conv_out{s}.weight"], out[f"conv_out{s}.bias"] = g[o:o + k].clone(), gb[o:o + k].clone()
+                    o += k
+            else:
+                out[name + ".weight"], out[name + ".bias"] = g, gb
+        return out
+
+    # ------------------------------------------------------------------ randomness
+    def draw_masks(self, t: int, generator: Optional[torch.Generator] = None) -> dict:
+        """the train-time random pieces as reference-shaped tensors ([1,D,T] / [1,D,1] / {prefix: [1,C,T]})"""
+        g = generator
+        n = self.D * t
+        perm = torch.randperm(n, generator=g)
+        flat = torch.cat((torch.zeros(n - int(n * 0.75)), torch.ones(int(n * 0.75))))[perm]   # `network.py:44-47`
+        masks = {"input_mask": flat.view(1, self.D, t), "channel_mask": (torch.rand(1, self.D, 1, generator=g) >= 0.5).float() * 2.0,
+                 "layer_masks": {}}
+        for prefix, nl in self._stages():
+            for i in range(nl):
+                masks["layer_masks"][f"{prefix}.layers.{i}"] = (torch.rand(1, self.C, t, generator=g) >= 0.5).float() * 2.0
+        return masks
+
+    # ------------------------------------------------------------------ one step
+    def _conv(self, x, c: _Conv, dil=1, residual=None, act=None, transposed=False, cout=None):
+        w = c.wt if transposed else c.w
+        b = None if transposed else (c.b if cout is None else c.b[:cout])
+        pad = dil if c.taps == 3 else 0
+        return ops.conv_nhwc(x, w, b, kh=1, kw=c.taps, pad=(0, pad), dil=(1, dil), residual=residual, act=act)
+
+    def train_step(self, x: torch.Tensor, labels: Dict[str, torch.Tensor], masks: Optional[dict] = None, apply_update: bool = True):
+        """x [1,T,D] fp32 on the GPU; labels {'': [T,100], '_i': [T,6], '_v': [T,10], '_t': [T,15]} multi-hot.
+        Returns (loss, {head: loss term})."""
+        assert x.dim() == 3 and x.shape[0] == 1 and x.shape[2] == self.D
+        T, C, dev = x.shape[1], self.C, self.dev
+        cv = self.convs
+        to_rows = lambda m: m[0].transpose(0, 1).contiguous().to(dev)        # [1,C,T] -> [T,C]
+        h0 = x.contiguous().view(1, 1, T, self.D)
+        if masks and masks.get("input_mask") is not None:
+            h0 = ops.mul_add(h0, to_rows(masks["input_mask"]).view_as(h0))
+        if masks and masks.get("channel_mask") is not None:
+            h0 = ops.mul_add(h0, masks["channel_mask"][0].transpose(0, 1).expand(T, self.D).contiguous().to(dev).view_as(h0))
+        lm = {k: to_rows(v).view(1, 1, T, C) for k, v in ((masks or {}).get("layer_masks") or {}).items()}
+
+        # ---- forward, saving layer inputs z and ReLU outputs u
+        saved: List[tuple] = []
+        f = self._conv(h0, cv["PG.conv_1x1"])
+        stage_out = []
+        for prefix, n in self._stages():
+            for i in range(n):
+                p = f"{prefix}.layers.{i}"
+                d = 2 ** i
+                u = self._conv(f, cv[p + ".conv_dilated"], dil=d, act="relu")
+                if p in lm:
+                    o = self._conv(u, cv[p + ".conv_1x1"])
+                    fn = ops.mul_add(o, lm[p], f)
+                else:
+                    fn = self._conv(u, cv[p + ".conv_1x1"], residual=f)
+                saved.append((p, d, f, u))
+                f = fn
+            stage_out.append(f)
+        c1, c2, c3, p4 = stage_out
+        lat = cv["fpn.latlayer1"]
+        p3 = self._conv(c3, lat, residual=p4)
+        p2 = self._conv(c2, lat, residual=p3)
+        p1 = self._conv(c1, lat, residual=p2)
+        levels = [p1, p2, p3, p4]
+        hd = cv["heads"]
+        logits = [self._conv(l, hd) for l in levels]                          # [1,1,T,132], column 131 is padding (= 0)
+
+        # ---- loss + dL/dlogits
+        z = torch.cat([labels[s].to(dev, torch.float32) for s, _, _ in HEADS], 1).contiguous()
+        col_scale = torch.cat([torch.full((k,), w / (T * k)) for _, k, w in HEADS]).to(dev)
+        col_loss = torch.zeros(NH, device=dev)
+        dys = []
+        for lg in logits:
+            dy = torch.zeros((1, 1, T, NHP), device=dev)
+            ops.bce_logits(lg.view(T, NHP)[:, :NH], z, col_scale, dy.view(T, NHP), col_loss)
+            dys.append(dy)
+        cl = col_loss.cpu()
+        terms, o = {}, 0
+        for s, k, _ in HEADS:
+            terms[s] = float(cl[o:o + k].sum() / (T * k))
+            o += k
+        loss = sum(w * terms[s] for s, _, w in HEADS)
+
+        # ---- backward: heads and FPN (top-down adds fan the level gradients into each other)
+        g = None
+        dstage = [None, None, None, None]
+        for li, (lv, dy) in enumerate(zip(levels, dys)):
+            ops.wgrad_conv1d(dy.view(T, NHP), lv.view(T, C), hd.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=li > 0)
+            ops.colsum(dy.view(T, NHP), hd.gb, accumulate=li > 0)
+            g = self._conv(dy, hd, transposed=True, residual=g)               # gradient w.r.t. p_{li+1}
+            if li < 3:
+                cl_ = stage_out[li]                                            # lateral input c_{li+1}
+                ops.wgrad_conv1d(g.view(T, C), cl_.view(T, C), lat.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=li > 0)
+                ops.colsum(g.view(T, C), lat.gb, accumulate=li > 0)
+                dstage[li] = self._conv(g, lat, transposed=True)
+            else:
+                dstage[3] = g                                                  # p4 is the last stage's output itself
+        # ---- backward through the stages, last to first
+        df = dstage[3]
+        idx = len(saved)
+        for si in range(len(self._stages()) - 1, -1, -1):
+            prefix, n = self._stages()[si]
+            for i in range(n - 1, -1, -1):
+                idx -= 1
+                p, d, zin, u = saved[idx]
+                w1, wd = cv[p + ".conv_1x1"], cv[p + ".conv_dilated"]
+                do = ops.mul_add(df, lm[p]) if p in lm else df
+                ops.wgrad_conv1d(do.view(T, C), u.view(T, C), w1.gw, batch=1, t=T, taps=1, dil=1, pad=0)
+                ops.colsum(do.view(T, C), w1.gb)
+                du = self._conv(do, w1, transposed=True, residual=u, act="relu_gate")
+                ops.wgrad_conv1d(du.view(T, C), zin.view(T, C), wd.gw, batch=1, t=T, taps=3, dil=d, pad=d)
+                ops.colsum(du.view(T, C), wd.gb)
+                df = self._conv(du, wd, dil=d, transposed=True, residual=df)
+            if si > 0:
+                df = ops.mul_add(df, torch.ones_like(df), dstage[si - 1])      # + gradient of this stage's input as lateral c
+        pin = cv["PG.conv_1x1"]
+        ops.wgrad_conv1d(df.view(T, C), h0.view(T, self.D), pin.gw, batch=1, t=T, taps=1, dil=1, pad=0)
+        ops.colsum(df.view(T, C), pin.gb)
+
+        if apply_update:
+            self.apply_update()
+        return loss, terms
+
+    def apply_update(self):
+        """DDP exchange (one all-reduce of the flat gradient buffer, mean over ranks) + SGD + refresh of the transposed copies"""
+        scale = allreduce_sum_flat(self.G, self.pg)
+        ops.sgd_step(self.P, self.G, self.lr, self.wd, scale)
+        self._refresh_transposed()
+
+
+def allreduce_sum_flat(flat_grad: torch.Tensor, group=None) -> float:
+    """The ONE exchange of a data-parallel step: sum the flat gradient buffer over ranks in place (RCCL on the GPU,
+    gloo in the CPU tests) and return the factor that turns the sum into the mean (1/world).  No-op for one rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 1.0
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / dist.get_world_size(group)
+
+
+def lr_at_epoch(epoch: int, lr: float, power: float, warmup: int, decay_rate: float) -> float:
+    """The schedule of `Temporal_tenco/run.py:341-348` (same in Spatial_cnn): SGD(lr/power) under
+    SequentialLR([LinearLR(start_factor=power, total_iters=warmup), ExponentialLR(gamma)], milestones=[warmup+1]);
+    the value torch's schedulers hold during epoch `epoch` (0-based)."""
+    base = lr / power
+    if epoch <= warmup:
+        return base * (power + (1.0 - power) * min(epoch, warmup) / warmup)
+    return base * decay_rate ** (epoch - warmup - 1)

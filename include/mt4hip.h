@@ -66,7 +66,8 @@ typedef struct mt4_conv_desc {
     int32_t stride_h, stride_w;
     int32_t pad_h, pad_w;
     int32_t dil_h, dil_w;
-    int32_t relu;       /* activation: 0 none, 1 ReLU, 2 GELU (erf form, nn.GELU default) */
+    int32_t relu;       /* activation: 0 none, 1 ReLU, 2 GELU (erf form, nn.GELU default), 3 ReLU-backward gate: `residual` is
+                           NOT added but gates the result (y = residual > 0 ? conv : 0; the saved forward activation) */
     int32_t dtype;      /* MT4_F32 / MT4_BF16 : x, w, residual */
     int32_t out_dtype;  /* MT4_F32 / MT4_BF16 : y */
     int32_t tile;       /* 0 = auto; else a tile id from mt4_conv_tile_count() (for tuning/tests) */
@@ -167,6 +168,29 @@ int mt4_dwconv1d_k3(const void* x, const float* w, const float* bias, void* y, i
  * out_n[b][c] = s[b][c] * softmax_n( s[b][c]/sqrt(C) * sum_d tea_n[b][d] ), n in {i,v,t}. */
 int mt4_kd_mix(const float* s, const float* tea_i, const float* tea_v, const float* tea_t, float* out_i, float* out_v,
                float* out_t, int32_t B, int32_t C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training step of the temporal head (Temporal_tenco/run.py:181-235: forward, BCE, backward, SGD).  fp32.
+ * Data gradients reuse mt4_conv_nhwc with the transposed / tap-reversed weights produced by
+ * mt4_transpose_pack_conv1d_f32 (and act 3 for the ReLU gate).
+ */
+
+/* Conv1d weight gradient in the packed layout of mt4_conv_nhwc: dw[co][tap*CPT4 + ci] (+)= sum_{b,t} dy[b,t][co] *
+ * x[b, t + tap*dil - pad][ci] (zero outside the sequence).  dy [B*T][Cout], x [B*T][Cin]; Cin, Cout % 4 == 0. */
+int mt4_wgrad_conv1d_f32(const float* dy, const float* x, float* dw_packed, int32_t B, int32_t T, int32_t Cout, int32_t Cin,
+                         int32_t taps, int32_t dil, int32_t pad, int32_t accumulate, void* stream);
+/* out[c] (+)= sum_m x[m*ld + c]   (bias gradients) */
+int mt4_colsum_f32(const float* x, float* out, int64_t M, int32_t C, int32_t ld, int32_t accumulate, void* stream);
+/* nn.BCEWithLogitsLoss pieces (run.py:196-212, 331): col_loss[n] += sum_m bce(y[m][n], z[m][n]);
+ * dy[m*ld_dy + n] = (sigmoid(y) - z) * col_scale[n].  z [M][N] dense. */
+int mt4_bce_logits_f32(const float* y, const float* z, const float* col_scale, float* dy, float* col_loss, int64_t M, int32_t N,
+                       int32_t ld_y, int32_t ld_dy, void* stream);
+/* torch.optim.SGD without momentum (run.py:343): p -= lr * (grad_scale * g + weight_decay * p) */
+int mt4_sgd_step_f32(float* p, const float* g, int64_t n, float lr, float weight_decay, float grad_scale, void* stream);
+/* y = a * b (+ c): dropout masks (network.py:194-196) forward and backward */
+int mt4_mul_add_f32(const float* a, const float* b, const float* c, float* y, int64_t n, void* stream);
+/* packed Conv1d weight [Cout][Kpad(Cin,taps)] -> packed weight of its data-gradient conv [Cin][Kpad(Cout,taps)] */
+int mt4_transpose_pack_conv1d_f32(const float* w_packed, float* wt_packed, int32_t Cout, int32_t Cin, int32_t taps, void* stream);
 
 #ifdef __cplusplus
 }

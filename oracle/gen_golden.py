@@ -320,11 +320,75 @@ def gen_mstct(name):
     print(name, "ok: logits", y.shape, "absmax", float(y.abs().max()), "concat absmean", float(concat.abs().mean()))
 
 
+# ------------------------------------------------------------------------------------------ tenco train step
+TRAIN_CASES = {
+    "tenco_train_small": dict(num_layers_PG=4, num_layers_R=3, num_R=3, num_f_maps=64, dim=32, T=50, seed=501, lr=0.1),
+    "tenco_train_full": dict(num_layers_PG=11, num_layers_R=10, num_R=3, num_f_maps=512, dim=512, T=120, seed=502, lr=0.1),
+}
+
+
+def gen_tenco_train(name):
+    """Reference module + torch autograd + torch.optim.SGD for one step with the module in eval() (dropout/mask pieces
+    are identities; they are pinned oracle-vs-HIP with explicit masks in the GPU tests)."""
+    from oracle import tenco_train as o_tt
+    cfg = TRAIN_CASES[name]
+    torch.set_grad_enabled(True)
+    try:
+        mc = dict(num_layers_PG=cfg["num_layers_PG"], num_layers_R=cfg["num_layers_R"], num_R=cfg["num_R"], num_f_maps=cfg["num_f_maps"],
+                  dim=cfg["dim"], fpn=True)
+        m = _ref_tenco(mc)
+        table = shapes.tenco_shapes(cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["num_f_maps"], cfg["dim"], 100, fpn=True)
+        sd = synth.fill_from_shapes(table, seed=cfg["seed"])
+        m.load_state_dict(sd, strict=True)
+        x = synth.synthetic_features(cfg["T"], cfg["dim"], seed=cfg["seed"])
+        labels = {s: torch.from_numpy((synth.uniform01(cfg["seed"], 900 + i, cfg["T"] * k) < 0.1).reshape(cfg["T"], k).astype(np.int64))
+                  for i, (s, k, _) in enumerate(o_tt.HEADS)}
+        opt = torch.optim.SGD(m.parameters(), lr=cfg["lr"], weight_decay=1e-5)
+        out = m(x, False)
+        bce = torch.nn.BCEWithLogitsLoss()
+        terms = {}
+        for gi, (s, _, _) in enumerate(o_tt.HEADS):
+            terms[s] = sum(bce(lv[0].transpose(0, 1), labels[s].float()) for lv in out[gi])
+        loss = 0.1 * (terms["_i"] + terms["_v"] + terms["_t"]) + terms[""]
+        for p_ in m.parameters():
+            p_.grad = None
+        loss.backward()
+        grads = {k: (p_.grad.clone() if p_.grad is not None else None) for k, p_ in m.named_parameters()}
+        opt.step()
+        new_ref = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        cfgk = dict(num_layers_PG=cfg["num_layers_PG"], num_layers_R=cfg["num_layers_R"], num_R=cfg["num_R"])
+        new_o, loss_o, terms_o, g_o = o_tt.train_step(sd, x, labels, cfg["lr"], 1e-5, **cfgk)
+        assert abs(loss_o - float(loss)) < 1e-5 * max(1, abs(float(loss))), (loss_o, float(loss))
+        outd = {"loss": np.array(float(loss)), "cfg": np.array(repr(cfg))}
+        for s in terms:
+            outd["loss" + (s or "_ivt")] = np.array(float(terms[s]))
+        unused = []
+        for k in new_ref:
+            assert _rel(new_o[k], new_ref[k]) < 1e-5, (name, k, _rel(new_o[k], new_ref[k]))
+            if grads[k] is None:
+                unused.append(k)
+                continue
+            assert _rel(g_o[k], grads[k]) < 1e-4, (name, "grad", k, _rel(g_o[k], grads[k]))
+        # fixtures: gradient norms of every parameter + samples of the updated tensors
+        outd["grad_norms"] = np.array([float(grads[k].norm()) if grads[k] is not None else -1.0 for k in new_ref], dtype=np.float64)
+        outd["grad_total_norm"] = np.array(float(torch.sqrt(sum((g ** 2).sum() for g in grads.values() if g is not None))))
+        for k in ("PG.conv_1x1.weight", "PG.layers.0.conv_dilated.weight", f"Rs.2.layers.{cfg['num_layers_R'] - 1}.conv_1x1.bias",
+                  "fpn.latlayer1.weight", "conv_out.weight", "conv_out_t.bias"):
+            flat = (new_ref[k] - sd[k]).flatten()
+            outd["delta::" + k] = flat[:: max(1, flat.numel() // 2048)].numpy()
+        outd["unused"] = np.array(";".join(unused))
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **outd)
+        print(name, "ok: loss", float(loss), "grad norm", float(outd["grad_total_norm"]), "unused params:", len(unused))
+    finally:
+        torch.set_grad_enabled(False)
+
+
 GENERATORS = {}
 GENERATORS.update({k: gen_tenco for k in TENCO_CASES})
 GENERATORS.update({k: gen_cnn for k in CNN_CASES})
 GENERATORS.update({k: gen_q2l for k in Q2L_CASES})
 GENERATORS.update({k: gen_mstct for k in MSTCT_CASES})
+GENERATORS.update({k: gen_tenco_train for k in TRAIN_CASES})
 
 
 def main(argv):

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""HBM traffic of the conv launches from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
+usage: python tools/collect_traffic.py <fetch_dir> <write_dir> <launches_per_step> <key> [out=profiles/traffic.json]
+Per MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports HALF the bytes of a wide
+(16 B/lane) coalesced stream -- doubled here; WRITE_SIZE is exact for 16-B-per-lane stores."""
+import collections, csv, glob, json, os, sys
+
+def per_dispatch(d, counter):
+    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    out = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter and "igemm_conv_kernel" in r["Kernel_Name"]:
+            out[int(r["Dispatch_Id"])] = out.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+    return list(out.values())
+
+fetch_dir, write_dir, per_step, key = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+out_path = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+fe, wr = per_dispatch(fetch_dir, "FETCH_SIZE"), per_dispatch(write_dir, "WRITE_SIZE")
+n = min(len(fe), len(wr)) // per_step * per_step
+steps = n // per_step
+# last full step (steady state)
+fe_s, wr_s = fe[n - per_step:n], wr[n - per_step:n]
+rd = 2.0 * sum(fe_s) * 1024
+wb = sum(wr_s) * 1024
+data = json.load(open(out_path)) if os.path.exists(out_path) else {}
+data[key] = {"hbm_bytes_per_step": rd + wb, "read_bytes": rd, "write_bytes": wb, "fetch_size_kib_raw": sum(fe_s),
+             "write_size_kib_raw": sum(wr_s), "launches": per_step, "steps_profiled": steps,
+             "note": "conv launches of one step; read = 2 x FETCH_SIZE (gfx950 half-count), units KiB"}
+json.dump(data, open(out_path, "w"), indent=1)
+print(key, "read GB", rd / 1e9, "write GB", wb / 1e9)
