@@ -131,6 +131,8 @@ def tenco_eval(argv=None) -> Dict[str, float]:
     model_dir = f"./__checkpoint__/run_{F.version}"
     logfile = os.path.join(model_dir, modelname + ".log")
     ckpt = F.test_ckpt or os.path.join(model_dir, modelname + ".pth")
+    if not os.path.exists(ckpt):   # the shipped scripts always pass --test_ckpt ..._latest.pth (Scripts/test_fold1.sh)
+        ckpt = os.path.join(model_dir, modelname + "_latest.pth")
     model = VideoNas(F, F.num_layers_PG, F.num_layers_R, F.num_R, 512, F.input_dim, 100).eval()
     sd = torch.load(ckpt, map_location="cpu")
     model.load_state_dict({k: v for k, v in sd.items() if k in dict(model._table)}, strict=False)   # `run.py:520`
@@ -175,7 +177,12 @@ def _tenco_train(F):
                                                   seed=F.seed))
     train_videos, _, _ = cholect.split_videos(F.dataset_variant, F.kfold)
     feats = featfile.read_feats(featfile.feats_path("..", F.version1, F.kfold, "all"))
-    labels = {v: cholect.load_labels(F.data_dir, v) for v in train_videos}
+    # features and labels of every training video are uploaded ONCE (a per-step pageable host->device copy stalls the step)
+    xs, zs = {}, {}
+    for v in train_videos:
+        lab = cholect.load_labels(F.data_dir, v)
+        xs[v] = torch.from_numpy(feats[featfile.video_key(v)]).unsqueeze(0).cuda()
+        zs[v] = tr.prepare_labels({k: torch.from_numpy(lab[n][:, 1:]) for k, n in (("", "ivt"), ("_i", "i"), ("_v", "v"), ("_t", "t"))})
     rng = random.Random(F.seed)
     gen = torch.Generator().manual_seed(F.seed + rank)
     for epoch in range(F.epochs):
@@ -186,10 +193,9 @@ def _tenco_train(F):
         t0, tot = time.time(), 0.0
         for s in range(steps):
             v = order[(s * world + rank) % len(order)]
-            x = torch.from_numpy(feats[featfile.video_key(v)]).unsqueeze(0).cuda()
-            lab = {k: torch.from_numpy(labels[v][n][:, 1:]) for k, n in (("", "ivt"), ("_i", "i"), ("_v", "v"), ("_t", "t"))}
+            x = xs[v]
             masks = tr.draw_masks(x.shape[1], gen) if F.mask else None
-            loss, _ = tr.train_step(x, lab, masks=masks)
+            loss, _ = tr.train_step(x, zs[v], masks=masks)
             tot += loss
         if rank == 0:
             _log(logfile, f"Traning | lr: {tr.lr:.6f} | epoch {epoch} | loss {tot / steps:.4f} | {time.time() - t0:.2f} secs")

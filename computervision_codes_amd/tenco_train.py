@@ -42,6 +42,8 @@ class TencoTrainer:
         self._table = tenco_shapes(num_layers_PG, num_layers_R, num_R, num_f_maps, dim, 100, fpn=True)
         self._extra: Dict[str, torch.Tensor] = {}   # parameters outside the trained graph, kept verbatim
         self.convs: Dict[str, _Conv] = {}
+        self._graphs: Dict[int, object] = {}
+        self._scales: Dict[int, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ parameters
     def _stages(self):
@@ -153,10 +155,42 @@ class TencoTrainer:
         pad = dil if c.taps == 3 else 0
         return ops.conv_nhwc(x, w, b, kh=1, kw=c.taps, pad=(0, pad), dil=(1, dil), residual=residual, act=act)
 
-    def train_step(self, x: torch.Tensor, labels: Dict[str, torch.Tensor], masks: Optional[dict] = None, apply_update: bool = True):
+    def train_step(self, x: torch.Tensor, labels: Dict[str, torch.Tensor], masks: Optional[dict] = None, apply_update: bool = True,
+                   use_graph: bool = False):
         """x [1,T,D] fp32 on the GPU; labels {'': [T,100], '_i': [T,6], '_v': [T,10], '_t': [T,15]} multi-hot.
-        Returns (loss, {head: loss term})."""
+        Returns (loss, {head: loss term}).  use_graph: replay a hipGraph of the whole forward+backward captured for this T
+        (no masks: the draw changes every step) -- ~900 launches become one."""
         assert x.dim() == 3 and x.shape[0] == 1 and x.shape[2] == self.D
+        T, dev = x.shape[1], self.dev
+        z = labels if torch.is_tensor(labels) else self.prepare_labels(labels)
+        assert z.is_cuda and tuple(z.shape) == (T, NH) and z.dtype == torch.float32
+        if use_graph and not masks:
+            g = self._graphs.get(T)
+            if g is None:
+                from .graph import GraphedForward
+                g = self._graphs[T] = GraphedForward(lambda xx, zz: self._fwd_bwd(xx, zz, None), [x, z])
+            col_loss = g(x, z)
+        else:
+            col_loss = self._fwd_bwd(x, z, masks)
+        cl = col_loss.cpu()
+        terms, o = {}, 0
+        for s, k, _ in HEADS:
+            terms[s] = float(cl[o:o + k].sum() / (T * k))
+            o += k
+        loss = sum(w * terms[s] for s, _, w in HEADS)
+        if apply_update:
+            self.apply_update()
+        return loss, terms
+
+    def prepare_labels(self, labels: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """{'': [T,100], '_i': [T,6], '_v': [T,10], '_t': [T,15]} -> one fp32 [T,131] device tensor.  Goes through pinned
+        memory: a pageable copy of this size makes ROCm pin the user pages on the fly, which was measured to stall the
+        step by 70-170 ms every other step (tools/probe_train2.py)."""
+        z = torch.cat([labels[s].to(torch.float32) for s, _, _ in HEADS], 1).contiguous()
+        return z.pin_memory().to(self.dev, non_blocking=True) if not z.is_cuda else z
+
+    def _fwd_bwd(self, x: torch.Tensor, z: torch.Tensor, masks: Optional[dict]) -> torch.Tensor:
+        """device part of a step (enqueue only): forward, loss, backward into self.G.  Returns the per-column loss sums."""
         T, C, dev = x.shape[1], self.C, self.dev
         cv = self.convs
         to_rows = lambda m: m[0].transpose(0, 1).contiguous().to(dev)        # [1,C,T] -> [T,C]
@@ -194,21 +228,13 @@ class TencoTrainer:
         logits = [self._conv(l, hd) for l in levels]                          # [1,1,T,132], column 131 is padding (= 0)
 
         # ---- loss + dL/dlogits
-        z = torch.cat([labels[s].to(dev, torch.float32) for s, _, _ in HEADS], 1).contiguous()
-        col_scale = torch.cat([torch.full((k,), w / (T * k)) for _, k, w in HEADS]).to(dev)
+        col_scale = self._col_scale(T)
         col_loss = torch.zeros(NH, device=dev)
         dys = []
         for lg in logits:
             dy = torch.zeros((1, 1, T, NHP), device=dev)
             ops.bce_logits(lg.view(T, NHP)[:, :NH], z, col_scale, dy.view(T, NHP), col_loss)
             dys.append(dy)
-        cl = col_loss.cpu()
-        terms, o = {}, 0
-        for s, k, _ in HEADS:
-            terms[s] = float(cl[o:o + k].sum() / (T * k))
-            o += k
-        loss = sum(w * terms[s] for s, _, w in HEADS)
-
         # ---- backward: heads and FPN (top-down adds fan the level gradients into each other)
         g = None
         dstage = [None, None, None, None]
@@ -244,10 +270,13 @@ class TencoTrainer:
         pin = cv["PG.conv_1x1"]
         ops.wgrad_conv1d(df.view(T, C), h0.view(T, self.D), pin.gw, batch=1, t=T, taps=1, dil=1, pad=0)
         ops.colsum(df.view(T, C), pin.gb)
+        return col_loss
 
-        if apply_update:
-            self.apply_update()
-        return loss, terms
+    def _col_scale(self, T: int) -> torch.Tensor:
+        cs = self._scales.get(T)
+        if cs is None:
+            cs = self._scales[T] = torch.cat([torch.full((k,), w / (T * k)) for _, k, w in HEADS]).to(self.dev)
+        return cs
 
     def apply_update(self):
         """DDP exchange (one all-reduce of the flat gradient buffer, mean over ranks) + SGD + refresh of the transposed copies"""

@@ -78,6 +78,19 @@ def test_train_step_with_masks_vs_oracle(cuda):
         assert (new[k] - new_o[k]).abs().max().item() <= 1e-5 * max(1.0, new_o[k].abs().max().item()), k
 
 
+def test_graph_replay_equals_eager(cuda):
+    cfg = dict(num_layers_PG=3, num_layers_R=2, num_R=3, num_f_maps=64, dim=32, T=48, seed=79, lr=0.1)
+    a, sd, _ = _trainer(cfg)
+    b, _, _ = _trainer(cfg)
+    x = synth.synthetic_features(cfg["T"], cfg["dim"], seed=cfg["seed"]).to(cuda)
+    labels = _labels(cfg["seed"], cfg["T"])
+    for _ in range(3):
+        la, _ = a.train_step(x, labels)
+        lb, _ = b.train_step(x, labels, use_graph=True)
+        assert abs(la - lb) < 1e-6
+    assert torch.equal(a.P, b.P)
+
+
 def test_two_steps_reduce_loss_and_keep_layouts(cuda):
     cfg = dict(num_layers_PG=3, num_layers_R=2, num_R=3, num_f_maps=64, dim=32, T=64, seed=78, lr=0.5)
     tr, sd, table = _trainer(cfg)

@@ -9,6 +9,7 @@ import torch
 from computervision_codes_amd import shapes, synth
 from computervision_codes_amd.tenco_train import TencoTrainer
 ap = argparse.ArgumentParser(); ap.add_argument("--T", type=int, default=1000); ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--no-gc", action="store_true"); ap.add_argument("--graph", action="store_true")
 a = ap.parse_args()
 world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
 torch.cuda.set_device(local)
@@ -19,12 +20,16 @@ tr = TencoTrainer(lr=0.01, device=f"cuda:{local}").load_state_dict(synth.fill_fr
 x = synth.synthetic_features(a.T, 512, seed=10 + rank).to(f"cuda:{local}")
 labels = {s: torch.from_numpy((synth.uniform01(3 + rank, i, a.T * k) < 0.1).reshape(a.T, k).astype(np.int64)) for i, (s, k) in
           enumerate((("", 100), ("_i", 6), ("_v", 10), ("_t", 15)))}
+zl = tr.prepare_labels(labels)   # resident on the device, like the features
 for _ in range(2):
-    tr.train_step(x, labels)
+    tr.train_step(x, zl, use_graph=a.graph)
 torch.cuda.synchronize()
+if a.no_gc:
+    import gc
+    gc.disable()
 t0 = time.perf_counter()
 for _ in range(a.steps):
-    loss, _ = tr.train_step(x, labels)
+    loss, _ = tr.train_step(x, zl, use_graph=a.graph)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 if rank == 0:
