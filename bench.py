@@ -196,6 +196,16 @@ def temporal_bench(dev, do_cpu):
                 n += 1
             rec["cpu_ms_per_window"] = round((time.perf_counter() - t0) / n * 1e3, 2)
     out["mstct_T256"] = rec
+    # one DDP-style training step of the 4-stage head (forward + BCE + backward + SGD; Temporal_tenco/run.py:181-235)
+    from computervision_codes_amd.tenco_train import TencoTrainer
+    import numpy as np
+    tr = TencoTrainer(lr=0.01, device=str(dev)).load_state_dict(synth.fill_from_shapes(shapes.tenco_shapes(), seed=47))
+    for T in (256, 2000):
+        xt = synth.synthetic_features(T, 512, seed=47).to(dev)
+        zl = tr.prepare_labels({s: torch.from_numpy((synth.uniform01(3, i, T * k) < 0.1).reshape(T, k).astype(np.int64))
+                                for i, (s, k) in enumerate((("", 100), ("_i", 6), ("_v", 10), ("_t", 15)))})
+        ms = _time_call(lambda: tr.train_step(xt, zl, use_graph=True), iters=10)
+        out[f"tenco4_train_T{T}"] = dict(ms_per_step=round(ms, 3), T=T, note="fwd+BCE+bwd+SGD, hipGraph replay, 1 GPU")
     return out
 
 
@@ -272,17 +282,20 @@ def main():
         conv_ms = sum(per_launch)
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_MFMA_TFLOPS
         achieved = flops_frame * a.batch / (conv_ms * 1e-3) / 1e12
+        # HBM bytes of the same launches from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/collect_traffic.py),
+        # collected offline with the command recorded in profiles/README.md and committed; null when not collected for this config
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(f"{a.network}_{a.dtype}_b{a.batch}_{a.height}x{a.width}")
+                rec = json.load(open(tfile)).get(f"{a.network}_{a.dtype}_b{a.batch}_{a.height}x{a.width}")
+                traffic = rec["hbm_bytes_per_step"] if rec else None
             except Exception:
                 traffic = None
         roofline = dict(bound="mfma", kernel="igemm_conv_kernel (all conv launches of one step)", achieved=round(achieved, 2),
                         peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
                         launches_per_step=len(per_launch), conv_ms_per_step=round(conv_ms, 4),
-                        gflop_per_frame=round(flops_frame / 1e9, 3))
+                        gflop_per_frame=round(flops_frame / 1e9, 3), traffic_unit="HBM bytes per step (all conv launches)")
         if a.per_layer:
             plan = model.conv_plan(a.height, a.width)
             rows = []
