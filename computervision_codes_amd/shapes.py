@@ -184,17 +184,37 @@ def q2l_transformer_shapes(prefix: str, d: int, ffn: int = 8192) -> Table:
     return t
 
 
-def q2l_param_shapes(backbone: str, img_size: int, hidden_dim: int, loss_type: str) -> Table:
-    """`Qeruy2Label` (`Spatial_transformer/network.py:48-80`) for a single-task loss_type: backbone.0.* + one Decoder."""
-    assert loss_type in ("i", "v", "t")
-    k = {"i": 6, "v": 10, "t": 15}[loss_type]
+def q2l_param_shapes(backbone: str, img_size: int, hidden_dim: int, loss_type: str, teacher_dim: int = 512) -> Table:
+    """`Qeruy2Label` (`Spatial_transformer/network.py:48-80`): backbone.0.* + one Decoder per task.  For `loss_type all` the four
+    decoders hold the SAME Transformer object (`network.py:66-73`): its parameters appear once (under decoder_i, the first
+    registration, as `named_parameters()` reports them); `q2l_state_dict_aliases` lists the three aliased copies a
+    `state_dict()` additionally holds.  KD adaptors wi/wv/wt (student_dim=hidden -> teacher_dim) and mi/mv/mt follow."""
+    assert loss_type in ("i", "v", "t", "all")
+    kmap = {"i": 6, "v": 10, "t": 15, "ivt": 100}
     c = SWIN_CFG[backbone]["embed_dim"] * 8
     t = swin_param_shapes(backbone, img_size, prefix="backbone.0.")
-    p = f"decoder_{loss_type}."
-    t += q2l_transformer_shapes(p + "transformer.", hidden_dim)
-    t += [(p + "input_proj.weight", (hidden_dim, c, 1, 1)), (p + "input_proj.bias", (hidden_dim,)),
-          (p + "query_embed.weight", (k, hidden_dim)), (p + "fc.W", (1, k, hidden_dim)), (p + "fc.b", (1, k))]
+    tasks = ("i", "v", "t", "ivt") if loss_type == "all" else (loss_type,)
+    for n, task in enumerate(tasks):
+        p = f"decoder_{task}."
+        if n == 0:
+            t += q2l_transformer_shapes(p + "transformer.", hidden_dim)
+        t += [(p + "input_proj.weight", (hidden_dim, c, 1, 1)), (p + "input_proj.bias", (hidden_dim,)),
+              (p + "query_embed.weight", (kmap[task], hidden_dim)), (p + "fc.W", (1, kmap[task], hidden_dim)), (p + "fc.b", (1, kmap[task]))]
+    if loss_type == "all":
+        for n in ("wi", "wv", "wt"):
+            t += [(n + ".weight", (teacher_dim, hidden_dim, 1)), (n + ".bias", (teacher_dim,))]
+        for n in ("mi", "mv", "mt"):
+            t += [(n + ".weight", (hidden_dim, teacher_dim, 1)), (n + ".bias", (hidden_dim,))]
     return t
+
+
+def q2l_state_dict_aliases(hidden_dim: int):
+    """(alias key, source key) pairs of the shared transformer in a `loss_type all` state dict"""
+    out = []
+    for k, _ in q2l_transformer_shapes("decoder_i.transformer.", hidden_dim):
+        for task in ("v", "t", "ivt"):
+            out.append((k.replace("decoder_i.", f"decoder_{task}.", 1), k))
+    return out
 
 
 # --------------------------------------------------------------------------- MS-TCT

@@ -87,8 +87,10 @@ def sine_position_rows(hidden_dim: int, h: int, w: int) -> torch.Tensor:
 class Qeruy2Label:
     """Drop-in for `Spatial_transformer.network.Qeruy2Label` as built by `build_q2l` (eval path).
 
-    args needs: backbone ('swin_{T,B,L}_{224,384}_*'), img_size, hidden_dim (= 8*embed_dim), loss_type ('i'|'v'|'t').
-    loss_type 'all' (4 decoders + always-on KD mixing, `network.py:98-124`) is not built yet."""
+    args needs: backbone ('swin_{T,B,L}_{224,384}_*'), img_size, hidden_dim (= 8*embed_dim), loss_type ('i'|'v'|'t'|'all'),
+    teacher_dim (KD adaptors, 'all' only; default 512 as `Spatial_transformer/test.py:82`).
+    'all' = four decoders over ONE shared transformer (`network.py:66-73`) + the always-on KD mixing (`:98-124`), which
+    needs the three teacher features as forward arguments exactly like the reference."""
 
     def __init__(self, args, dtype: torch.dtype = torch.float32, device: str = "cuda"):
         self.args = args
@@ -96,13 +98,14 @@ class Qeruy2Label:
         self.img_size = int(args.img_size)
         self.hidden = int(args.hidden_dim)
         self.loss_type = args.loss_type
-        if self.loss_type not in ("i", "v", "t"):
-            raise NotImplementedError("loss_type 'all' for Spatial_transformer (4 decoders + KD branch) is a later row")
+        if self.loss_type not in ("i", "v", "t", "all"):
+            raise ValueError(f"loss_type {self.loss_type}")
+        self.tasks = ("i", "v", "t", "ivt") if self.loss_type == "all" else (self.loss_type,)
+        self.teacher_dim = int(getattr(args, "teacher_dim", 512))
         self.cfg = SWIN_CFG[self.backbone_name]
-        assert self.hidden == self.cfg["embed_dim"] * 8 or True
         self.dtype, self.device = dtype, torch.device(device)
         self.training = False
-        self._table = q2l_param_shapes(self.backbone_name, self.img_size, self.hidden, self.loss_type)
+        self._table = q2l_param_shapes(self.backbone_name, self.img_size, self.hidden, self.loss_type, self.teacher_dim)
         self._sd: Dict[str, torch.Tensor] = {}
         self._p: Dict[str, object] = {}
 
@@ -118,7 +121,8 @@ class Qeruy2Label:
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
         names = [k for k, _ in self._table]
-        extra = [k for k in sd if k not in names and not k.endswith(SWIN_BUFFER_SUFFIXES)]
+        # a reference `loss_type all` checkpoint lists the shared transformer under every decoder: the copies are aliases
+        extra = [k for k in sd if k not in names and not k.endswith(SWIN_BUFFER_SUFFIXES) and ".transformer." not in k]
         missing = [k for k in names if k not in sd]
         if strict and (missing or extra):
             raise KeyError(f"state dict mismatch: missing {missing[:4]}, unexpected {extra[:4]}")
@@ -170,10 +174,9 @@ class Qeruy2Label:
                 st["merge"] = dict(norm=self._ln(q + "norm"), red=self._lin(q + "reduction.weight", None), row_map=_merge_row_map(res).to(dev))
             self._stages.append(st)
         p["norm"] = self._ln(pre + "norm")
-        # decoder (`network.py:144-171`) with the nn.MultiheadAttention in_proj split into its q/k/v row blocks
-        d, q = self.hidden, f"decoder_{self.loss_type}."
-        t = q + "transformer."
-        p["in_proj"] = self._lin(q + "input_proj.weight", q + "input_proj.bias")
+        # shared transformer (`network.py:66-73`: one object for all decoders), nn.MultiheadAttention in_proj split into q/k/v
+        d = self.hidden
+        t = f"decoder_{self.tasks[0]}.transformer."
 
         def mha(prefix):
             w, b = self._sd[prefix + ".in_proj_weight"], self._sd[prefix + ".in_proj_bias"]
@@ -192,9 +195,16 @@ class Qeruy2Label:
         p["dec_norm"] = self._ln(t + "decoder.norm")
         hh = self.img_size // 32
         p["pos"] = sine_position_rows(d, hh, hh).to(dev, self.dtype)
-        p["query"] = self._sd[q + "query_embed.weight"].to(dev, self.dtype).contiguous()
-        p["fc.W"] = self._sd[q + "fc.W"][0].to(dev).contiguous()
-        p["fc.b"] = self._sd[q + "fc.b"][0].to(dev).contiguous()
+        # per-task pieces (`Decoder.__init__`, `network.py:144-161`)
+        p["task"] = {}
+        for task in self.tasks:
+            q = f"decoder_{task}."
+            p["task"][task] = dict(in_proj=self._lin(q + "input_proj.weight", q + "input_proj.bias"),
+                                   query=self._sd[q + "query_embed.weight"].to(dev, self.dtype).contiguous(),
+                                   W=self._sd[q + "fc.W"][0].to(dev).contiguous(), b=self._sd[q + "fc.b"][0].to(dev).contiguous())
+        if self.loss_type == "all":   # KD adaptors, fp32 (`network.py:75-80`)
+            for n in ("wi", "wv", "wt", "mi", "mv", "mt"):
+                p[n] = (ops.pack_linear_weight(self._sd[n + ".weight"].to(dev), torch.float32), self._sd[n + ".bias"].to(dev).contiguous())
         self._p = p
 
     def _mfma_attn(self, stage: int) -> bool:
@@ -249,12 +259,13 @@ class Qeruy2Label:
                           scale=(d // nhead) ** -0.5)
         return ops.linear(o, *a["out"], residual=residual)
 
-    def decode(self, src_tokens: torch.Tensor, batch: int):
+    def decode(self, src_tokens: torch.Tensor, batch: int, task: Optional[str] = None):
         """`Decoder.forward` (`network.py:163-171`): tokens [B*L, C] -> (feat [B,d] fp32, logits [B,K] fp32)"""
         p = self._p
+        tp = p["task"][task or self.tasks[0]]
         L = src_tokens.shape[0] // batch
-        kq = p["query"].shape[0]
-        s = ops.linear(src_tokens, *p["in_proj"])
+        kq = tp["query"].shape[0]
+        s = ops.linear(src_tokens, *tp["in_proj"])
         e = p["enc"]
         sp = ops.add_rowbcast(s, p["pos"])
         s = ops.layernorm(self._mha(e["attn"], sp, sp, s, batch, L, L, residual=s), *e["n1"])
@@ -264,11 +275,11 @@ class Qeruy2Label:
         mem_pos = ops.add_rowbcast(memory, p["pos"])
         tgt = torch.zeros((batch * kq, self.hidden), dtype=self.dtype, device=memory.device)
         for dl in p["dec"]:
-            qin = ops.add_rowbcast(tgt, p["query"])
+            qin = ops.add_rowbcast(tgt, tp["query"])
             tgt = ops.layernorm(self._mha(dl["attn"], qin, mem_pos, memory, batch, kq, L, residual=tgt), *dl["n2"])
             tgt = ops.layernorm(ops.linear(ops.linear(tgt, *dl["l1"], act="relu"), *dl["l2"], residual=tgt), *dl["n3"])
         hs = ops.layernorm(tgt, *p["dec_norm"])
-        logits = ops.groupwise_linear(hs, p["fc.W"], p["fc.b"], batch, kq)
+        logits = ops.groupwise_linear(hs, tp["W"], tp["b"], batch, kq)
         return feat, logits
 
     def forward(self, input: torch.Tensor, tool=None, verb=None, target=None):
@@ -277,10 +288,22 @@ class Qeruy2Label:
         if not self._p:
             raise RuntimeError("load_state_dict first")
         b = input.shape[0]
-        feat, y = self.decode(self.forward_features(input), b)
-        ys = {k: torch.zeros((b, n), device=feat.device) for k, n in _K.items()}  # `network.py:85-88`
-        ys[self.loss_type] = y
-        return (0, ys["i"]), (0, ys["v"]), (0, ys["t"]), (feat, ys["ivt"])
+        src = self.forward_features(input)
+        if self.loss_type != "all":
+            feat, y = self.decode(src, b)
+            ys = {k: torch.zeros((b, n), device=feat.device) for k, n in _K.items()}  # `network.py:85-88`
+            ys[self.loss_type] = y
+            return (0, ys["i"]), (0, ys["v"]), (0, ys["t"]), (feat, ys["ivt"])
+        ys = {}
+        for task in self.tasks:          # four decoders, shared transformer weights; feat = the last one's (`:100`)
+            feat, ys[task] = self.decode(src, b, task)
+        if tool is None or verb is None or target is None:
+            raise TypeError("loss_type 'all' runs the KD mixing unconditionally (network.py:98-124): pass tool, verb, target features")
+        p = self._p
+        teas = [ops.linear(t.contiguous().float(), *p[m]) for m, t in zip(("mi", "mv", "mt"), (tool, verb, target))]
+        mixed = ops.kd_mix(feat, *teas)
+        kd = [ops.linear(mx, *p[w]) for mx, w in zip(mixed, ("wi", "wv", "wt"))]
+        return (kd[0], ys["i"]), (kd[1], ys["v"]), (kd[2], ys["t"]), (feat, ys["ivt"])
 
     __call__ = forward
 

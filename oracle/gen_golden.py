@@ -199,50 +199,49 @@ def _check_params(table, module, what, buffers_ok=()):
     for k, shp in table:
         assert tuple(params[k].shape) == tuple(shp), f"{what}: {k} {tuple(params[k].shape)} != {shp}"
     for k in module.state_dict():
-        assert k in params or k.endswith(tuple(buffers_ok)), f"{what}: unexpected non-parameter entry {k}"
+        assert k in params or k.endswith(tuple(buffers_ok)) or ".transformer." in k, f"{what}: unexpected non-parameter entry {k}"
 
 
-class _RefQ2L(torch.nn.Module):
-    """Assembles the reference's own classes the way `build_q2l`/`build_backbone` do (`network.py:187-204`,
-    `backbone.py:188-201,218-220`) without importing `models/__init__.py`/`utils.misc` (they pull torchvision)."""
-
-    def __init__(self, backbone, img_size, hidden_dim, loss_type):
-        super().__init__()
-        _install_timm_stub()
-        sm = _load_by_path("ref_swin", os.path.join(REF, "Spatial_transformer", "models", "swin_transformer.py"))
-        tm = _load_by_path("ref_q2l_transformer", os.path.join(REF, "Spatial_transformer", "models", "transformer.py"))
-        pm = _load_by_path("ref_posenc", os.path.join(REF, "Spatial_transformer", "models", "position_encoding.py"))
-        cfg = shapes.SWIN_CFG[backbone]
-        # build_swin_transformer asserts a name list that excludes swin_B_224_22k although its config exists
-        # (swin_transformer.py:597): construct SwinTransformer directly with the table's parameters
-        bb = sm.SwinTransformer(img_size=img_size, num_classes=1000, embed_dim=cfg["embed_dim"], depths=list(cfg["depths"]),
-                                num_heads=list(cfg["num_heads"]), window_size=cfg["window_size"])
-        bb.forward = bb.forward_features
-        del bb.avgpool
-        del bb.head
-        pe = pm.PositionEmbeddingSine(hidden_dim // 2, normalize=True, maxH=img_size // 32, maxW=img_size // 32)
-        self.backbone = torch.nn.Sequential(bb, pe)
-        a = types.SimpleNamespace(hidden_dim=hidden_dim)
-        self.transformer_obj = [tm.build_transformer(a)]
-        # Decoder / GroupWiseLinear live in network.py, whose imports need torchvision: load it with stub modules
-        for name in ("models", "models.backbone", "models.transformer", "utils", "utils.misc"):
-            if name not in sys.modules:
-                sys.modules[name] = types.ModuleType(name)
-        sys.modules["models.backbone"].build_backbone = None
-        sys.modules["models.transformer"].build_transformer = tm.build_transformer
-        sys.modules["utils.misc"].clean_state_dict = None
-        nm = _load_by_path("ref_q2l_network", os.path.join(REF, "Spatial_transformer", "network.py"))
-        k = {"i": 6, "v": 10, "t": 15}[loss_type]
-        setattr(self, f"decoder_{loss_type}", nm.Decoder(cfg["embed_dim"] * 8, self.transformer_obj[0], k))
-        self.loss_type = loss_type
+class _RefJoiner(torch.nn.Sequential):
+    """stand-in for `models/backbone.py:159-181` Joiner (that module imports torchvision): backbone -> ([src], [pos])"""
 
     def forward(self, x):
-        src = self.backbone[0](x)
-        pos = self.backbone[1](src).to(src.dtype)
-        return getattr(self, f"decoder_{self.loss_type}")([src], [pos])
+        xs = self[0](x)
+        return [xs], [self[1](xs).to(xs.dtype)]
+
+
+def _ref_q2l(backbone, img_size, hidden_dim, loss_type, teacher_dim=512):
+    """The reference's own `Qeruy2Label` (`network.py:48-128`) assembled as `build_q2l`/`build_backbone` do
+    (`network.py:187-204`, `backbone.py:188-201`) without importing `models/__init__.py`/`utils.misc` (torchvision)."""
+    _install_timm_stub()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sm = _load_by_path("ref_swin", os.path.join(REF, "Spatial_transformer", "models", "swin_transformer.py"))
+    tm = _load_by_path("ref_q2l_transformer", os.path.join(REF, "Spatial_transformer", "models", "transformer.py"))
+    pm = _load_by_path("ref_posenc", os.path.join(REF, "Spatial_transformer", "models", "position_encoding.py"))
+    cfg = shapes.SWIN_CFG[backbone]
+    # build_swin_transformer asserts a name list that excludes swin_B_224_22k although its config exists
+    # (swin_transformer.py:597): construct SwinTransformer directly with the table's parameters
+    bb = sm.SwinTransformer(img_size=img_size, num_classes=1000, embed_dim=cfg["embed_dim"], depths=list(cfg["depths"]),
+                            num_heads=list(cfg["num_heads"]), window_size=cfg["window_size"])
+    bb.forward = bb.forward_features
+    del bb.avgpool
+    del bb.head
+    pe = pm.PositionEmbeddingSine(hidden_dim // 2, normalize=True, maxH=img_size // 32, maxW=img_size // 32)
+    joiner = _RefJoiner(bb, pe)
+    joiner.num_channels = cfg["embed_dim"] * 8
+    for name in ("models", "models.backbone", "models.transformer", "utils", "utils.misc"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["models.backbone"].build_backbone = None
+    sys.modules["models.transformer"].build_transformer = tm.build_transformer
+    sys.modules["utils.misc"].clean_state_dict = None
+    nm = _load_by_path("ref_q2l_network", os.path.join(REF, "Spatial_transformer", "network.py"))
+    a = types.SimpleNamespace(hidden_dim=hidden_dim, loss_type=loss_type, teacher_dim=teacher_dim, student_dim=hidden_dim)
+    return nm.Qeruy2Label(a, joiner, tm.build_transformer(a), {"i": 6, "v": 10, "t": 15, "all": 100}[loss_type]).eval()
 
 
 Q2L_CASES = {
+    "q2l_swinT_224_all": dict(backbone="swin_T_224_1k", img=224, hidden=768, loss_type="all", B=2, seed=304),
     "q2l_swinT_224_i": dict(backbone="swin_T_224_1k", img=224, hidden=768, loss_type="i", B=2, seed=301),
     "q2l_swinB_224_v": dict(backbone="swin_B_224_22k", img=224, hidden=1024, loss_type="v", B=1, seed=302),
     "q2l_swinB_384_t": dict(backbone="swin_B_384_22k", img=384, hidden=1024, loss_type="t", B=1, seed=303),
@@ -252,25 +251,43 @@ Q2L_CASES = {
 def gen_q2l(name):
     from oracle import swin_q2l as o_q2l
     cfg = Q2L_CASES[name]
-    m = _RefQ2L(cfg["backbone"], cfg["img"], cfg["hidden"], cfg["loss_type"]).eval()
-    table = shapes.q2l_param_shapes(cfg["backbone"], cfg["img"], cfg["hidden"], cfg["loss_type"])
+    lt = cfg["loss_type"]
+    m = _ref_q2l(cfg["backbone"], cfg["img"], cfg["hidden"], lt)
+    table = shapes.q2l_param_shapes(cfg["backbone"], cfg["img"], cfg["hidden"], lt)
     _check_params(table, m, name, buffers_ok=shapes.SWIN_BUFFER_SUFFIXES)
+    if lt == "all":   # a state_dict() additionally lists the shared transformer under the other three decoders
+        ali = dict(shapes.q2l_state_dict_aliases(cfg["hidden"]))
+        extra = [k for k in m.state_dict() if k not in dict(table) and not k.endswith(shapes.SWIN_BUFFER_SUFFIXES)]
+        assert sorted(extra) == sorted(ali), (len(extra), len(ali))
     sd = synth.fill_from_shapes(table, seed=cfg["seed"])
     missing = m.load_state_dict(sd, strict=False)
-    assert not missing.unexpected_keys and all(k.endswith(shapes.SWIN_BUFFER_SUFFIXES) for k in missing.missing_keys), missing
+    assert not missing.unexpected_keys
+    assert all(k.endswith(shapes.SWIN_BUFFER_SUFFIXES) or k in dict(shapes.q2l_state_dict_aliases(cfg["hidden"])) for k in missing.missing_keys)
     img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["img"], cfg["img"], seed=cfg["seed"]))
-    feat, y = m(img)
     src = m.backbone[0](img)
-    out = o_q2l.q2l_forward(sd, img, cfg["backbone"], cfg["img"], cfg["hidden"], cfg["loss_type"])
-    ofeat = out[3][0]
-    oy = {"i": out[0][1], "v": out[1][1], "t": out[2][1]}[cfg["loss_type"]]
     osrc = o_q2l.swin_forward_features(sd, img, cfg["backbone"], cfg["img"], prefix="backbone.0.")
     assert _rel(osrc, src) < 2e-5, (name, "src", _rel(osrc, src))
-    assert _rel(oy, y) < 2e-5 and _rel(ofeat, feat) < 2e-5, (name, _rel(oy, y), _rel(ofeat, feat))
     flat = src.flatten()
-    np.savez_compressed(os.path.join(GOLD, name + ".npz"), logits=y.numpy(), feat=feat.numpy(),
-                        src_sample=flat[:: max(1, flat.numel() // 8192)].numpy(),
-                        src_stats=np.array([flat.mean(), flat.abs().mean(), flat.norm()], dtype=np.float64), cfg=np.array(repr(cfg)))
+    outd = dict(src_sample=flat[:: max(1, flat.numel() // 8192)].numpy(),
+                src_stats=np.array([flat.mean(), flat.abs().mean(), flat.norm()], dtype=np.float64), cfg=np.array(repr(cfg)))
+    if lt == "all":
+        tf = [synth.synthetic_features(cfg["B"], 512, seed=cfg["seed"] + k)[0] for k in (1, 2, 3)]
+        (fi, yi), (fv, yv), (ft, yt), (feat, yivt) = m(img, *tf)
+        o = o_q2l.q2l_forward(sd, img, cfg["backbone"], cfg["img"], cfg["hidden"], "all", teacher=tf)
+        for r, q, nme in ((yi, o[0][1], "yi"), (yv, o[1][1], "yv"), (yt, o[2][1], "yt"), (yivt, o[3][1], "yivt"), (feat, o[3][0], "feat"),
+                          (fi, o[0][0], "kd_i"), (fv, o[1][0], "kd_v"), (ft, o[2][0], "kd_t")):
+            assert _rel(q, r) < 1e-4, (name, nme, _rel(q, r))
+        outd.update(logit_i=yi.numpy(), logit_v=yv.numpy(), logit_t=yt.numpy(), logit_ivt=yivt.numpy(), feat=feat.numpy(), kd_i=fi.numpy(),
+                    kd_v=fv.numpy(), kd_t=ft.numpy())
+        y = yivt
+    else:
+        out_ref = m(img)
+        gi = {"i": 0, "v": 1, "t": 2}[lt]
+        y, feat = out_ref[gi][1], out_ref[3][0]
+        out = o_q2l.q2l_forward(sd, img, cfg["backbone"], cfg["img"], cfg["hidden"], lt)
+        assert _rel(out[gi][1], y) < 2e-5 and _rel(out[3][0], feat) < 2e-5, (name, _rel(out[gi][1], y), _rel(out[3][0], feat))
+        outd.update(logits=y.numpy(), feat=feat.numpy())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **outd)
     print(name, "ok: logits", y.shape, "absmax", float(y.abs().max()), "src absmean", float(src.abs().mean()))
 
 

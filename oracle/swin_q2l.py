@@ -206,13 +206,31 @@ def q2l_decoder(sd: SD, p: str, src, pos):
     return feat, out
 
 
-def q2l_forward(sd: SD, img: torch.Tensor, backbone: str, img_size: int, hidden_dim: int, loss_type: str):
-    """`Qeruy2Label.forward` (`network.py:82-128`) for a single-task loss_type ('i'|'v'|'t'): the KD branch is off."""
-    assert loss_type in ("i", "v", "t")
+def q2l_forward(sd: SD, img: torch.Tensor, backbone: str, img_size: int, hidden_dim: int, loss_type: str, teacher=None):
+    """`Qeruy2Label.forward` (`network.py:82-128`).  Single-task loss_type ('i'|'v'|'t'): one decoder, KD slots are 0.
+    'all': four decoders over ONE shared transformer (its weights live under decoder_i.transformer.*, `network.py:66-73`),
+    feat = decoder_ivt's pooled memory, and the always-on KD mixing (`:98-124`; reduced form, see oracle/spatial_cnn.kd_branch)
+    with teacher = (tool, verb, target) features [B, teacher_dim]."""
     src = swin_forward_features(sd, img, backbone, img_size, prefix="backbone.0.")
     pos = sine_position_encoding(hidden_dim, img_size // 32, img_size // 32).repeat(src.shape[0], 1, 1, 1)
-    feat, y = q2l_decoder(sd, f"decoder_{loss_type}.", src, pos)
     b = img.shape[0]
-    ys = {"i": torch.zeros(b, 6), "v": torch.zeros(b, 10), "t": torch.zeros(b, 15), "ivt": torch.zeros(b, 100)}
-    ys[loss_type] = y
-    return (0, ys["i"]), (0, ys["v"]), (0, ys["t"]), (feat, ys["ivt"])
+    if loss_type != "all":
+        feat, y = q2l_decoder(sd, f"decoder_{loss_type}.", src, pos)
+        ys = {"i": torch.zeros(b, 6), "v": torch.zeros(b, 10), "t": torch.zeros(b, 15), "ivt": torch.zeros(b, 100)}
+        ys[loss_type] = y
+        return (0, ys["i"]), (0, ys["v"]), (0, ys["t"]), (feat, ys["ivt"])
+    ys = {}
+    for task in ("i", "v", "t", "ivt"):
+        sdt = dict(sd)
+        if task != "i":   # the shared Transformer: alias decoder_i's weights
+            for k, v in sd.items():
+                if k.startswith("decoder_i.transformer."):
+                    sdt[k.replace("decoder_i.", f"decoder_{task}.", 1)] = v
+        feat, ys[task] = q2l_decoder(sdt, f"decoder_{task}.", src, pos)
+    s = feat
+    c = s.shape[1]
+    teas = [F.conv1d(t.unsqueeze(-1), sd[f"{m}.weight"], sd[f"{m}.bias"]).squeeze(-1) for m, t in zip(("mi", "mv", "mt"), teacher)]
+    tsum = torch.stack([t.sum(dim=1) for t in teas], dim=-1)
+    attn = torch.softmax((s / (c ** 0.5)).unsqueeze(-1) * tsum.unsqueeze(1), dim=-1)
+    kd = [F.conv1d((s * attn[:, :, n]).unsqueeze(-1), sd[f"{w}.weight"], sd[f"{w}.bias"]).squeeze(-1) for n, w in enumerate(("wi", "wv", "wt"))]
+    return (kd[0], ys["i"]), (kd[1], ys["v"]), (kd[2], ys["t"]), (feat, ys["ivt"])

@@ -164,6 +164,20 @@ def test_q2l_fp32_vs_reference_golden(cuda, name):
     assert _maxerr(out2[gi][1], z["logits"]) < 1e-3
 
 
+def test_q2l_loss_type_all_with_kd_vs_reference_golden(cuda):
+    """four decoders over the shared transformer + the always-on KD mixing (`Spatial_transformer/network.py:98-124`)"""
+    z, cfg = load_golden("q2l_swinT_224_all")
+    m = _q2l_model(cfg, torch.float32)
+    frames = synth.synthetic_frames(cfg["B"], cfg["img"], cfg["img"], seed=cfg["seed"])
+    tf = [synth.synthetic_features(cfg["B"], 512, seed=cfg["seed"] + k)[0].to(cuda) for k in (1, 2, 3)]
+    (kd_i, yi), (kd_v, yv), (kd_t, yt), (feat, yivt) = m(synth.normalize_frames(frames).to(cuda), *tf)
+    for got, key in ((yi, "logit_i"), (yv, "logit_v"), (yt, "logit_t"), (yivt, "logit_ivt"), (feat, "feat"), (kd_i, "kd_i"), (kd_v, "kd_v"),
+                     (kd_t, "kd_t")):
+        assert tuple(got.shape) == z[key].shape and _maxerr(got, z[key]) < 1e-3, (key, _maxerr(got, z[key]))
+    with pytest.raises(TypeError):
+        m(frames.to(cuda))
+
+
 @pytest.mark.parametrize("name", ["q2l_swinT_224_i", "q2l_swinB_384_t"])
 def test_q2l_bf16_mode(cuda, name):
     z, cfg = load_golden(name)
