@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
         ("pad_h", C.c_int32), ("pad_w", C.c_int32),
         ("dil_h", C.c_int32), ("dil_w", C.c_int32),
         ("relu", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile", C.c_int32),
-        ("out_row_map_len", C.c_int32), ("y_ld", C.c_int32), ("res_ld", C.c_int32),
+        ("out_row_map_len", C.c_int32), ("y_ld", C.c_int32), ("res_ld", C.c_int32), ("out_rows_per_image", C.c_int32),
     ]
 
 
@@ -69,6 +69,16 @@ SIGNATURES = {
     "mt4_sgd_step_f32": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float, _vp]),
     "mt4_mul_add_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "mt4_transpose_pack_conv1d_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "mt4_bn_stats_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, C.c_float, C.c_float, _vp]),
+    "mt4_bn_apply_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _vp]),
+    "mt4_bn_backward_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _vp]),
+    "mt4_wgrad_conv2d_f32": (C.c_int, [_vp, _vp, _vp] + [_i32] * 15 + [_vp]),
+    "mt4_maxpool3x3s2_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_avgpool_bwd_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "mt4_bce_logits_pw_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_distill_kl_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _i32, _vp]),
+    "mt4_mse_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, _vp]),
+    "mt4_kd_mix_bwd_f32": (C.c_int, [_vp] * 9 + [_i32, _i32, _vp]),
 }
 
 

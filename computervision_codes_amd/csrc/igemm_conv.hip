@@ -77,6 +77,7 @@ struct ConvK {
     char* y;
     const int* row_map;  // optional: output/residual row of pixel m = (m / map_len) * map_len + row_map[m % map_len]
     int map_len;
+    int map_img;         // output rows per image on the y/residual side (map_len when the map is a permutation)
     int y_ld, res_ld;    // row pitch (elements) of y / residual; Cout when dense
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, sh, sw, ph, pw, dh, dw, relu;  // relu: 0 none, 1 ReLU, 2 GELU(erf)
     int M, HoWo, CPT, SPT, taps, nsteps, n_tiles, total_tiles;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
                 orow[it] = -1;
                 rres[it] = make_uint4(0, 0, 0, 0);
                 if (lrow < BMP && m < a.M && n < a.Cout) {
-                    if (a.row_map) m = (m / a.map_len) * a.map_len + a.row_map[m % a.map_len];
+                    if (a.row_map) m = (m / a.map_len) * a.map_img + a.row_map[m % a.map_len];
                     orow[it] = m;
                     if (a.res) {
                         const char* rp = a.res + ((long long)m * a.res_ld + n) * ES;
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
     for (int j = 0; j < MT; ++j) {
         int m = m0 + wave_m * WM + j * 16 + r16;
         if (m >= a.M) continue;
-        if (a.row_map) m = (m / a.map_len) * a.map_len + a.row_map[m % a.map_len];
+        if (a.row_map) m = (m / a.map_len) * a.map_img + a.row_map[m % a.map_len];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int n = n0 + wave_n * WN + i * 16 + q * 4;
@@ -608,13 +609,8 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     const int es = d->dtype == MT4_BF16 ? 2 : 4;
     if ((d->Cin * es) % 16 != 0) return MT4_EALIGN;
     if (((uintptr_t)d->x | (uintptr_t)d->w | (uintptr_t)d->y | (uintptr_t)d->residual | (uintptr_t)d->bias) & 15) return MT4_EALIGN;
-    // Ho/Wo may not exceed what the geometry yields (every read is bounds-checked anyway)
-    {
-        const long long eh = (long long)d->H + 2LL * d->pad_h - (long long)d->dil_h * (d->KH - 1) - 1;
-        const long long ew = (long long)d->W + 2LL * d->pad_w - (long long)d->dil_w * (d->KW - 1) - 1;
-        if (eh < 0 || ew < 0) return MT4_EINVAL;
-        if (d->Ho > eh / d->stride_h + 1 || d->Wo > ew / d->stride_w + 1) return MT4_EINVAL;
-    }
+    // (Ho/Wo are taken as given: every read is bounds-checked, out-of-image taps contribute zeros -- the sub-pixel phases of
+    //  a strided conv's data gradient ask for one output row/column more than the 'valid' formula yields)
     const long long M = (long long)d->B * d->Ho * d->Wo;
     if (M > 0x7fffffffLL || M * d->Cout * 4 > (1LL << 40)) return MT4_EUNSUPPORTED;
 
@@ -626,6 +622,7 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     if (d->relu < 0 || d->relu > 3) return MT4_EINVAL;
     if (d->relu == 3 && !d->residual) return MT4_EINVAL;
     k.row_map = d->out_row_map; k.map_len = d->out_row_map_len;
+    k.map_img = d->out_rows_per_image > 0 ? d->out_rows_per_image : d->out_row_map_len;
     k.y_ld = d->y_ld > 0 ? d->y_ld : d->Cout;
     k.res_ld = d->res_ld > 0 ? d->res_ld : d->Cout;
     if (k.y_ld < d->Cout || k.res_ld < d->Cout) return MT4_EINVAL;

@@ -65,7 +65,8 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
               stride: Tuple[int, int] = (1, 1), pad: Tuple[int, int] = (0, 0), dil: Tuple[int, int] = (1, 1),
               residual: Optional[torch.Tensor] = None, relu: bool = False, out_dtype: Optional[torch.dtype] = None,
               out: Optional[torch.Tensor] = None, tile: int = 0, act: Optional[str] = None,
-              out_row_map: Optional[torch.Tensor] = None, y_ld: int = 0, res_ld: int = 0) -> torch.Tensor:
+              out_row_map: Optional[torch.Tensor] = None, y_ld: int = 0, res_ld: int = 0, out_hw: Optional[Tuple[int, int]] = None,
+              out_rows_per_image: int = 0) -> torch.Tensor:
     """y = act(conv(x, w) + bias [+ residual]); x [B,H,W,Cin] contiguous channels-last storage."""
     _need_cuda(x, w_packed, bias, residual)
     assert x.dim() == 4 and x.is_contiguous()
@@ -73,18 +74,22 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     cout = w_packed.shape[0]
     ho = conv_out_size(h, kh, stride[0], pad[0], dil[0])
     wo = conv_out_size(w_, kw, stride[1], pad[1], dil[1])
+    if out_hw is not None:      # explicit output grid (taps beyond the image read zeros): data-gradient phases
+        ho, wo = out_hw
     od = out_dtype or x.dtype
     if out is None:
         assert y_ld == 0
         out = torch.empty((b, ho, wo, cout), dtype=od, device=x.device)
-    elif y_ld == 0:
+    elif y_ld == 0 and out_rows_per_image == 0:
         assert out.is_contiguous() and out.numel() == b * ho * wo * cout and out.dtype == od
+    elif y_ld == 0:
+        assert out.is_contiguous() and out.numel() == b * out_rows_per_image * cout and out.dtype == od
     else:  # `out` is a column-slice view of a [rows, y_ld] buffer: its data_ptr is the slice start
         assert out.dtype == od and out.stride(-1) == 1
     if residual is not None:
         assert residual.dtype == x.dtype and residual.stride(-1) == 1
         if res_ld == 0:
-            assert residual.is_contiguous() and residual.numel() == b * ho * wo * cout
+            assert residual.is_contiguous() and residual.numel() == b * (out_rows_per_image or ho * wo) * cout
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == cout
     assert w_packed.dtype == x.dtype and w_packed.shape[1] == packed_k(cin, kh, kw, x.dtype)
@@ -96,7 +101,8 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
                  residual.data_ptr() if residual is not None else None, out.data_ptr(),
                  out_row_map.data_ptr() if out_row_map is not None else None,
                  b, h, w_, cin, ho, wo, cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1],
-                 act_code, dt_code(x.dtype), dt_code(od), tile, out_row_map.numel() if out_row_map is not None else 0, y_ld, res_ld)
+                 act_code, dt_code(x.dtype), dt_code(od), tile, out_row_map.numel() if out_row_map is not None else 0, y_ld, res_ld,
+                 out_rows_per_image)
     check(lib.mt4_conv_nhwc(C.byref(d), _stream()), "mt4_conv_nhwc")
     return out
 
@@ -345,3 +351,86 @@ def transpose_pack_conv1d(w_packed: torch.Tensor, cout: int, cin: int, taps: int
     wt = torch.empty((cin, kt), dtype=torch.float32, device=w_packed.device) if out is None else out
     check(lib.mt4_transpose_pack_conv1d_f32(w_packed.data_ptr(), wt.data_ptr(), cout, cin, taps, _stream()), "mt4_transpose_pack_conv1d_f32")
     return wt
+
+
+# ----------------------------------------------------------------------------------------- spatial training pieces (fp32)
+def bn_stats(x2d, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    _need_cuda(x2d)
+    m, c = x2d.shape
+    sums = torch.zeros(2 * c, dtype=torch.float64, device=x2d.device)   # scratch: float64 accumulators
+    mean, invstd = torch.empty(c, device=x2d.device), torch.empty(c, device=x2d.device)
+    check(lib.mt4_bn_stats_f32(x2d.data_ptr(), sums.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                               running_mean.data_ptr() if running_mean is not None else None,
+                               running_var.data_ptr() if running_var is not None else None, m, c, momentum, eps, _stream()), "mt4_bn_stats_f32")
+    return mean, invstd
+
+
+def bn_apply(x2d, mean, invstd, gamma, beta, residual=None, relu=True):
+    y = torch.empty_like(x2d)
+    m, c = x2d.shape
+    check(lib.mt4_bn_apply_f32(x2d.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                               residual.data_ptr() if residual is not None else None, y.data_ptr(), m, c, 1 if relu else 0, _stream()),
+          "mt4_bn_apply_f32")
+    return y
+
+
+def bn_backward(dy, y_post, x2d, mean, invstd, gamma, dgamma, dbeta, relu=True, want_dres=False):
+    m, c = x2d.shape
+    sums = torch.zeros(2 * c, dtype=torch.float64, device=x2d.device)   # scratch: float64 accumulators
+    dx = torch.empty_like(x2d)
+    dres = torch.empty_like(x2d) if want_dres else None
+    check(lib.mt4_bn_backward_f32(dy.data_ptr(), y_post.data_ptr() if y_post is not None else None, x2d.data_ptr(), mean.data_ptr(),
+                                  invstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(), dx.data_ptr(), dres.data_ptr() if want_dres else None,
+                                  dgamma.data_ptr(), dbeta.data_ptr(), m, c, 1 if relu else 0, _stream()), "mt4_bn_backward_f32")
+    return dx, dres
+
+
+def wgrad_conv2d(dy, x, dw_packed, kh, kw, stride, pad, dil=(1, 1)):
+    """dy [B,Ho,Wo,Cout], x [B,H,W,Cin]; dw_packed is zeroed here and filled"""
+    _need_cuda(dy, x, dw_packed)
+    b, ho, wo, cout = dy.shape
+    _, h, w, cin = x.shape
+    assert dw_packed.shape == (cout, packed_k(cin, kh, kw, torch.float32)) and dy.is_contiguous() and x.is_contiguous()
+    dw_packed.zero_()
+    check(lib.mt4_wgrad_conv2d_f32(dy.data_ptr(), x.data_ptr(), dw_packed.data_ptr(), b, h, w, cin, ho, wo, cout, kh, kw, stride[0], stride[1],
+                                   pad[0], pad[1], dil[0], dil[1], _stream()), "mt4_wgrad_conv2d_f32")
+
+
+def maxpool3x3s2_bwd(x, dy):
+    b, h, w, c = x.shape
+    dx = torch.zeros_like(x)
+    check(lib.mt4_maxpool3x3s2_bwd_f32(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), b, h, w, c, _stream()), "mt4_maxpool3x3s2_bwd_f32")
+    return dx
+
+
+def avgpool_bwd(dfeat, b, hw, c):
+    dx = torch.empty((b, hw, c), dtype=torch.float32, device=dfeat.device)
+    check(lib.mt4_avgpool_bwd_f32(dfeat.data_ptr(), dx.data_ptr(), b, hw, c, _stream()), "mt4_avgpool_bwd_f32")
+    return dx
+
+
+def bce_logits_pw(y, z, pos_weight, col_scale, dy, col_loss):
+    m, n = z.shape
+    check(lib.mt4_bce_logits_pw_f32(y.data_ptr(), z.data_ptr(), pos_weight.data_ptr() if pos_weight is not None else None, col_scale.data_ptr(),
+                                    dy.data_ptr(), col_loss.data_ptr(), m, n, y.stride(0), dy.stride(0), _stream()), "mt4_bce_logits_pw_f32")
+
+
+def distill_kl(y_s, t_pred, dy_s, loss, temp, grad_scale, accumulate=True):
+    b, k = t_pred.shape
+    check(lib.mt4_distill_kl_f32(y_s.data_ptr(), t_pred.data_ptr(), dy_s.data_ptr(), loss.data_ptr(), b, k, y_s.stride(0), dy_s.stride(0), temp,
+                                 grad_scale, 1 if accumulate else 0, _stream()), "mt4_distill_kl_f32")
+
+
+def mse(a, b, loss, grad_scale):
+    da = torch.empty_like(a)
+    check(lib.mt4_mse_f32(a.data_ptr(), b.data_ptr(), da.data_ptr(), loss.data_ptr(), a.numel(), grad_scale, _stream()), "mt4_mse_f32")
+    return da
+
+
+def kd_mix_bwd(s, teas, gs):
+    b, c = s.shape
+    ds = torch.empty_like(s)
+    dtau = torch.empty((b, 3), dtype=torch.float32, device=s.device)
+    check(lib.mt4_kd_mix_bwd_f32(s.data_ptr(), teas[0].data_ptr(), teas[1].data_ptr(), teas[2].data_ptr(), gs[0].data_ptr(), gs[1].data_ptr(),
+                                 gs[2].data_ptr(), ds.data_ptr(), dtau.data_ptr(), b, c, _stream()), "mt4_kd_mix_bwd_f32")
+    return ds, dtau

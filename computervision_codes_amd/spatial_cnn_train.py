@@ -1,0 +1,342 @@
+"""One training step of the spatial student on MI355X (`Spatial_cnn/run.py:145-224`): train-mode ResNet-18/50 trunk
+(BatchNorm on batch statistics), KD branch (`network.py:47-71`), hard BCE (pos_weight) + soft DistillKL + feature MSE
+(`run.py:159-192,284-295,322-328`), backward and SGD (`:342-351`) as explicit HIP launches -- no autograd.  fp32, NHWC.
+
+* conv forward / data gradient: `mt4_conv_nhwc` (data gradient = conv of dY with the transposed, tap-reversed weights;
+  stride-2 3x3 convs as 4 sub-pixel phases and the stride-2 1x1 downsample as one phase, scattered through the output row
+  map into dX);  weight gradient: `mt4_wgrad_conv2d_f32` / `mt4_wgrad_conv1d_f32`;
+* BatchNorm: `mt4_bn_stats_f32` + `mt4_bn_apply_f32` forward, `mt4_bn_backward_f32` (ReLU gate and residual fan-out fused);
+* losses: `mt4_bce_logits_pw_f32`, `mt4_distill_kl_f32`, `mt4_mse_f32`; KD mixing `mt4_kd_mix` / `mt4_kd_mix_bwd_f32`;
+* one flat fp32 parameter buffer and one flat gradient buffer (packed layouts) -> ONE all-reduce per step for DDP, one
+  `mt4_sgd_step_f32`.  BatchNorm statistics stay per GPU, like the reference's plain `BatchNorm2d`.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .shapes import resnet_feat_dim, spatial_cnn_shapes
+from .tenco_train import allreduce_sum_flat
+
+_DEPTHS = {"resnet18": (2, 2, 2, 2), "resnet50": (3, 4, 6, 3)}
+_HEADS = (("i", 6), ("v", 10), ("t", 15), ("ivt", 100))
+NH, NHP, TD = 131, 132, 1536
+# `Spatial_cnn/run.py:306-311`
+TOOL_W = [0.93487068, 0.94234964, 0.93487068, 1.18448115, 1.02368339, 0.97974447]
+VERB_W = [0.60002400, 0.60002400, 0.60002400, 0.61682467, 0.67082683, 0.80163207, 0.70562823, 2.11208448, 2.69230769, 0.60062402]
+TARGET_W = [0.49752894, 0.52041527, 0.49752894, 0.51394739, 2.71899565, 1.75577963, 0.58509403, 1.25228034, 0.49752894, 2.42993134,
+            0.49802647, 0.87266576, 1.36074165, 0.50150917, 0.49802647]
+F32 = torch.float32
+
+
+class _Unit:
+    """conv + BatchNorm (+ReLU) with its parameter / gradient views"""
+    __slots__ = ("name", "bn", "cin", "cout", "k", "stride", "pad", "w", "gw", "gamma", "beta", "ggamma", "gbeta", "rmean", "rvar", "wt", "phase_w")
+
+
+class SpatialCnnTrainer:
+    def __init__(self, network: str = "resnet50", lr: float = 0.01, weight_decay: float = 1e-5, rates: Sequence[float] = (1.0, 1.0, 1.0),
+                 temp: float = 4.0, device: str = "cuda", process_group=None):
+        self.network, self.lr, self.wd, self.rates, self.temp = network, lr, weight_decay, tuple(rates), float(temp)
+        self.dev, self.pg = torch.device(device), process_group
+        self.C = resnet_feat_dim(network)
+        self._table = spatial_cnn_shapes(network)
+        self.units: Dict[str, _Unit] = {}
+        self.nbt: Dict[str, int] = {}
+        self._extra: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ parameters
+    def _unit_specs(self):
+        pre = "basemodel.basemodel."
+        specs = [(pre + "conv1", pre + "bn1", 4, 64, 7, 2, 0)]   # stem on the physically padded 4-channel image
+        bott = self.network == "resnet50"
+        cin = 64
+        for li, (planes, n) in enumerate(zip((64, 128, 256, 512), _DEPTHS[self.network]), start=1):
+            for b in range(n):
+                s = 2 if (b == 0 and li > 1) else 1
+                q = f"{pre}layer{li}.{b}."
+                cout = planes * (4 if bott else 1)
+                if bott:
+                    specs += [(q + "conv1", q + "bn1", cin, planes, 1, 1, 0), (q + "conv2", q + "bn2", planes, planes, 3, s, 1),
+                              (q + "conv3", q + "bn3", planes, cout, 1, 1, 0)]
+                else:
+                    specs += [(q + "conv1", q + "bn1", cin, planes, 3, s, 1), (q + "conv2", q + "bn2", planes, planes, 3, 1, 1)]
+                if b == 0 and (s != 1 or cin != cout):
+                    specs.append((q + "downsample.0", q + "downsample.1", cin, cout, 1, s, 0))
+                cin = cout
+        return specs
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        assert all(k in sd for k, _ in self._table), "state dict incomplete"
+        dev, C = self.dev, self.C
+        specs = self._unit_specs()
+        lin = [("heads", NHP, C), ("wi", TD, C), ("wv", TD, C), ("wt", TD, C), ("mi", C, TD), ("mv", C, TD), ("mt", C, TD)]
+        r4 = lambda n: (n + 3) // 4 * 4
+        total = sum(co * ops.packed_k(ci, k, k, F32) + 2 * r4(co) for _, _, ci, co, k, _, _ in specs)
+        total += sum(co * ops.packed_k(ci, 1, 1, F32) + r4(co) for _, co, ci in lin)
+        self.P, self.G = torch.zeros(total, dtype=F32, device=dev), torch.zeros(total, dtype=F32, device=dev)
+        off = 0
+
+        def take(n, shape=None):
+            nonlocal off
+            p, g = self.P[off:off + n], self.G[off:off + n]
+            off += r4(n)
+            return (p.view(shape), g.view(shape)) if shape else (p, g)
+
+        trained = set()
+        for conv, bn, ci, co, k, s, pad in specs:
+            u = _Unit()
+            u.name, u.bn, u.cin, u.cout, u.k, u.stride, u.pad = conv, bn, ci, co, k, s, pad
+            kp = ops.packed_k(ci, k, k, F32)
+            u.w, u.gw = take(co * kp, (co, kp))
+            u.gamma, u.ggamma = take(co)
+            u.beta, u.gbeta = take(co)
+            w = sd[conv + ".weight"].float().to(dev)
+            if ci == 4 and k == 7:
+                w = torch.cat([w, torch.zeros(co, 1, 7, 7, device=dev)], 1)
+            u.w.copy_(ops.pack_conv_weight(w, None, F32))
+            u.gamma.copy_(sd[bn + ".weight"].float())
+            u.beta.copy_(sd[bn + ".bias"].float())
+            u.rmean, u.rvar = sd[bn + ".running_mean"].float().to(dev).clone(), sd[bn + ".running_var"].float().to(dev).clone()
+            self.nbt[bn] = int(sd[bn + ".num_batches_tracked"])
+            u.wt, u.phase_w = None, None
+            self.units[conv] = u
+            trained |= {conv + ".weight", bn + ".weight", bn + ".bias", bn + ".running_mean", bn + ".running_var", bn + ".num_batches_tracked"}
+        self.lin: Dict[str, tuple] = {}
+        for name, co, ci in lin:
+            kp = ops.packed_k(ci, 1, 1, F32)
+            w, gw = take(co * kp, (co, kp))
+            b, gb = take(co)
+            if name == "heads":
+                wsrc = torch.cat([sd[f"classifier_{t}.fc.weight"].float() for t, _ in _HEADS] + [torch.zeros(NHP - NH, C)], 0)
+                bsrc = torch.cat([sd[f"classifier_{t}.fc.bias"].float() for t, _ in _HEADS] + [torch.zeros(NHP - NH)], 0)
+                trained |= {f"classifier_{t}.fc.{p}" for t, _ in _HEADS for p in ("weight", "bias")}
+            else:
+                wsrc, bsrc = sd[name + ".weight"].float()[:, :, 0], sd[name + ".bias"].float()
+                trained |= {name + ".weight", name + ".bias"}
+            w.copy_(ops.pack_linear_weight(wsrc.to(dev), F32))
+            b.copy_(bsrc.to(dev))
+            self.lin[name] = (w, b, gw, gb, co, ci)
+        assert off == total
+        self._extra = {k: sd[k].detach().clone() for k, _ in self._table if k not in trained}   # the trunk's unused 1000-way fc
+        self.pos_weight = torch.tensor(TOOL_W + VERB_W + TARGET_W + [1.0] * 100, dtype=F32, device=dev)
+        self._refresh_transposed()
+        return self
+
+    def _refresh_transposed(self):
+        """weights of the data-gradient convolutions, rebuilt from the master weights after every update"""
+        for u in self.units.values():
+            if u.cin == 4:
+                continue   # stem: the image needs no gradient
+            taps = u.k * u.k
+            if u.stride == 1 or u.k == 1:
+                u.wt = ops.transpose_pack_conv1d(u.w, u.cout, u.cin, taps, out=u.wt)
+            else:   # 3x3 stride 2 pad 1: sub-pixel phases (device index/permute copies of 1-4 taps each)
+                w9 = u.w[:, :9 * u.cin].view(u.cout, 3, 3, u.cin)
+                sel = {0: [1], 1: [2, 0]}   # phase parity -> original taps, in the order of the data-gradient offsets 0, +1
+                u.phase_w = {}
+                for ph in (0, 1):
+                    for pw in (0, 1):
+                        sub = w9[:, sel[ph]][:, :, sel[pw]]                               # [Cout, kh', kw', Cin]
+                        sub = sub.permute(3, 1, 2, 0).contiguous()                        # [Cin, kh', kw', Cout]
+                        u.phase_w[(ph, pw)] = (ops.pack_conv_weight(sub.permute(0, 3, 1, 2).contiguous(), None, F32), len(sel[ph]), len(sel[pw]))
+        for name, (w, b, gw, gb, co, ci) in self.lin.items():
+            pass   # linear data gradients use transpose_pack on the fly (small)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        out = dict(self._extra)
+        for u in self.units.values():
+            taps = u.k * u.k
+            tapw = (u.cin + 3) // 4 * 4
+            w = u.w[:, :taps * tapw].reshape(u.cout, u.k, u.k, tapw)[..., :u.cin].permute(0, 3, 1, 2).contiguous().cpu()
+            if u.cin == 4:
+                w = w[:, :3].contiguous()
+            out[u.name + ".weight"] = w
+            out[u.bn + ".weight"], out[u.bn + ".bias"] = u.gamma.clone().cpu(), u.beta.clone().cpu()
+            out[u.bn + ".running_mean"], out[u.bn + ".running_var"] = u.rmean.clone().cpu(), u.rvar.clone().cpu()
+            out[u.bn + ".num_batches_tracked"] = torch.tensor(self.nbt[u.bn], dtype=torch.int64)
+        for name, (w, b, gw, gb, co, ci) in self.lin.items():
+            ww, bb = w[:, :ci].clone().cpu(), b.clone().cpu()
+            if name == "heads":
+                o = 0
+                for t, k in _HEADS:
+                    out[f"classifier_{t}.fc.weight"], out[f"classifier_{t}.fc.bias"] = ww[o:o + k].clone(), bb[o:o + k].clone()
+                    o += k
+            else:
+                out[name + ".weight"], out[name + ".bias"] = ww.unsqueeze(-1), bb
+        return {k: out[k] for k, _ in self._table}
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        for u in self.units.values():
+            taps, tapw = u.k * u.k, (u.cin + 3) // 4 * 4
+            g = u.gw[:, :taps * tapw].reshape(u.cout, u.k, u.k, tapw)[..., :u.cin].permute(0, 3, 1, 2).contiguous().cpu()
+            out[u.name + ".weight"] = g[:, :3].contiguous() if u.cin == 4 else g
+            out[u.bn + ".weight"], out[u.bn + ".bias"] = u.ggamma.clone().cpu(), u.gbeta.clone().cpu()
+        for name, (w, b, gw, gb, co, ci) in self.lin.items():
+            gg, gbb = gw[:, :ci].clone().cpu(), gb.clone().cpu()
+            if name == "heads":
+                o = 0
+                for t, k in _HEADS:
+                    out[f"classifier_{t}.fc.weight"], out[f"classifier_{t}.fc.bias"] = gg[o:o + k].clone(), gbb[o:o + k].clone()
+                    o += k
+            else:
+                out[name + ".weight"], out[name + ".bias"] = gg.unsqueeze(-1), gbb
+        return out
+
+    # ------------------------------------------------------------------ building blocks
+    def _fwd_unit(self, u: _Unit, x, residual=None, relu=True, saved=None):
+        z = ops.conv_nhwc(x, u.w, None, kh=u.k, kw=u.k, stride=(u.stride, u.stride), pad=(u.pad, u.pad))
+        b, ho, wo, c = z.shape
+        z2 = z.view(-1, c)
+        mean, invstd = ops.bn_stats(z2, u.rmean, u.rvar)
+        self.nbt[u.bn] += 1
+        a = ops.bn_apply(z2, mean, invstd, u.gamma, u.beta, residual.view(-1, c) if residual is not None else None, relu).view(b, ho, wo, c)
+        saved.append((u, x, z, mean, invstd, a, relu))
+        return a
+
+    def _dgrad(self, u: _Unit, dz, x_shape, residual=None):
+        """gradient w.r.t. the unit's input [B,H,W,Cin] from dz [B,Ho,Wo,Cout]"""
+        b, h, w, cin = x_shape
+        if u.stride == 1:
+            p = u.k - 1 - u.pad
+            return ops.conv_nhwc(dz, u.wt, None, kh=u.k, kw=u.k, pad=(p, p), residual=residual)
+        assert h % 2 == 0 and w % 2 == 0, "stride-2 data gradient is built for even input sizes"
+        ho, wo = dz.shape[1], dz.shape[2]
+        dx = torch.zeros((b, h, w, cin), dtype=F32, device=dz.device) if (u.k == 1 and residual is None) else \
+            (residual.clone() if u.k == 1 else torch.empty((b, h, w, cin), dtype=F32, device=dz.device))
+        aa, bb = torch.meshgrid(torch.arange(ho), torch.arange(wo), indexing="ij")
+        if u.k == 1:   # dX[2a][2b] = W^T dY[a][b]; every other position keeps the residual (or zero)
+            rm = ((2 * aa) * w + 2 * bb).reshape(-1).to(torch.int32).to(dz.device)
+            ops.conv_nhwc(dz, u.wt, None, kh=1, kw=1, residual=dx if residual is not None else None, out=dx, out_row_map=rm, out_rows_per_image=h * w)
+            return dx
+        for (ph, pw), (wsub, khs, kws) in u.phase_w.items():
+            rm = ((2 * aa + ph) * w + 2 * bb + pw).reshape(-1).to(torch.int32).to(dz.device)
+            ops.conv_nhwc(dz, wsub, None, kh=khs, kw=kws, out_hw=(ho, wo), residual=residual, out=dx, out_row_map=rm, out_rows_per_image=h * w)
+        return dx
+
+    def _bwd_unit(self, rec, dy, residual_for_dx=None, want_dres=False, need_dx=True):
+        u, x, z, mean, invstd, a, relu = rec
+        c = z.shape[-1]
+        dz, dres = ops.bn_backward(dy.reshape(-1, c), a.view(-1, c) if relu else None, z.view(-1, c), mean, invstd, u.gamma, u.ggamma, u.gbeta,
+                                   relu=relu, want_dres=want_dres)
+        dz = dz.view(z.shape)
+        ops.wgrad_conv2d(dz, x, u.gw, u.k, u.k, (u.stride, u.stride), (u.pad, u.pad))
+        dx = self._dgrad(u, dz, x.shape, residual_for_dx) if need_dx else None
+        return dx, (dres.view(z.shape) if dres is not None else None)
+
+    def _linear_fwd(self, name, x):
+        w, b, _, _, co, ci = self.lin[name]
+        return ops.linear(x, w, b)
+
+    def _linear_bwd(self, name, dy, x, need_dx=True):
+        w, b, gw, gb, co, ci = self.lin[name]
+        ops.wgrad_conv1d(dy, x, gw, batch=1, t=x.shape[0], taps=1, dil=1, pad=0)
+        ops.colsum(dy, gb)
+        if not need_dx:
+            return None
+        wt = ops.transpose_pack_conv1d(w, co, ci, 1)
+        return ops.linear(dy, wt, None)
+
+    # ------------------------------------------------------------------ one step
+    def train_step(self, frames, labels, teacher_pred, teacher_feat, apply_update: bool = True):
+        """frames: normalised float32 NCHW [B,3,H,W] or uint8 NHWC on the GPU; labels (y_i, y_v, y_t, y_ivt) multi-hot [B,K];
+        teacher_pred 3 x raw logits [B,K]; teacher_feat 3 x [B,1536].  Returns dict of loss terms."""
+        from .synth import IMAGENET_MEAN, IMAGENET_STD
+        dev, C = self.dev, self.C
+        if frames.dtype == torch.uint8:
+            B, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+            xp = ops.preprocess_u8(frames, IMAGENET_MEAN, IMAGENET_STD, F32)
+        else:
+            B, H, W = frames.shape[0], frames.shape[2], frames.shape[3]
+            xp = ops.pad_nchw(frames, F32)
+        saved: List[tuple] = []
+        self.last_saved = saved          # (unit, input, conv output, mean, invstd, post-activation, relu) per conv+BN, forward order
+        pre = "basemodel.basemodel."
+        U = self.units
+        a0 = self._fwd_unit(U[pre + "conv1"], xp, saved=saved)
+        x = ops.maxpool3x3s2(a0)
+        blocks = []
+        bott = self.network == "resnet50"
+        for li, n in enumerate(_DEPTHS[self.network], start=1):
+            for bi in range(n):
+                q = f"{pre}layer{li}.{bi}."
+                first = len(saved)
+                has_ds = (q + "downsample.0") in U
+                idt = self._fwd_unit(U[q + "downsample.0"], x, relu=False, saved=saved) if has_ds else x
+                o = self._fwd_unit(U[q + "conv1"], x, saved=saved)
+                if bott:
+                    o = self._fwd_unit(U[q + "conv2"], o, saved=saved)
+                    x = self._fwd_unit(U[q + "conv3"], o, residual=idt, saved=saved)
+                else:
+                    x = self._fwd_unit(U[q + "conv2"], o, residual=idt, saved=saved)
+                blocks.append((first, has_ds, bott))
+        Bh, Hh, Wh, _ = x.shape
+        feat = ops.global_avgpool(x)                                               # [B, C]
+        # ---- heads, KD branch
+        logits = self._linear_fwd("heads", feat)                                   # [B, 132]
+        tf = [t.to(dev, F32).contiguous() for t in teacher_feat]
+        teas = [self._linear_fwd(m, t) for m, t in zip(("mi", "mv", "mt"), tf)]
+        mixed = ops.kd_mix(feat, *teas)
+        cams = [self._linear_fwd(wn, mx) for wn, mx in zip(("wi", "wv", "wt"), mixed)]
+        # ---- losses and their gradients
+        r0, r1, r2 = self.rates
+        z = torch.cat([l.to(dev, F32) for l in labels], 1).contiguous()
+        col_scale = torch.cat([torch.full((k,), r0 / (B * k)) for _, k in _HEADS]).to(dev)
+        col_loss = torch.zeros(NH, device=dev)
+        dlog = torch.zeros((B, NHP), device=dev)
+        ops.bce_logits_pw(logits[:, :NH], z, self.pos_weight, col_scale, dlog, col_loss)
+        soft = torch.zeros(1, device=dev)
+        o = 0
+        for (t, k), tp in zip(_HEADS[:3], teacher_pred):
+            ops.distill_kl(logits[:, o:o + k], tp.to(dev, F32).contiguous(), dlog[:, o:o + k], soft, self.temp, r1 / 3.0, accumulate=True)
+            o += k
+        kdl = torch.zeros(1, device=dev)
+        dcams = [ops.mse(c, t, kdl, r2 / 3.0) for c, t in zip(cams, tf)]
+        # ---- backward: heads + KD branch -> dfeat
+        dfeat = self._linear_bwd("heads", dlog, feat)
+        gs = [self._linear_bwd(wn, dc, mx) for wn, dc, mx in zip(("wi", "wv", "wt"), dcams, mixed)]
+        ds_kd, dtau = ops.kd_mix_bwd(feat, teas, gs)
+        dfeat = ops.mul_add(dfeat, torch.ones_like(dfeat), ds_kd)
+        for n, (m, t) in enumerate(zip(("mi", "mv", "mt"), tf)):
+            dte = dtau[:, n:n + 1].expand(B, C).contiguous()                        # d(tea_n)[b][:] = dtau[b][n]
+            self._linear_bwd(m, dte, t, need_dx=False)
+        # ---- backward through the trunk
+        dx = ops.avgpool_bwd(dfeat, Bh, Hh * Wh, C).view(Bh, Hh, Wh, C)
+        for first, has_ds, bott in reversed(blocks):
+            recs = saved[first:first + (1 if has_ds else 0) + (3 if bott else 2)]
+            main = recs[1:] if has_ds else recs
+            d, dres = self._bwd_unit(main[-1], dx, want_dres=True)                  # last conv: ReLU gate after the residual add
+            for rec in reversed(main[1:-1]):
+                d, _ = self._bwd_unit(rec, d)
+            if has_ds:
+                d_id, _ = self._bwd_unit(recs[0], dres)                             # identity path through downsample conv+bn
+                dx, _ = self._bwd_unit(main[0], d, residual_for_dx=d_id)
+            else:
+                dx, _ = self._bwd_unit(main[0], d, residual_for_dx=dres)
+        da0 = ops.maxpool3x3s2_bwd(a0, dx)
+        self._bwd_unit(saved[0], da0, need_dx=False)
+        # ---- scalars
+        cl = col_loss.cpu()
+        terms, o = {}, 0
+        hard = 0.0
+        for t, k in _HEADS:
+            terms["hard_" + t] = float(cl[o:o + k].sum() / (B * k))
+            hard += terms["hard_" + t]
+            o += k
+        terms.update(hard=hard, soft=float(soft.item()) / 3.0, kd=float(kdl.item()) / 3.0)
+        terms["loss"] = r0 * terms["hard"] + r1 * terms["soft"] + r2 * terms["kd"]
+        if apply_update:
+            self.apply_update()
+        return terms
+
+    def relu_outputs(self) -> Dict[str, torch.Tensor]:
+        """post-ReLU activations of the last step by BatchNorm name, NCHW on the host (tests: ReLU-gate comparison)"""
+        return {u.bn: a.permute(0, 3, 1, 2).cpu() for (u, _, _, _, _, a, relu) in self.last_saved if relu}
+
+    def apply_update(self):
+        scale = allreduce_sum_flat(self.G, self.pg)
+        ops.sgd_step(self.P, self.G, self.lr, self.wd, scale)
+        self._refresh_transposed()

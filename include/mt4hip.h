@@ -75,6 +75,8 @@ typedef struct mt4_conv_desc {
     int32_t y_ld;       /* row pitch of y in elements (0 = Cout): lets a GEMM write a column slice of a wider buffer
                            (Temporal_Mixer's channel concat, TS_Mixer.py:83) */
     int32_t res_ld;     /* row pitch of residual in elements (0 = Cout) */
+    int32_t out_rows_per_image; /* with out_row_map: rows per image on the OUTPUT side (0 = out_row_map_len); > len scatters
+                                   the result into a larger image (sub-pixel phases of a strided conv's data gradient) */
 } mt4_conv_desc;
 
 int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream);
@@ -191,6 +193,39 @@ int mt4_sgd_step_f32(float* p, const float* g, int64_t n, float lr, float weight
 int mt4_mul_add_f32(const float* a, const float* b, const float* c, float* y, int64_t n, void* stream);
 /* packed Conv1d weight [Cout][Kpad(Cin,taps)] -> packed weight of its data-gradient conv [Cin][Kpad(Cout,taps)] */
 int mt4_transpose_pack_conv1d_f32(const float* w_packed, float* wt_packed, int32_t Cout, int32_t Cin, int32_t taps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training step of the spatial stage (Spatial_cnn/run.py:145-224).  fp32, channels-last.
+ */
+/* BatchNorm2d in training mode: batch mean / biased variance over the M rows of x [M][C] -> mean, invstd; running stats
+ * updated with `momentum` and the unbiased variance (may be NULL).  sums_zeroed: 2*C DOUBLES, zero on entry
+ * (the per-channel reductions accumulate in float64, like the CPU BatchNorm of torch). */
+int mt4_bn_stats_f32(const float* x, double* sums_zeroed, float* mean, float* invstd, float* running_mean, float* running_var, int64_t M,
+                     int32_t C, float momentum, float eps, void* stream);
+/* y = act((x - mean) * invstd * gamma + beta [+ residual]); relu 0/1 (resnet.py:105-119) */
+int mt4_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* residual,
+                     float* y, int64_t M, int32_t C, int32_t relu, void* stream);
+/* backward of the above: dy' = relu ? (y_post > 0 ? dy : 0) : dy; dx (w.r.t. x), dres = dy' (w.r.t. residual, may be NULL),
+ * dgamma, dbeta.  sums_zeroed: 2*C floats. */
+int mt4_bn_backward_f32(const float* dy, const float* y_post, const float* x, const float* mean, const float* invstd, const float* gamma,
+                        double* sums_zeroed, float* dx, float* dres, float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t relu, void* stream);
+/* Conv2d weight gradient in the packed layout, accumulated with atomics into a zeroed buffer */
+int mt4_wgrad_conv2d_f32(const float* dy, const float* x, float* dw_packed_zeroed, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Ho,
+                         int32_t Wo, int32_t Cout, int32_t KH, int32_t KW, int32_t stride_h, int32_t stride_w, int32_t pad_h, int32_t pad_w,
+                         int32_t dil_h, int32_t dil_w, void* stream);
+/* MaxPool2d(3,2,1) backward (first maximum in scan order, like torch) into a zeroed dx; AdaptiveAvgPool2d(1) backward */
+int mt4_maxpool3x3s2_bwd_f32(const float* x, const float* dy, float* dx_zeroed, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int mt4_avgpool_bwd_f32(const float* dfeat, float* dx, int32_t B, int32_t HW, int32_t C, void* stream);
+/* losses of run.py:159-192: BCEWithLogitsLoss(pos_weight), DistillKL (T, on sigmoid(teacher)), MSELoss; each writes the
+ * gradient w.r.t. its first argument scaled by grad_scale / col_scale and ADDS its value to *loss / col_loss */
+int mt4_bce_logits_pw_f32(const float* y, const float* z, const float* pos_weight, const float* col_scale, float* dy, float* col_loss, int32_t M,
+                          int32_t N, int32_t ld_y, int32_t ld_dy, void* stream);
+int mt4_distill_kl_f32(const float* y_s, const float* t_pred, float* dy_s, float* loss, int32_t B, int32_t K, int32_t ld_y, int32_t ld_dy,
+                       float temp, float grad_scale, int32_t accumulate, void* stream);
+int mt4_mse_f32(const float* a, const float* b, float* da, float* loss, int64_t n, float grad_scale, void* stream);
+/* backward of mt4_kd_mix: ds [B][C] and dtau [B][3] (gradient w.r.t. the per-teacher sums) from g_n = dL/d(out_n) */
+int mt4_kd_mix_bwd_f32(const float* s, const float* tea_i, const float* tea_v, const float* tea_t, const float* g_i, const float* g_v,
+                       const float* g_t, float* ds, float* dtau, int32_t B, int32_t C, void* stream);
 
 #ifdef __cplusplus
 }

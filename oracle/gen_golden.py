@@ -400,12 +400,90 @@ def gen_tenco_train(name):
         torch.set_grad_enabled(False)
 
 
+# ------------------------------------------------------------------------------------------ spatial_cnn train step
+CNN_TRAIN_CASES = {
+    "cnn_train_resnet18": dict(network="resnet18", B=4, H=64, W=64, seed=601, lr=0.05, rates=(1.0, 1.0, 1.0)),
+    # damp: see oracle/spatial_cnn_train.py damp_residual_gamma -- one well-conditioned ResNet-50 case, one with the plain fill
+    "cnn_train_resnet50": dict(network="resnet50", B=8, H=64, W=96, seed=602, lr=0.05, rates=(1.0, 1.0, 1.0), damp=0.1),
+    "cnn_train_resnet50_hard": dict(network="resnet50", B=3, H=96, W=64, seed=603, lr=0.05, rates=(1.0, 0.0, 0.0)),
+}
+
+
+def cnn_train_inputs(cfg):
+    img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["H"], cfg["W"], seed=cfg["seed"]))
+    labels = [torch.from_numpy((synth.uniform01(cfg["seed"], 700 + i, cfg["B"] * k) < 0.15).reshape(cfg["B"], k).astype(np.int64))
+              for i, k in enumerate((6, 10, 15, 100))]
+    tpred = [synth.synthetic_features(cfg["B"], k, seed=cfg["seed"] + 10 + i)[0] * 2.0 for i, k in enumerate((6, 10, 15))]
+    tfeat = [synth.synthetic_features(cfg["B"], 1536, seed=cfg["seed"] + 20 + i)[0] for i in range(3)]
+    return img, labels, tpred, tfeat
+
+
+def gen_cnn_train(name):
+    """The reference `VideoNas` in train() mode (BatchNorm batch statistics, KD branch on) + its losses (`run.py:159-192,284-295`)
+    + torch.optim.SGD for one step."""
+    from oracle import spatial_cnn_train as o_ct
+    cfg = CNN_TRAIN_CASES[name]
+    torch.set_grad_enabled(True)
+    try:
+        m = _ref_spatial_cnn(cfg["network"], "all", train=True)
+        m.train()
+        table = shapes.spatial_cnn_shapes(cfg["network"])
+        sd = o_ct.damp_residual_gamma(synth.fill_from_shapes(table, seed=cfg["seed"]), cfg["network"], cfg.get("damp", 1.0))
+        m.load_state_dict(sd, strict=True)
+        img, labels, tpred, tfeat = cnn_train_inputs(cfg)
+        opt = torch.optim.SGD(m.parameters(), lr=cfg["lr"], weight_decay=1e-5)
+        (cam_i, li), (cam_v, lv), (cam_t, lt), (_, livt) = m(img, *tfeat)
+        f_i = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(o_ct.TOOL_W))
+        f_v = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(o_ct.VERB_W))
+        f_t = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(o_ct.TARGET_W))
+        f_ivt = torch.nn.BCEWithLogitsLoss()
+        hard = f_i(li, labels[0].float()) + f_v(lv, labels[1].float()) + f_t(lt, labels[2].float()) + f_ivt(livt, labels[3].float())
+        soft = sum(o_ct.distill_kl(l, torch.sigmoid(tp), 4.0) for l, tp in zip((li, lv, lt), tpred)) / 3
+        kd = sum(torch.nn.functional.mse_loss(c, f) for c, f in zip((cam_i, cam_v, cam_t), tfeat)) / 3
+        r = cfg["rates"]
+        loss = r[0] * hard + r[1] * soft + r[2] * kd
+        for p_ in m.parameters():
+            p_.grad = None
+        loss.backward()
+        grads = {k: (p_.grad.clone() if p_.grad is not None else None) for k, p_ in m.named_parameters()}
+        opt.step()
+        new_ref = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        new_o, terms_o, g_o = o_ct.train_step(sd, img, labels, tpred, tfeat, cfg["network"], cfg["lr"], 1e-5, r, 4.0)
+        assert abs(terms_o["loss"] - float(loss)) < 2e-5 * max(1, abs(float(loss))), (terms_o["loss"], float(loss))
+        worst = 0.0
+        for k in new_ref:
+            e = _rel(new_o[k].float(), new_ref[k].float())
+            worst = max(worst, e)
+            assert e < 5e-4, (name, k, e)
+        outd = {"cfg": np.array(repr(cfg)), "loss": np.array(float(loss)), "hard": np.array(float(hard)), "soft": np.array(float(soft)),
+                "kd": np.array(float(kd))}
+        keys = list(new_ref)
+        outd["grad_norms"] = np.array([float(grads[k].norm()) if (k in grads and grads[k] is not None) else -1.0 for k in keys], dtype=np.float64)
+        # conditioning: how far the reference's own fp32 gradient is from the fp64 gradient of the same step (max-abs, relative to the
+        # tensor's max-abs) -- the tests scale their tolerance for each tensor with it
+        _, _, g64 = o_ct.train_step_f64(sd, img, labels, tpred, tfeat, network=cfg["network"], lr=cfg["lr"], weight_decay=1e-5, rates=r, temp=4.0)
+        outd["grad_cond"] = np.array([float((grads[k].double() - g64[k]).abs().max() / max(float(g64[k].abs().max()), 1e-30))
+                                      if (k in grads and grads[k] is not None) else -1.0 for k in keys], dtype=np.float64)
+        samp = ["basemodel.basemodel.conv1.weight", "basemodel.basemodel.bn1.weight", "basemodel.basemodel.bn1.running_mean",
+                "basemodel.basemodel.bn1.running_var", "basemodel.basemodel.layer1.0.conv1.weight", "basemodel.basemodel.layer2.0.conv2.weight",
+                "basemodel.basemodel.layer2.0.downsample.0.weight", "basemodel.basemodel.layer4.1.bn2.bias", "basemodel.basemodel.layer4.1.bn2.running_var",
+                "classifier_ivt.fc.weight", "classifier_v.fc.bias", "wi.weight", "mt.weight", "mv.bias"]
+        for k in samp:
+            flat = (new_ref[k].float() - sd[k].float()).flatten()
+            outd["delta::" + k] = flat[:: max(1, flat.numel() // 2048)].numpy()
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **outd)
+        print(name, "ok: loss", float(loss), "hard", float(hard), "soft", float(soft), "kd", float(kd), "worst oracle-vs-ref rel", worst)
+    finally:
+        torch.set_grad_enabled(False)
+
+
 GENERATORS = {}
 GENERATORS.update({k: gen_tenco for k in TENCO_CASES})
 GENERATORS.update({k: gen_cnn for k in CNN_CASES})
 GENERATORS.update({k: gen_q2l for k in Q2L_CASES})
 GENERATORS.update({k: gen_mstct for k in MSTCT_CASES})
 GENERATORS.update({k: gen_tenco_train for k in TRAIN_CASES})
+GENERATORS.update({k: gen_cnn_train for k in CNN_TRAIN_CASES})
 
 
 def main(argv):
