@@ -102,6 +102,136 @@ def spatial_cnn_test(argv=None) -> Dict[str, np.ndarray]:
     return all_feats
 
 
+# ------------------------------------------------------------------------------------------------ Spatial_cnn/run.py -t
+def _augment(im, rng, names):
+    """the reference's PIL-side train augmentations (`Spatial_cnn/dataloader.py:89-100`; its dict lists 'contrast' twice, so the later
+    RandomAutocontrast is the one in effect), drawn from `rng` (python `random.Random`)"""
+    from PIL import Image, ImageOps
+    for n in names:
+        if n == "vflip" and rng.random() < 0.4:
+            im = ImageOps.flip(im)
+        elif n == "hflip" and rng.random() < 0.4:
+            im = ImageOps.mirror(im)
+        elif n == "contrast" and rng.random() < 0.5:
+            im = ImageOps.autocontrast(im)
+        elif n == "rot90":
+            im = im.rotate(rng.uniform(-90.0, 90.0), resample=Image.NEAREST, expand=True)
+    return im
+
+
+def load_train_frames_u8(data_dir, video, frame_ids, height, width, rng, aug_names) -> np.ndarray:
+    """`Resize -> augmentations -> Resize` of the train transform (`dataloader.py:153-162`) -> uint8 [N,H,W,3]"""
+    from PIL import Image
+    out = np.empty((len(frame_ids), height, width, 3), np.uint8)
+    for i, fid in enumerate(frame_ids):
+        with Image.open(os.path.join(data_dir, "data", video, "{}.png".format(str(int(fid)).zfill(6)))) as im:
+            im = im.convert("RGB").resize((width, height), Image.BILINEAR)
+            im = _augment(im, rng, aug_names)
+            if im.size != (width, height):
+                im = im.resize((width, height), Image.BILINEAR)
+            out[i] = np.asarray(im)
+    return out
+
+
+def spatial_cnn_train(argv=None) -> Dict[str, float]:
+    """`Spatial_cnn/run.py -t` (:296-470): student distillation.  Shuffled frames of all training videos in batches of --batch; with
+    torchrun every rank takes its own batch of a step (frame-DDP: global batch = world x --batch), BatchNorm statistics stay per
+    GPU and the flat gradient buffer is all-reduced over RCCL once per step.  SGD without momentum, LinearLR warm-up ->
+    ExponentialLR per epoch, validation mAP every --val_interval epochs with `_latest.pth` / best `.pth` like `weight_mgt` (:258-269)."""
+    import random
+
+    from .spatial_cnn import VideoNas
+    from .spatial_cnn_train import SpatialCnnTrainer
+    from .tenco_train import lr_at_epoch
+    from . import shapes, synth
+    p = argparse.ArgumentParser()
+    _common(p)
+    p.add_argument("--network", type=str, default="resnet18")
+    p.add_argument("--student_dim", type=int, default=512)
+    p.add_argument("--teacher_dim", type=int, default=1536)
+    p.add_argument("--teacher_feat_version", type=str, default="Q2L")
+    p.add_argument("--teacher_pred_version", type=str, default="Q2LMSTCT")
+    p.add_argument("--augmentation_list", type=str, nargs="*", default=["original", "vflip", "hflip", "contrast", "rot90"])
+    p.add_argument("--epochs", type=int, default=100)
+    p.add_argument("-w", "--warmups", type=int, nargs="+", default=[9, 18, 58])
+    p.add_argument("-l", "--initial_learning_rates", type=float, nargs="+", default=[0.01, 0.01, 0.01])
+    p.add_argument("--rates", type=float, nargs="+", default=[1, 0, 0.1])
+    p.add_argument("--weight_decay", type=float, default=1e-5)
+    p.add_argument("--temp", type=int, default=4)
+    p.add_argument("--decay_rate", type=float, default=0.99)
+    p.add_argument("--power", type=float, default=0.1)
+    p.add_argument("--val_interval", type=int, default=1)
+    p.add_argument("--pretrain_dir", type=str, default="")
+    F, _ = p.parse_known_args(argv)
+    if F.loss_type != "all":
+        raise NotImplementedError("the student recipe trains with --loss_type all (Scripts/train_fold1.sh:24)")
+    rank, world = _dist()
+    kfold = F.kfold if "crossval" in F.dataset_variant else 0
+    modelname = f"{F.model}_l{F.dataset_variant}_cholect{kfold}"
+    model_dir = f"./__checkpoint__/run_{F.version}"
+    logfile = os.path.join(model_dir, modelname + ".log")
+    ckpt, latest = os.path.join(model_dir, modelname + ".pth"), os.path.join(model_dir, modelname + "_latest.pth")
+    val_interval = F.epochs - 1 if F.val_interval == -1 else F.val_interval
+    tr = SpatialCnnTrainer(F.network, lr=F.initial_learning_rates[2], weight_decay=F.weight_decay, rates=F.rates, temp=float(F.temp))
+    table = shapes.spatial_cnn_shapes(F.network, F.student_dim, F.teacher_dim)
+    sd = synth.fill_from_shapes(table, seed=F.seed)          # no torch.nn init here: deterministic synthetic start
+    for src in (F.pretrain_dir, latest):                     # `load_model` (:272-278): keys present in the model, strict=False
+        if src and os.path.exists(src):
+            sd.update({k: v for k, v in torch.load(src, map_location="cpu").items() if k in sd})
+    tr.load_state_dict(sd)
+    train_videos, val_videos, _ = cholect.split_videos(F.dataset_variant, kfold)
+    labels = {v: cholect.load_labels(F.data_dir, v) for v in train_videos + val_videos}
+    tdir = lambda ver, task, kind: featfile.feats_path("..", ver, kfold, task, kind)
+    tpred = {t: featfile.read_feats(tdir(F.teacher_pred_version, t, "pred")) for t in "ivt"}
+    tfeat = {t: featfile.read_feats(tdir(F.teacher_feat_version, t, "feats")) for t in "ivt"}
+    samples = [(v, i) for v in train_videos for i in range(len(labels[v]["ivt"]))]
+    order_rng, aug_rng = random.Random(F.seed), random.Random(F.seed * 1000003 + rank)
+    eval_args = argparse.Namespace(**vars(F))
+    eval_args.train = False
+    best, last = 0.0, {}
+    for epoch in range(F.epochs):
+        tr.lr = lr_at_epoch(epoch, F.initial_learning_rates[2], F.power, F.warmups[2], F.decay_rate)
+        order = list(samples)
+        order_rng.shuffle(order)                             # the same permutation on every rank
+        nb = (len(order) + F.batch - 1) // F.batch
+        steps = (nb + world - 1) // world
+        t0, tot = time.time(), 0.0
+        for s in range(steps):
+            bi = (s * world + rank) % nb
+            batch = order[bi * F.batch:(bi + 1) * F.batch]
+            frames = np.concatenate([load_train_frames_u8(F.data_dir, v, [labels[v]["ivt"][i, 0]], F.image_height, F.image_width, aug_rng,
+                                                          F.augmentation_list) for v, i in batch])
+            lab = [torch.from_numpy(np.stack([labels[v][k][i, 1:] for v, i in batch])) for k in ("i", "v", "t", "ivt")]
+            key = lambda v: featfile.video_key(v)
+            tp = [torch.from_numpy(np.stack([tpred[t][key(v)][i] for v, i in batch]).astype(np.float32)) for t in "ivt"]
+            tf = [torch.from_numpy(np.stack([tfeat[t][key(v)][i] for v, i in batch]).astype(np.float32)) for t in "ivt"]
+            terms = tr.train_step(torch.from_numpy(frames).cuda(), lab, tp, tf)
+            tot += terms["loss"]
+        last = {"loss": tot / steps, "lr": tr.lr}
+        if rank == 0:
+            _log(logfile, f"Traning | lr: {tr.lr:.6f} | epoch {epoch} | loss {tot / steps:.4f} | {time.time() - t0:.2f} secs")
+        if epoch % val_interval == 0 and rank == 0:          # `weight_mgt`: latest every validation, best by triplet mAP
+            state = tr.state_dict()
+            torch.save(state, latest)
+            model = VideoNas(args=eval_args, dtype=torch.float32).eval()
+            model.load_state_dict(state)
+            m = Recognition(100)
+            for v in val_videos:
+                lv = labels[v]["ivt"]
+                for s0 in range(0, len(lv), F.batch):
+                    fr = torch.from_numpy(cholect.load_frames_u8(F.data_dir, v, lv[s0:s0 + F.batch, 0], F.image_height, F.image_width)).cuda()
+                    m.update(lv[s0:s0 + F.batch, 1:], _sigmoid(model.extract_u8(fr)[3][1]))
+                m.video_end()
+            score = float(m.compute_video_AP()["mAP"]) if val_videos else 0.0
+            last["val_mAP_ivt"] = score
+            if score > best or not os.path.exists(ckpt):
+                best = max(best, score)
+                torch.save(state, ckpt)
+                _log(logfile, f">>> Saving checkpoint for epoch {epoch + 1} at {ckpt}, time {time.ctime()} ")
+            _log(logfile, f"\t\t\t\t\t\t\t video-wise | eta {time.time() - t0:.2f} secs | mAP => ivt: [{score:.5f}] ")
+    return last
+
+
 # ------------------------------------------------------------------------------------------------ Temporal_tenco/run.py -e
 def tenco_eval(argv=None) -> Dict[str, float]:
     from .temporal_tenco import VideoNas

@@ -64,3 +64,91 @@ def test_synth_is_deterministic_and_in_range():
     assert fr.dtype == torch.uint8 and fr.shape == (2, 8, 8, 3)
     # known-answer: guards the generator itself (golden fixtures depend on it)
     assert np.allclose(synth.uniform01(47, 0, 3), synth.uniform01(47, 0, 5)[:3])
+
+
+def test_q2l_oracle_matches_reference_outputs():
+    """Swin-T + Query2Label decoder(s) (`Spatial_transformer/network.py:82-128`), single-task and loss_type 'all' with KD"""
+    from oracle import swin_q2l as o_q
+    z, cfg = load_golden("q2l_swinT_224_i")
+    sd = synth.fill_from_shapes(shapes.q2l_param_shapes(cfg["backbone"], cfg["img"], cfg["hidden"], cfg["loss_type"]), seed=cfg["seed"])
+    img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["img"], cfg["img"], seed=cfg["seed"]))
+    with torch.no_grad():
+        out = o_q.q2l_forward(sd, img, cfg["backbone"], cfg["img"], cfg["hidden"], cfg["loss_type"])
+    _close(out[0][1], z["logits"], tol=1e-4)
+    _close(out[3][0], z["feat"], tol=1e-4)
+    z, cfg = load_golden("q2l_swinT_224_all")
+    sd = synth.fill_from_shapes(shapes.q2l_param_shapes(cfg["backbone"], cfg["img"], cfg["hidden"], "all"), seed=cfg["seed"])
+    img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["img"], cfg["img"], seed=cfg["seed"]))
+    tf = [synth.synthetic_features(cfg["B"], 512, seed=cfg["seed"] + k)[0] for k in (1, 2, 3)]
+    with torch.no_grad():
+        (kd_i, yi), (kd_v, yv), (kd_t, yt), (feat, yivt) = o_q.q2l_forward(sd, img, cfg["backbone"], cfg["img"], cfg["hidden"], "all", teacher=tf)
+    for got, key in ((yi, "logit_i"), (yv, "logit_v"), (yt, "logit_t"), (yivt, "logit_ivt"), (feat, "feat"), (kd_i, "kd_i"), (kd_v, "kd_v"),
+                     (kd_t, "kd_t")):
+        _close(got, z[key], tol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["mstct_tiny", "mstct_full_ivt_ragged"])
+def test_mstct_oracle_matches_reference_outputs(name):
+    from oracle import mstct as o_m
+    z, cfg = load_golden(name)
+    sd = synth.fill_from_shapes(shapes.mstct_shapes(cfg["D"], cfg["inter"], 2, 8, cfg["final"], cfg["loss_type"]), seed=cfg["seed"])
+    x = torch.cat([synth.synthetic_features(cfg["T"], cfg["D"], seed=cfg["seed"] + b) for b in range(cfg["B"])], 0)
+    with torch.no_grad():
+        out = o_m.mstct_forward(sd, x.permute(0, 2, 1), cfg["loss_type"])
+    gi = {"i": 0, "v": 1, "t": 2, "ivt": 3}[cfg["loss_type"]]
+    _close(out[gi][0], z["logits"], tol=1e-4)
+    flat = out[3][1].contiguous().flatten()
+    _close(flat[:: max(1, flat.numel() // 8192)], z["concat_sample"], tol=1e-4)
+
+
+def test_tenco_train_oracle_matches_reference_step():
+    """one Temporal_tenco step (`run.py:128-213`): the oracle's loss, gradients and SGD update vs the reference-captured fixture"""
+    from oracle import tenco_train as o_tt
+    z, cfg = load_golden("tenco_train_small")
+    table = shapes.tenco_shapes(cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["num_f_maps"], cfg["dim"], 100, fpn=True)
+    sd = synth.fill_from_shapes(table, seed=cfg["seed"])
+    x = synth.synthetic_features(cfg["T"], cfg["dim"], seed=cfg["seed"])
+    heads = (("", 100), ("_i", 6), ("_v", 10), ("_t", 15))
+    labels = {s: torch.from_numpy((synth.uniform01(cfg["seed"], 900 + i, cfg["T"] * k) < 0.1).reshape(cfg["T"], k).astype(np.int64))
+              for i, (s, k) in enumerate(heads)}
+    new, loss, terms, g = o_tt.train_step(sd, x, labels, cfg["lr"], 1e-5, num_layers_PG=cfg["num_layers_PG"], num_layers_R=cfg["num_layers_R"],
+                                          num_R=cfg["num_R"])
+    assert abs(loss - float(z["loss"])) < 1e-5 * max(1.0, abs(float(z["loss"])))
+    unused = set(str(z["unused"]).split(";"))          # parameters the reference's autograd leaves without gradient
+    for k, ref in zip([k for k, _ in table], z["grad_norms"]):
+        if k in unused:
+            assert g.get(k) is None or float(g[k].abs().max()) == 0.0
+        else:
+            assert abs(float(g[k].norm()) - ref) <= 1e-4 * max(ref, 1e-3), k
+    for key in z.files:
+        if key.startswith("delta::"):
+            k = key[len("delta::"):]
+            flat = (new[k] - sd[k]).flatten()
+            _close(flat[:: max(1, flat.numel() // 2048)], z[key], tol=1e-4)
+
+
+def test_spatial_cnn_train_oracle_matches_reference_step():
+    """one Spatial_cnn step (`run.py:145-224`, train-mode BatchNorm + KD branch + hard/soft/KD losses + SGD) vs the fixture captured from
+    the reference VideoNas + torch autograd + torch.optim.SGD"""
+    from oracle import spatial_cnn_train as o_ct
+    z, cfg = load_golden("cnn_train_resnet18")
+    table = shapes.spatial_cnn_shapes(cfg["network"])
+    sd = o_ct.damp_residual_gamma(synth.fill_from_shapes(table, seed=cfg["seed"]), cfg["network"], cfg.get("damp", 1.0))
+    img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["H"], cfg["W"], seed=cfg["seed"]))
+    labels = [torch.from_numpy((synth.uniform01(cfg["seed"], 700 + i, cfg["B"] * k) < 0.15).reshape(cfg["B"], k).astype(np.int64))
+              for i, k in enumerate((6, 10, 15, 100))]
+    tpred = [synth.synthetic_features(cfg["B"], k, seed=cfg["seed"] + 10 + i)[0] * 2.0 for i, k in enumerate((6, 10, 15))]
+    tfeat = [synth.synthetic_features(cfg["B"], 1536, seed=cfg["seed"] + 20 + i)[0] for i in range(3)]
+    new, terms, g = o_ct.train_step(sd, img, labels, tpred, tfeat, cfg["network"], cfg["lr"], 1e-5, cfg["rates"], 4.0)
+    for key in ("loss", "hard", "soft", "kd"):
+        assert abs(terms[key] - float(z[key])) < 2e-5 * max(1.0, abs(float(z[key]))), key
+    for k, ref in zip([k for k, _ in table], z["grad_norms"]):
+        if ref >= 0:
+            assert abs(float(g[k].norm()) - ref) <= 1e-4 * max(ref, 1e-5), (k, float(g[k].norm()), ref)
+        else:
+            assert k not in g or g[k] is None
+    for key in z.files:
+        if key.startswith("delta::"):
+            k = key[len("delta::"):]
+            flat = (new[k].float() - sd[k].float()).flatten()
+            _close(flat[:: max(1, flat.numel() // 2048)], z[key], tol=2e-4)
