@@ -9,23 +9,41 @@
 // The per-channel reductions of BatchNorm (these and the two of the backward) accumulate in float64: the kernels are
 // HBM-bound, CDNA4 runs fp64 VALU at half the fp32 rate, and E[x^2]-E[x]^2 as well as the backward's projections cancel
 // badly in fp32 -- torch's CPU BatchNorm (the reference's arithmetic) accumulates in double too.
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, long long M, int C) {
-    __shared__ double red[2][4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
-    double s = 0.0, q = 0.0;
-    if (c < C)
-        for (long long m = (long long)blockIdx.y * 4 + w; m < M; m += (long long)gridDim.y * 4) {
-            const double v = (double)x[m * C + c];
-            s += v;
-            q += v * v;
-        }
-    red[0][w][threadIdx.x & 63] = s;
-    red[1][w][threadIdx.x & 63] = q;
+// Work split of the three reductions: a thread owns 4 consecutive channels (one 16-byte load per row), a workgroup 64 channels x 16
+// rows per iteration; gridDim.y row slabs per channel block.
+__device__ __forceinline__ void bn_block_reduce(double (&acc)[8], double* __restrict__ sums, int C, int c0) {
+    __shared__ double red[16][8][17];               // [row lane][value][channel group], padded
+    const int cg = threadIdx.x & 15, r = threadIdx.x >> 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[r][j][cg] = acc[j];
     __syncthreads();
-    if (w == 0 && c < C) {
-        atomicAdd(sums + c, red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
-        atomicAdd(sums + C + c, red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+    if (threadIdx.x < 128) {                        // 16 channel groups x 8 values
+        const int g = threadIdx.x & 15, j = threadIdx.x >> 4;
+        double t = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) t += red[rr][j][g];
+        const int c = c0 + g * 4 + (j & 3);
+        if (c < C) atomicAdd(sums + (j >> 2) * C + c, t);
     }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, long long M, int C) {
+    const int c0 = blockIdx.x * 64, c = c0 + (threadIdx.x & 15) * 4;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < C)
+        for (long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4); m < M; m += (long long)gridDim.y * 16) {
+            const float4 v = *(const float4*)(x + m * C + c);
+            acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
+            acc[4] += (double)v.x * v.x; acc[5] += (double)v.y * v.y; acc[6] += (double)v.z * v.z; acc[7] += (double)v.w * v.w;
+        }
+    bn_block_reduce(acc, sums, C, c0);
+}
+
+static inline int bn_row_slabs(long long M, int C) {
+    long long gy = (M + 63) / 64;
+    const long long cap = (2048 + cdiv(C, 64) - 1) / cdiv(C, 64);
+    if (gy > cap) gy = cap;
+    return gy < 1 ? 1 : (int)gy;
 }
 
 // pass 2: batch mean / biased variance -> (mean, invstd); running stats with momentum and the UNBIASED variance (torch)
@@ -48,10 +66,9 @@ extern "C" int mt4_bn_stats_f32(const float* x, double* sums_zeroed, float* mean
                                 int64_t M, int32_t C, float momentum, float eps, void* stream) {
     mt4_clear_error();
     if (!x || !sums_zeroed || !mean || !invstd || M <= 0 || C <= 0) return MT4_EINVAL;
-    int gy = (int)((M + 255) / 256);
-    if (gy > 256) gy = 256;
+    if (C % 4) return MT4_EALIGN;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(C, 64), gy), dim3(256), 0, s, x, sums_zeroed, (long long)M, C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(C, 64), bn_row_slabs(M, C)), dim3(256), 0, s, x, sums_zeroed, (long long)M, C);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, sums_zeroed, mean, invstd, running_mean, running_var,
                        (long long)M, C, momentum, eps);
     return mt4_check_launch();
@@ -88,25 +105,26 @@ extern "C" int mt4_bn_apply_f32(const float* x, const float* mean, const float* 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                             const float* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, double* __restrict__ sums, long long M, int C, int relu) {
-    __shared__ double red[2][4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
-    double s = 0.0, q = 0.0;
+    const int c0 = blockIdx.x * 64, c = c0 + (threadIdx.x & 15) * 4;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (c < C) {
-        const float mu = mean[c], is = invstd[c];
-        for (long long m = (long long)blockIdx.y * 4 + w; m < M; m += (long long)gridDim.y * 4) {
-            float g = dy[m * C + c];
-            if (relu && !(y[m * C + c] > 0.f)) g = 0.f;
-            s += (double)g;
-            q += (double)g * (double)((x[m * C + c] - mu) * is);
+        const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
+        for (long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4); m < M; m += (long long)gridDim.y * 16) {
+            float4 g = *(const float4*)(dy + m * C + c);
+            const float4 xv = *(const float4*)(x + m * C + c);
+            if (relu) {
+                const float4 yv = *(const float4*)(y + m * C + c);
+                if (!(yv.x > 0.f)) g.x = 0.f;
+                if (!(yv.y > 0.f)) g.y = 0.f;
+                if (!(yv.z > 0.f)) g.z = 0.f;
+                if (!(yv.w > 0.f)) g.w = 0.f;
+            }
+            acc[0] += (double)g.x; acc[1] += (double)g.y; acc[2] += (double)g.z; acc[3] += (double)g.w;
+            acc[4] += (double)g.x * (double)((xv.x - mu.x) * is.x); acc[5] += (double)g.y * (double)((xv.y - mu.y) * is.y);
+            acc[6] += (double)g.z * (double)((xv.z - mu.z) * is.z); acc[7] += (double)g.w * (double)((xv.w - mu.w) * is.w);
         }
     }
-    red[0][w][threadIdx.x & 63] = s;
-    red[1][w][threadIdx.x & 63] = q;
-    __syncthreads();
-    if (w == 0 && c < C) {
-        atomicAdd(sums + c, red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
-        atomicAdd(sums + C + c, red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
-    }
+    bn_block_reduce(acc, sums, C, c0);
 }
 
 // backward pass 2: dx = gamma * invstd * (dy' - sum(dy')/M - xhat * sum(dy' xhat)/M);  dres = dy' (gradient of the residual input);
@@ -115,18 +133,27 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const double* __restrict__ sums, float* __restrict__ dx, float* __restrict__ dres, float* __restrict__ dgamma,
                                     float* __restrict__ dbeta, long long M, int C, int relu) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long n = M * C;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 (4 channels of one row) per thread
     if (i < C) { dbeta[i] = (float)sums[i]; dgamma[i] = (float)sums[C + i]; }
-    if (i >= n) return;
-    const int c = (int)(i % C);
-    float g = dy[i];
-    if (relu && !(y[i] > 0.f)) g = 0.f;
-    const float is = invstd[c];
-    const float xh = (x[i] - mean[c]) * is;
+    if (i >= M * C / 4) return;
+    const int c = (int)((i * 4) % C);
+    float4 g = *(const float4*)(dy + i * 4);
+    if (relu) {
+        const float4 yv = *(const float4*)(y + i * 4);
+        if (!(yv.x > 0.f)) g.x = 0.f;
+        if (!(yv.y > 0.f)) g.y = 0.f;
+        if (!(yv.z > 0.f)) g.z = 0.f;
+        if (!(yv.w > 0.f)) g.w = 0.f;
+    }
+    const float4 xv = *(const float4*)(x + i * 4), mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c), ga = *(const float4*)(gamma + c);
     const double invM = 1.0 / (double)M;
-    dx[i] = gamma[c] * is * (g - (float)(sums[c] * invM) - xh * (float)(sums[C + c] * invM));
-    if (dres) dres[i] = g;
+    float4 o;
+    o.x = ga.x * is.x * (g.x - (float)(sums[c] * invM) - (xv.x - mu.x) * is.x * (float)(sums[C + c] * invM));
+    o.y = ga.y * is.y * (g.y - (float)(sums[c + 1] * invM) - (xv.y - mu.y) * is.y * (float)(sums[C + c + 1] * invM));
+    o.z = ga.z * is.z * (g.z - (float)(sums[c + 2] * invM) - (xv.z - mu.z) * is.z * (float)(sums[C + c + 2] * invM));
+    o.w = ga.w * is.w * (g.w - (float)(sums[c + 3] * invM) - (xv.w - mu.w) * is.w * (float)(sums[C + c + 3] * invM));
+    *(float4*)(dx + i * 4) = o;
+    if (dres) *(float4*)(dres + i * 4) = g;
 }
 
 extern "C" int mt4_bn_backward_f32(const float* dy, const float* y_post, const float* x, const float* mean, const float* invstd,
@@ -135,11 +162,12 @@ extern "C" int mt4_bn_backward_f32(const float* dy, const float* y_post, const f
     mt4_clear_error();
     if (!dy || !x || !mean || !invstd || !gamma || !sums_zeroed || !dx || !dgamma || !dbeta || M <= 0 || C <= 0) return MT4_EINVAL;
     if (relu && !y_post) return MT4_EINVAL;
-    int gy = (int)((M + 255) / 256);
-    if (gy > 256) gy = 256;
+    if (C % 4) return MT4_EALIGN;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), gy), dim3(256), 0, s, dy, y_post, x, mean, invstd, sums_zeroed, (long long)M, C, relu);
-    const long long n = M * C;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), bn_row_slabs(M, C)), dim3(256), 0, s, dy, y_post, x, mean, invstd, sums_zeroed,
+                       (long long)M, C, relu);
+    long long n = M * C / 4;
+    if (n < C) n = C;                               // the first C threads also publish dgamma / dbeta
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, y_post, x, mean, invstd, gamma, sums_zeroed, dx,
                        dres, dgamma, dbeta, (long long)M, C, relu);
     return mt4_check_launch();

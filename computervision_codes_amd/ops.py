@@ -354,10 +354,13 @@ def transpose_pack_conv1d(w_packed: torch.Tensor, cout: int, cin: int, taps: int
 
 
 # ----------------------------------------------------------------------------------------- spatial training pieces (fp32)
-def bn_stats(x2d, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+def bn_stats(x2d, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, sums=None):
+    """`sums`: optional zeroed float64 scratch of 2*C (callers with many BatchNorms zero one arena per step)"""
     _need_cuda(x2d)
     m, c = x2d.shape
-    sums = torch.zeros(2 * c, dtype=torch.float64, device=x2d.device)   # scratch: float64 accumulators
+    if sums is None:
+        sums = torch.zeros(2 * c, dtype=torch.float64, device=x2d.device)   # scratch: float64 accumulators
+    assert sums.dtype == torch.float64 and sums.numel() == 2 * c
     mean, invstd = torch.empty(c, device=x2d.device), torch.empty(c, device=x2d.device)
     check(lib.mt4_bn_stats_f32(x2d.data_ptr(), sums.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                running_mean.data_ptr() if running_mean is not None else None,
@@ -374,9 +377,11 @@ def bn_apply(x2d, mean, invstd, gamma, beta, residual=None, relu=True):
     return y
 
 
-def bn_backward(dy, y_post, x2d, mean, invstd, gamma, dgamma, dbeta, relu=True, want_dres=False):
+def bn_backward(dy, y_post, x2d, mean, invstd, gamma, dgamma, dbeta, relu=True, want_dres=False, sums=None):
     m, c = x2d.shape
-    sums = torch.zeros(2 * c, dtype=torch.float64, device=x2d.device)   # scratch: float64 accumulators
+    if sums is None:
+        sums = torch.zeros(2 * c, dtype=torch.float64, device=x2d.device)   # scratch: float64 accumulators
+    assert sums.dtype == torch.float64 and sums.numel() == 2 * c
     dx = torch.empty_like(x2d)
     dres = torch.empty_like(x2d) if want_dres else None
     check(lib.mt4_bn_backward_f32(dy.data_ptr(), y_post.data_ptr() if y_post is not None else None, x2d.data_ptr(), mean.data_ptr(),
@@ -385,13 +390,14 @@ def bn_backward(dy, y_post, x2d, mean, invstd, gamma, dgamma, dbeta, relu=True, 
     return dx, dres
 
 
-def wgrad_conv2d(dy, x, dw_packed, kh, kw, stride, pad, dil=(1, 1)):
-    """dy [B,Ho,Wo,Cout], x [B,H,W,Cin]; dw_packed is zeroed here and filled"""
+def wgrad_conv2d(dy, x, dw_packed, kh, kw, stride, pad, dil=(1, 1), zero=True):
+    """dy [B,Ho,Wo,Cout], x [B,H,W,Cin]; dw_packed is zeroed here (zero=False: the caller already did) and filled"""
     _need_cuda(dy, x, dw_packed)
     b, ho, wo, cout = dy.shape
     _, h, w, cin = x.shape
     assert dw_packed.shape == (cout, packed_k(cin, kh, kw, torch.float32)) and dy.is_contiguous() and x.is_contiguous()
-    dw_packed.zero_()
+    if zero:
+        dw_packed.zero_()
     check(lib.mt4_wgrad_conv2d_f32(dy.data_ptr(), x.data_ptr(), dw_packed.data_ptr(), b, h, w, cin, ho, wo, cout, kh, kw, stride[0], stride[1],
                                    pad[0], pad[1], dil[0], dil[1], _stream()), "mt4_wgrad_conv2d_f32")
 

@@ -33,7 +33,8 @@ F32 = torch.float32
 
 class _Unit:
     """conv + BatchNorm (+ReLU) with its parameter / gradient views"""
-    __slots__ = ("name", "bn", "cin", "cout", "k", "stride", "pad", "w", "gw", "gamma", "beta", "ggamma", "gbeta", "rmean", "rvar", "wt", "phase_w")
+    __slots__ = ("name", "bn", "cin", "cout", "k", "stride", "pad", "w", "gw", "gamma", "beta", "ggamma", "gbeta", "rmean", "rvar", "wt", "phase_w",
+                 "sums_f", "sums_b")
 
 
 class SpatialCnnTrainer:
@@ -120,6 +121,15 @@ class SpatialCnnTrainer:
             b.copy_(bsrc.to(dev))
             self.lin[name] = (w, b, gw, gb, co, ci)
         assert off == total
+        # float64 scratch of every BatchNorm reduction of a step (forward 2C + backward 2C), zeroed once per step
+        self._arena = torch.zeros(sum(4 * u.cout for u in self.units.values()), dtype=torch.float64, device=dev)
+        o = 0
+        for u in self.units.values():
+            u.sums_f, u.sums_b = self._arena[o:o + 2 * u.cout], self._arena[o + 2 * u.cout:o + 4 * u.cout]
+            o += 4 * u.cout
+        self._row_maps: Dict[tuple, torch.Tensor] = {}
+        self._col_scales: Dict[int, torch.Tensor] = {}
+        self._graphs: Dict[tuple, object] = {}
         self._extra = {k: sd[k].detach().clone() for k, _ in self._table if k not in trained}   # the trunk's unused 1000-way fc
         self.pos_weight = torch.tensor(TOOL_W + VERB_W + TARGET_W + [1.0] * 100, dtype=F32, device=dev)
         self._refresh_transposed()
@@ -136,12 +146,18 @@ class SpatialCnnTrainer:
             else:   # 3x3 stride 2 pad 1: sub-pixel phases (device index/permute copies of 1-4 taps each)
                 w9 = u.w[:, :9 * u.cin].view(u.cout, 3, 3, u.cin)
                 sel = {0: [1], 1: [2, 0]}   # phase parity -> original taps, in the order of the data-gradient offsets 0, +1
-                u.phase_w = {}
+                first = u.phase_w is None
+                if first:
+                    u.phase_w = {}
                 for ph in (0, 1):
                     for pw in (0, 1):
                         sub = w9[:, sel[ph]][:, :, sel[pw]]                               # [Cout, kh', kw', Cin]
                         sub = sub.permute(3, 1, 2, 0).contiguous()                        # [Cin, kh', kw', Cout]
-                        u.phase_w[(ph, pw)] = (ops.pack_conv_weight(sub.permute(0, 3, 1, 2).contiguous(), None, F32), len(sel[ph]), len(sel[pw]))
+                        packed = ops.pack_conv_weight(sub.permute(0, 3, 1, 2).contiguous(), None, F32)
+                        if first:
+                            u.phase_w[(ph, pw)] = (packed, len(sel[ph]), len(sel[pw]))
+                        else:                                                             # in place: captured graphs keep the address
+                            u.phase_w[(ph, pw)][0].copy_(packed)
         for name, (w, b, gw, gb, co, ci) in self.lin.items():
             pass   # linear data gradients use transpose_pack on the fly (small)
 
@@ -191,8 +207,7 @@ class SpatialCnnTrainer:
         z = ops.conv_nhwc(x, u.w, None, kh=u.k, kw=u.k, stride=(u.stride, u.stride), pad=(u.pad, u.pad))
         b, ho, wo, c = z.shape
         z2 = z.view(-1, c)
-        mean, invstd = ops.bn_stats(z2, u.rmean, u.rvar)
-        self.nbt[u.bn] += 1
+        mean, invstd = ops.bn_stats(z2, u.rmean, u.rvar, sums=u.sums_f)
         a = ops.bn_apply(z2, mean, invstd, u.gamma, u.beta, residual.view(-1, c) if residual is not None else None, relu).view(b, ho, wo, c)
         saved.append((u, x, z, mean, invstd, a, relu))
         return a
@@ -207,23 +222,30 @@ class SpatialCnnTrainer:
         ho, wo = dz.shape[1], dz.shape[2]
         dx = torch.zeros((b, h, w, cin), dtype=F32, device=dz.device) if (u.k == 1 and residual is None) else \
             (residual.clone() if u.k == 1 else torch.empty((b, h, w, cin), dtype=F32, device=dz.device))
-        aa, bb = torch.meshgrid(torch.arange(ho), torch.arange(wo), indexing="ij")
         if u.k == 1:   # dX[2a][2b] = W^T dY[a][b]; every other position keeps the residual (or zero)
-            rm = ((2 * aa) * w + 2 * bb).reshape(-1).to(torch.int32).to(dz.device)
+            rm = self._row_map(ho, wo, w, 0, 0)
             ops.conv_nhwc(dz, u.wt, None, kh=1, kw=1, residual=dx if residual is not None else None, out=dx, out_row_map=rm, out_rows_per_image=h * w)
             return dx
         for (ph, pw), (wsub, khs, kws) in u.phase_w.items():
-            rm = ((2 * aa + ph) * w + 2 * bb + pw).reshape(-1).to(torch.int32).to(dz.device)
+            rm = self._row_map(ho, wo, w, ph, pw)
             ops.conv_nhwc(dz, wsub, None, kh=khs, kw=kws, out_hw=(ho, wo), residual=residual, out=dx, out_row_map=rm, out_rows_per_image=h * w)
         return dx
+
+    def _row_map(self, ho, wo, w, ph, pw) -> torch.Tensor:
+        """output rows (2a+ph, 2b+pw) of a [*, 2*ho, w] image for the ho x wo results of one sub-pixel phase (cached on the device)"""
+        key = (ho, wo, w, ph, pw)
+        if key not in self._row_maps:
+            aa, bb = torch.meshgrid(torch.arange(ho), torch.arange(wo), indexing="ij")
+            self._row_maps[key] = ((2 * aa + ph) * w + 2 * bb + pw).reshape(-1).to(torch.int32).to(self.dev)
+        return self._row_maps[key]
 
     def _bwd_unit(self, rec, dy, residual_for_dx=None, want_dres=False, need_dx=True):
         u, x, z, mean, invstd, a, relu = rec
         c = z.shape[-1]
         dz, dres = ops.bn_backward(dy.reshape(-1, c), a.view(-1, c) if relu else None, z.view(-1, c), mean, invstd, u.gamma, u.ggamma, u.gbeta,
-                                   relu=relu, want_dres=want_dres)
+                                   relu=relu, want_dres=want_dres, sums=u.sums_b)
         dz = dz.view(z.shape)
-        ops.wgrad_conv2d(dz, x, u.gw, u.k, u.k, (u.stride, u.stride), (u.pad, u.pad))
+        ops.wgrad_conv2d(dz, x, u.gw, u.k, u.k, (u.stride, u.stride), (u.pad, u.pad), zero=False)     # G is zeroed once per step
         dx = self._dgrad(u, dz, x.shape, residual_for_dx) if need_dx else None
         return dx, (dres.view(z.shape) if dres is not None else None)
 
@@ -241,9 +263,48 @@ class SpatialCnnTrainer:
         return ops.linear(dy, wt, None)
 
     # ------------------------------------------------------------------ one step
-    def train_step(self, frames, labels, teacher_pred, teacher_feat, apply_update: bool = True):
-        """frames: normalised float32 NCHW [B,3,H,W] or uint8 NHWC on the GPU; labels (y_i, y_v, y_t, y_ivt) multi-hot [B,K];
-        teacher_pred 3 x raw logits [B,K]; teacher_feat 3 x [B,1536].  Returns dict of loss terms."""
+    def train_step(self, frames, labels, teacher_pred, teacher_feat, apply_update: bool = True, use_graph: bool = False):
+        """frames: normalised float32 NCHW [B,3,H,W] or uint8 NHWC [B,H,W,3] on the GPU; labels (y_i, y_v, y_t, y_ivt) multi-hot [B,K]
+        (or one prepared fp32 [B,131] device tensor); teacher_pred 3 x raw logits [B,K]; teacher_feat 3 x [B,1536].
+        Returns the dict of loss terms.  use_graph: replay a hipGraph of the whole forward+backward captured for this input shape
+        (~900 launches become one; running statistics and gradients are updated by the replay exactly as by the eager step)."""
+        dev = self.dev
+        z = labels if torch.is_tensor(labels) else torch.cat([l.to(dev, F32) for l in labels], 1).contiguous()
+        tp = [t.to(dev, F32).contiguous() for t in teacher_pred]
+        tf = [t.to(dev, F32).contiguous() for t in teacher_feat]
+        B = frames.shape[0]
+        assert frames.is_cuda and tuple(z.shape) == (B, NH)
+        if use_graph:
+            key = (tuple(frames.shape), frames.dtype)
+            g = self._graphs.get(key)
+            if g is None:
+                from .graph import GraphedForward
+                keep = {n: (u.rmean.clone(), u.rvar.clone()) for n, u in self.units.items()}   # warm-up + capture runs must not count
+                g = self._graphs[key] = GraphedForward(lambda f, zz, *t: self._fwd_bwd(f, zz, t[:3], t[3:]), [frames, z, *tp, *tf])
+                for n, u in self.units.items():
+                    u.rmean.copy_(keep[n][0])
+                    u.rvar.copy_(keep[n][1])
+            col_loss, soft, kdl = g(frames, z, *tp, *tf)
+        else:
+            col_loss, soft, kdl = self._fwd_bwd(frames, z, tp, tf)
+        for bn in self.nbt:
+            self.nbt[bn] += 1
+        r0, r1, r2 = self.rates
+        cl, sk = col_loss.cpu(), torch.cat([soft, kdl]).cpu()
+        terms, o = {}, 0
+        hard = 0.0
+        for t, k in _HEADS:
+            terms["hard_" + t] = float(cl[o:o + k].sum() / (B * k))
+            hard += terms["hard_" + t]
+            o += k
+        terms.update(hard=hard, soft=float(sk[0]) / 3.0, kd=float(sk[1]) / 3.0)
+        terms["loss"] = r0 * terms["hard"] + r1 * terms["soft"] + r2 * terms["kd"]
+        if apply_update:
+            self.apply_update()
+        return terms
+
+    def _fwd_bwd(self, frames, z, tp, tf):
+        """device part of a step (enqueue only): forward, losses, backward into self.G.  Returns (per-column BCE sums, soft, kd)."""
         from .synth import IMAGENET_MEAN, IMAGENET_STD
         dev, C = self.dev, self.C
         if frames.dtype == torch.uint8:
@@ -252,6 +313,8 @@ class SpatialCnnTrainer:
         else:
             B, H, W = frames.shape[0], frames.shape[2], frames.shape[3]
             xp = ops.pad_nchw(frames, F32)
+        self._arena.zero_()
+        self.G.zero_()
         saved: List[tuple] = []
         self.last_saved = saved          # (unit, input, conv output, mean, invstd, post-activation, relu) per conv+BN, forward order
         pre = "basemodel.basemodel."
@@ -277,21 +340,19 @@ class SpatialCnnTrainer:
         feat = ops.global_avgpool(x)                                               # [B, C]
         # ---- heads, KD branch
         logits = self._linear_fwd("heads", feat)                                   # [B, 132]
-        tf = [t.to(dev, F32).contiguous() for t in teacher_feat]
         teas = [self._linear_fwd(m, t) for m, t in zip(("mi", "mv", "mt"), tf)]
         mixed = ops.kd_mix(feat, *teas)
         cams = [self._linear_fwd(wn, mx) for wn, mx in zip(("wi", "wv", "wt"), mixed)]
         # ---- losses and their gradients
         r0, r1, r2 = self.rates
-        z = torch.cat([l.to(dev, F32) for l in labels], 1).contiguous()
-        col_scale = torch.cat([torch.full((k,), r0 / (B * k)) for _, k in _HEADS]).to(dev)
+        col_scale = self._col_scale(B)
         col_loss = torch.zeros(NH, device=dev)
         dlog = torch.zeros((B, NHP), device=dev)
         ops.bce_logits_pw(logits[:, :NH], z, self.pos_weight, col_scale, dlog, col_loss)
         soft = torch.zeros(1, device=dev)
         o = 0
-        for (t, k), tp in zip(_HEADS[:3], teacher_pred):
-            ops.distill_kl(logits[:, o:o + k], tp.to(dev, F32).contiguous(), dlog[:, o:o + k], soft, self.temp, r1 / 3.0, accumulate=True)
+        for (t, k), tpn in zip(_HEADS[:3], tp):
+            ops.distill_kl(logits[:, o:o + k], tpn, dlog[:, o:o + k], soft, self.temp, r1 / 3.0, accumulate=True)
             o += k
         kdl = torch.zeros(1, device=dev)
         dcams = [ops.mse(c, t, kdl, r2 / 3.0) for c, t in zip(cams, tf)]
@@ -318,19 +379,12 @@ class SpatialCnnTrainer:
                 dx, _ = self._bwd_unit(main[0], d, residual_for_dx=dres)
         da0 = ops.maxpool3x3s2_bwd(a0, dx)
         self._bwd_unit(saved[0], da0, need_dx=False)
-        # ---- scalars
-        cl = col_loss.cpu()
-        terms, o = {}, 0
-        hard = 0.0
-        for t, k in _HEADS:
-            terms["hard_" + t] = float(cl[o:o + k].sum() / (B * k))
-            hard += terms["hard_" + t]
-            o += k
-        terms.update(hard=hard, soft=float(soft.item()) / 3.0, kd=float(kdl.item()) / 3.0)
-        terms["loss"] = r0 * terms["hard"] + r1 * terms["soft"] + r2 * terms["kd"]
-        if apply_update:
-            self.apply_update()
-        return terms
+        return col_loss, soft, kdl
+
+    def _col_scale(self, B: int) -> torch.Tensor:
+        if B not in self._col_scales:
+            self._col_scales[B] = torch.cat([torch.full((k,), self.rates[0] / (B * k)) for _, k in _HEADS]).to(self.dev)
+        return self._col_scales[B]
 
     def relu_outputs(self) -> Dict[str, torch.Tensor]:
         """post-ReLU activations of the last step by BatchNorm name, NCHW on the host (tests: ReLU-gate comparison)"""

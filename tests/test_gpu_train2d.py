@@ -81,7 +81,7 @@ def test_conv2d_weight_and_data_gradients(cuda, b, h, w, cin, cout, k, s, p):
     if cin == 4:
         return
     tr = SpatialCnnTrainer.__new__(SpatialCnnTrainer)
-    tr.units, tr.lin = {"c": u}, {}
+    tr.units, tr.lin, tr._row_maps, tr.dev = {"c": u}, {}, {}, cuda
     tr._refresh_transposed()
     for residual in (None, _rand((b, h, w, cin), 14).to(cuda)):
         dx = tr._dgrad(u, dyd, xd.shape, residual)
@@ -271,3 +271,23 @@ def test_gradients_as_close_to_fp64_as_torch_fp32(cuda, cfg):
         assert np.median(e_hip) <= 2 * np.median(e_t32) + 1e-6, (np.median(e_hip), np.median(e_t32))
     else:                                      # some gate on a rounding-error tie flipped in one of the fp32 runs
         assert max(e_hip) <= 0.3 and np.median(e_hip) <= max(2 * np.median(e_t32), 2e-2), (flips_hip, flips_t32, max(e_hip), np.median(e_hip))
+
+
+def test_graph_replay_equals_eager_step(cuda):
+    """hipGraph replay of the step: same losses, gradients, running statistics and update as the eager launches (atomics order aside)"""
+    cfg = dict(network="resnet18", B=4, H=64, W=64, seed=77, lr=0.05, rates=(1.0, 1.0, 1.0))
+    img, labels, tpred, tfeat = _inputs(cfg)
+    fr = synth.synthetic_frames(cfg["B"], cfg["H"], cfg["W"], seed=cfg["seed"]).to(cuda)          # uint8 entry
+    outs = []
+    for use_graph in (False, True):
+        tr, sd, table = _trainer(cfg)
+        for _ in range(2):                                   # two steps: the replay must also see the updated weights
+            terms = tr.train_step(fr, labels, tpred, tfeat, use_graph=use_graph)
+        outs.append((terms, tr.state_dict()))
+    (t0, s0), (t1, s1) = outs
+    assert abs(t0["loss"] - t1["loss"]) < 1e-4 * abs(t0["loss"])
+    for k in s0:
+        if "num_batches_tracked" in k:
+            assert int(s0[k]) == int(s1[k]) == int(sd[k]) + 2
+        else:
+            assert (s0[k].float() - s1[k].float()).abs().max().item() <= 1e-4 * max(1.0, s0[k].float().abs().max().item()), k
