@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
@@ -227,6 +228,27 @@ def swin_bench(dev, batch=32):
     return out
 
 
+def spatial_train_bench(dev):
+    """BASELINE configs[4] on one GPU: the student distillation step (`Spatial_cnn/run.py -t`, fp32, batch 8 of 256x448 frames as in
+    Scripts/train_fold1.sh) -- forward, hard+soft+KD losses, backward, SGD; hipGraph replay of forward+backward."""
+    from computervision_codes_amd import shapes, synth
+    from computervision_codes_amd.spatial_cnn_train import SpatialCnnTrainer
+    out = {}
+    for net in ("resnet18", "resnet50"):
+        B, H, W = 8, 256, 448
+        tr = SpatialCnnTrainer(net, lr=0.01, device=str(dev)).load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes(net), seed=5))
+        frames = synth.synthetic_frames(B, H, W, seed=1).to(dev)
+        z = torch.cat([torch.from_numpy((synth.uniform01(5, i, B * k) < 0.15).reshape(B, k).astype(np.float32)) for i, k in
+                       enumerate((6, 10, 15, 100))], 1).to(dev)
+        tp = [synth.synthetic_features(B, k, seed=11 + i)[0].to(dev) for i, k in enumerate((6, 10, 15))]
+        tf = [synth.synthetic_features(B, 1536, seed=21 + i)[0].to(dev) for i in range(3)]
+        ms = _time_call(lambda: tr.train_step(frames, z, tp, tf, use_graph=True), iters=10)
+        out[f"{net}_b{B}_{H}x{W}"] = dict(ms_per_step=round(ms, 3), frames_per_s=round(B / ms * 1e3, 1), dtype="f32",
+                                          note="fwd + BCE/DistillKL/MSE + bwd + SGD, train-mode BatchNorm, 1 GPU")
+        del tr
+    return out
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -317,6 +339,7 @@ def main():
         if world == 1 and not a.no_temporal:
             res["temporal"] = temporal_bench(dev, do_cpu=not a.no_cpu_baseline)
             res["swin_q2l"] = swin_bench(dev)
+            res["spatial_train"] = spatial_train_bench(dev)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_spatial(a.network, a.height, a.width, 1234)
             res["gpu_over_cpu"] = round(fps / res["cpu_baseline"]["value"], 1)
