@@ -31,9 +31,10 @@ __device__ __forceinline__ v4u make_srd(const void* p, unsigned bytes) {
     return r;
 }
 
-// N LDS-DMA pieces in ONE asm statement (one M0 save/restore): piece i goes to LDS [lds_addr + i*4096 + lane*16) from
+// N LDS-DMA pieces in ONE asm statement (one M0 save/restore): piece i goes to LDS [lds_addr + i*STRIDE + lane*16) from
 // buffer offset voff[i] (per lane, range-checked: out-of-range lanes write zeros) + soff (wave-uniform, NOT range-checked).
-template <int N>
+// STRIDE = bytes one staging pass of the whole workgroup covers (waves * 8 rows * 128 B).
+template <int N, int STRIDE>
 __device__ __forceinline__ void lds_dma16_group(v4u srd, const unsigned (&voff)[N], unsigned soff, unsigned lds_addr) {
     unsigned keep;
     if constexpr (N == 1) {
@@ -41,15 +42,16 @@ __device__ __forceinline__ void lds_dma16_group(v4u srd, const unsigned (&voff)[
                      : "=&s"(keep) : "v"(voff[0]), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
     } else if constexpr (N == 2) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "s"(srd), "s"(soff), "s"(lds_addr) : "memory", "scc");
+                     "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "s"(srd), "s"(soff), "s"(lds_addr), "n"(STRIDE) : "memory", "scc");
     } else {
         static_assert(N == 4, "1, 2 or 4 pieces");
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(srd), "s"(soff), "s"(lds_addr)
+                     "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"
+                     "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
+                     "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(srd), "s"(soff), "s"(lds_addr),
+                       "n"(STRIDE)
                      : "memory", "scc");
     }
 }
@@ -88,17 +90,20 @@ struct ConvK {
 };
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool FAST, bool OUT_F32>
-__global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(const ConvK a) {
     constexpr int ES = (int)sizeof(T);
     constexpr int ROWS = BM + BN;
-    constexpr int NLD = ROWS / 32;
-    constexpr int NLD_X = BM / 32;
-    constexpr int NLD_W = BN / 32;
+    constexpr int NW = WAVES_M * WAVES_N;   // 4 waves, or 8 for the 256-row tiles (1 workgroup per CU, same 2 waves per SIMD)
+    constexpr int NTH = NW * 64;
+    constexpr int RPP = NTH / 8;            // operand rows one staging pass of the workgroup covers (8 lanes per 128-B row)
+    constexpr int NLD = ROWS / RPP;
+    constexpr int NLD_X = BM / RPP;
+    constexpr int NLD_W = BN / RPP;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 16, NT = WN / 16;
     constexpr int STAGE_BYTES = ROWS * 128;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-    static_assert(BM % 32 == 0 && BN % 32 == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
         static_assert(NLD_X <= 4, "one mask byte per staged pixel row");
 #pragma unroll
         for (int i = 0; i < NLD_X; ++i) {
-            const int m = m0 + ld_row + 32 * i;
+            const int m = m0 + ld_row + RPP * i;
             const bool ok = m < a.M;
             const int mm = ok ? m : 0;
             int hi0 = 0, wi0 = 0;
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
         unsigned woff[NLD_W];
 #pragma unroll
         for (int i = 0; i < NLD_W; ++i) {
-            const int n = n0 + ld_row + 32 * i;
+            const int n = n0 + ld_row + RPP * i;
             woff[i] = n < a.Cout ? (unsigned)(n * a.w_row_bytes + gch * 16) : OOB;
         }
         int f_kh = 0, f_kw = 0, f_cs = 0;
@@ -250,8 +255,8 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
             unsigned vx[NLD_X];
 #pragma unroll
             for (int i = 0; i < NLD_X; ++i) vx[i] = ((bits >> (8 * i)) & 1u) ? (unsigned)xoff[i] : OOB;
-            lds_dma16_group<NLD_X>(rsx, vx, (unsigned)__builtin_amdgcn_readfirstlane(delta), dst);
-            lds_dma16_group<NLD_W>(rsw, woff, (unsigned)__builtin_amdgcn_readfirstlane(step * 128), dst + NLD_X * 4096);
+            lds_dma16_group<NLD_X, RPP * 128>(rsx, vx, (unsigned)__builtin_amdgcn_readfirstlane(delta), dst);
+            lds_dma16_group<NLD_W, RPP * 128>(rsw, woff, (unsigned)__builtin_amdgcn_readfirstlane(step * 128), dst + BM * 128);
         };
         // Ring of STAGES operand stages, DMA issued STAGES-1 K-steps ahead.  After computing step s the groups of steps
         // s+1 .. s+STAGES-1 are outstanding (fewer at the tail); only the OLDEST must have landed, so the wait leaves the
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
         bool px_ok[NLD_X];
 #pragma unroll
         for (int i = 0; i < NLD_X; ++i) {
-            const int m = m0 + ld_row + 32 * i;
+            const int m = m0 + ld_row + RPP * i;
             px_ok[i] = m < a.M;
             const int mm = px_ok[i] ? m : 0;
             const int b = mm / a.HoWo;
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
         bool w_ok[NLD_W];
 #pragma unroll
         for (int i = 0; i < NLD_W; ++i) {
-            const int n = n0 + ld_row + 32 * i;
+            const int n = n0 + ld_row + RPP * i;
             w_ok[i] = n < a.Cout;
             w_ptr[i] = a.w + (long long)(w_ok[i] ? n : 0) * a.w_row_bytes + ld_chunk * 16;
         }
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
         auto store_stage = [&](int stage) {
             char* base = smem + stage * STAGE_BYTES + st_off;
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) *(uint4*)(base + i * 32 * 128) = stg[i];
+            for (int i = 0; i < NLD; ++i) *(uint4*)(base + i * RPP * 128) = stg[i];
         };
         load_step(0);
         store_stage(0);
@@ -354,14 +359,14 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvK a) {
     constexpr int OS = OUT_F32 ? 4 : 2;
     constexpr int CH = 16 / OS;        // channels per 16-byte output vector
     constexpr int ROWB = BN * 4 + 16;  // fp32 row + 16 B pad: conflict-free ds_write_b128 per 8 lanes
-    constexpr int PASSES = (BM * ROWB > 2 * STAGE_BYTES) ? 2 : 1;
+    constexpr int PASSES = (BM * ROWB > 4 * STAGE_BYTES) ? 4 : (BM * ROWB > 2 * STAGE_BYTES) ? 2 : 1;   // (BM*ROWB <= 8 stages for every tile)
     static_assert(BM / PASSES * ROWB <= 2 * STAGE_BYTES, "epilogue staging fits the main-loop LDS");
     static_assert(MT % PASSES == 0, "passes split the m-tiles of a wave");
     constexpr int MTP = MT / PASSES;  // m-tiles per wave per pass
     constexpr int WMP = WM / PASSES;  // rows per wave_m group per pass
     constexpr int BMP = BM / PASSES;
     constexpr int TPR = BN / CH;      // threads per row on read-back
-    constexpr int RPI = 256 / TPR;    // rows per read-back iteration
+    constexpr int RPI = NTH / TPR;    // rows per read-back iteration
     constexpr int ITERS = (BMP + RPI - 1) / RPI;
     constexpr int RB = (sizeof(T) == 2 && CH == 4) ? 8 : 16;  // residual bytes per output vector
     if ((a.Cout % CH) == 0) {
@@ -497,8 +502,10 @@ struct TileCfg {
 };
 // tile ids are 1-based in the C-ABI
 // ids 1-6: two operand stages; 7-12: deeper rings (3 for the 128-wide tiles, 4 for the small ones)
+// ids 13-16: 8-wave workgroups (one per CU): 256x128 with 2 / 3 stages, 256x256, 128x256 with 3 stages
 constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {64, 128}, {32, 64}, {32, 32},
-                              {128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}, {128, 64}};
+                              {128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}, {128, 64},
+                              {256, 128}, {256, 128}, {256, 256}, {128, 256}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <typename T, int BM, int BN, int WM_, int WN_, int STAGES, bool OUT_F32>
@@ -512,8 +519,9 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     constexpr int stage = (BM + BN) * 128;
     constexpr int os = OUT_F32 ? 4 : 2;
     constexpr int rowb = BN * 4 + 16;
-    constexpr int passes = (BM * rowb > 2 * stage) ? 2 : 1;
+    constexpr int passes = (BM * rowb > 4 * stage) ? 4 : (BM * rowb > 2 * stage) ? 2 : 1;
     constexpr int epi = BM / passes * rowb;
+    constexpr int threads = WM_ * WN_ * 64;
     (void)os;
     const int lds = k.nsteps > 1 ? (fast ? STAGES : 2) * stage : (stage > epi ? stage : epi);
     const int grid = kk.total_tiles;  // one tile per workgroup (see PERSIST in the kernel)
@@ -523,10 +531,14 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
             static bool raised = false;   // per instantiation: allow > 64 KiB of dynamic LDS once
             if (!raised) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
         }
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, kk);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, s, kk);
     } else {
         auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, 2, false, OUT_F32>;
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, kk);
+        if (lds > 65536) {
+            static bool raised = false;
+            if (!raised) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+        }
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, s, kk);
     }
     return mt4_check_launch();
 }
@@ -546,17 +558,28 @@ int launch_dtype(const ConvK& k, int tile, bool fast, hipStream_t s) {
         case 10: return launch_tile<T, 32, 64, 1, 4, 4, OUT_F32>(k, fast, s);
         case 11: return launch_tile<T, 32, 32, 2, 2, 4, OUT_F32>(k, fast, s);
         case 12: return launch_tile<T, 128, 64, 2, 2, 3, OUT_F32>(k, fast, s);
+        case 13: return launch_tile<T, 256, 128, 4, 2, 2, OUT_F32>(k, fast, s);
+        case 14: return launch_tile<T, 256, 128, 4, 2, 3, OUT_F32>(k, fast, s);
+        case 15: return launch_tile<T, 256, 256, 2, 4, 2, OUT_F32>(k, fast, s);
+        case 16: return launch_tile<T, 128, 256, 2, 4, 3, OUT_F32>(k, fast, s);
     }
     return MT4_EINVAL;
 }
 
-int auto_tile(int M, int N, int nsteps) {
+int auto_tile(int M, int N, int nsteps, int es) {
     // Measured on MI355X over the ResNet-50 layer set (tools/tune_conv.py, profiles/r01_tile_tuning.txt):
     // long-K layers want the 128x128 tile (most MFMA per LDS byte); short-K (memory-bound) layers want the
     // smaller 64x128 / 128x64 footprints (more workgroups per CU -> more loads and stores in flight).
     auto tiles = [&](int t) { return (long long)cdiv(M, kTiles[t - 1].bm) * cdiv(N, kTiles[t - 1].bn); };
     const long long fill = 256;  // one workgroup per CU
+    // 8-wave 256-row tiles (bf16, profiles/r01_tile_tuning_8wave.txt): one workgroup per CU with the same 2 waves per SIMD, but
+    // 0.5-0.75x the operand bytes per FLOP through L2 -> LDS-DMA, whose issue cost is what the K-loop waits on
+    if (es == 2 && N >= 256) {
+        if (nsteps == 1 && tiles(13) >= fill) return 13;
+        if (nsteps >= 2 && tiles(15) >= 190) return (nsteps <= 4 && N >= 1024) ? 4 : 15;
+    }
     if (nsteps == 1 && tiles(3) >= 4 * fill) return 3;   // single K-step: smallest footprint, most workgroups per CU
+    if (es == 2 && N > 64 && N <= 128 && nsteps >= 8 && tiles(4) >= fill) return 4;   // one channel tile: no sharing to win from 128 rows
     if (N > 64) {
         if (nsteps >= 4 && tiles(1) >= fill) return 1;
         if (tiles(4) >= fill) return 4;
@@ -650,7 +673,7 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     k.SPT = fast ? k.CPT / 8 : 1;
     int tile = d->tile;
     if (tile < 0 || tile > kNumTiles) return MT4_EINVAL;
-    if (tile == 0) tile = auto_tile(k.M, k.Cout, k.nsteps);
+    if (tile == 0) tile = auto_tile(k.M, k.Cout, k.nsteps, d->dtype == MT4_F32 ? 4 : 2);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MT4_F32) return launch_dtype<float, true>(k, tile, fast, s);
     if (d->out_dtype == MT4_F32) return launch_dtype<u16, true>(k, tile, fast, s);

@@ -61,7 +61,7 @@ def test_conv_nhwc_auto_tile(cuda, shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", list(range(1, 13)))
+@pytest.mark.parametrize("tile", list(range(1, 17)))
 def test_conv_nhwc_every_tile(cuda, tile, dtype):
     # M = 2*13*11 = 286 (ragged vs every BM), N = 96 (ragged vs 64/128), both K modes
     _conv_case(cuda, 2, 13, 11, 64, 96, 3, 3, (1, 1), (1, 1), (1, 1), dtype, relu=False, use_res=False, tile=tile, seed=5)
@@ -69,6 +69,8 @@ def test_conv_nhwc_every_tile(cuda, tile, dtype):
     # long K (18-72 K-steps): exercises the multi-stage DMA ring's steady state and its tail
     _conv_case(cuda, 1, 9, 9, 256, 64, 3, 3, (1, 1), (1, 1), (1, 1), dtype, relu=True, use_res=False, tile=tile, seed=7)
     _conv_case(cuda, 1, 1, 40, 128, 32, 1, 3, (1, 1), (0, 2), (1, 2), dtype, relu=False, use_res=True, tile=tile, seed=8)
+    if tile >= 13:   # 8-wave tiles: several 256-row tiles with ragged edges in both directions, 4-pass epilogue
+        _conv_case(cuda, 3, 17, 19, 64, 320, 3, 3, (1, 1), (1, 1), (1, 1), dtype, relu=True, use_res=True, tile=tile, seed=9)
 
 
 def test_conv_bf16_in_f32_out(cuda):
