@@ -576,10 +576,10 @@ int auto_tile(int M, int N, int nsteps, int es) {
     // 0.5-0.75x the operand bytes per FLOP through L2 -> LDS-DMA, whose issue cost is what the K-loop waits on
     if (es == 2 && N >= 256) {
         if (nsteps == 1 && tiles(13) >= fill) return 13;
-        if (nsteps >= 2 && tiles(15) >= 190) return (nsteps <= 4 && N >= 1024) ? 4 : 15;
+        if (nsteps >= 2 && tiles(15) >= 190) return 15;
     }
+    if (es == 2 && N > 64 && N <= 128 && nsteps >= 4 && nsteps <= 8 && tiles(14) >= 8 * fill) return 14;   // many rounds: small tail
     if (nsteps == 1 && tiles(3) >= 4 * fill) return 3;   // single K-step: smallest footprint, most workgroups per CU
-    if (es == 2 && N > 64 && N <= 128 && nsteps >= 8 && tiles(4) >= fill) return 4;   // one channel tile: no sharing to win from 128 rows
     if (N > 64) {
         if (nsteps >= 4 && tiles(1) >= fill) return 1;
         if (tiles(4) >= fill) return 4;
