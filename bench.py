@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=1336, help="frames per GPU per step (1336: layer3/4 tile counts land on whole rounds of 256 CUs)")
     ap.add_argument("--network", default="resnet50")
     ap.add_argument("--height", type=int, default=224)
     ap.add_argument("--width", type=int, default=224)

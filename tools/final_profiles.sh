@@ -11,4 +11,4 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/p
 echo fetch done
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-temporal > gpurun_out/pmc_write.log 2>&1
 echo write done
-python tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 54 resnet50_bf16_b1024_224x224 gpurun_out/traffic.json
+python tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 54 resnet50_bf16_b1336_224x224 gpurun_out/traffic.json
