@@ -101,34 +101,45 @@ class VideoNas:
         self._p = p
 
     # ------------------------------------------------------------------ trunk
-    def _conv(self, x, key, k, stride=1, pad=0, residual=None, relu=True):
+    def _conv(self, x, key, k, stride=1, pad=0, residual=None, relu=True, out=None):
         wp, b = self._p[key]
-        return ops.conv_nhwc(x, wp, b, kh=k, kw=k, stride=(stride, stride), pad=(pad, pad), residual=residual, relu=relu)
+        return ops.conv_nhwc(x, wp, b, kh=k, kw=k, stride=(stride, stride), pad=(pad, pad), residual=residual, relu=relu, out=out)
 
-    def trunk_from_padded(self, xp: torch.Tensor, h: int, w: int) -> torch.Tensor:
-        """xp: stem input [B,H+6,Wp,4] (ops.preprocess_u8 / ops.pad_nchw).  Returns pooled fp32 [B,C]."""
+    def _stem(self, xp: torch.Tensor, h: int, w: int) -> torch.Tensor:
         b, hp, wp_, _ = xp.shape
         wst, bst = self._p["stem"]
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         xv = xp.view(b, hp, wp_ // 2, 8)  # pixel pairs: one 7-wide kernel row = 4 pairs (one zero slot)
         y = torch.empty((b, ho, wo, wst.shape[0]), dtype=self.dtype, device=xp.device)
         ops.conv_nhwc(xv, wst, bst, kh=7, kw=4, stride=(2, 1), relu=True, out=y)
-        x = ops.maxpool3x3s2(y)
+        return ops.maxpool3x3s2(y)
+
+    def _layers(self, x: torch.Tensor, first: int, last: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """residual layers first..last (1-based, inclusive); the last conv writes into `out` when given"""
         pre = "basemodel.basemodel."
         bottleneck = self.network == "resnet50"
-        for li, n in enumerate(_DEPTHS[self.network], start=1):
+        for li in range(first, last + 1):
+            n = _DEPTHS[self.network][li - 1]
             for bi in range(n):
                 q = f"{pre}layer{li}.{bi}."
                 s = 2 if (bi == 0 and li > 1) else 1
+                o_buf = out if (li == last and bi == n - 1) else None
                 idt = self._conv(x, q + "ds", 1, stride=s, relu=False) if (q + "ds") in self._p else x
                 if bottleneck:  # resnet.py:101-121 (stride on the 3x3)
                     o = self._conv(x, q + "conv1", 1)
                     o = self._conv(o, q + "conv2", 3, stride=s, pad=1)
-                    x = self._conv(o, q + "conv3", 1, residual=idt)
+                    x = self._conv(o, q + "conv3", 1, residual=idt, out=o_buf)
                 else:           # resnet.py:35-72
                     o = self._conv(x, q + "conv1", 3, stride=s, pad=1)
-                    x = self._conv(o, q + "conv2", 3, pad=1, residual=idt)
-        return ops.global_avgpool(x)
+                    x = self._conv(o, q + "conv2", 3, pad=1, residual=idt, out=o_buf)
+        return x
+
+    def trunk_from_padded(self, xp: torch.Tensor, h: int, w: int) -> torch.Tensor:
+        """xp: stem input [B,H+6,Wp,4] (ops.preprocess_u8 / ops.pad_nchw).  Returns pooled fp32 [B,C].
+        (Running the HBM-bound head -- stem, max-pool, layer1[, layer2] -- in sub-batches of 64-167 frames so that producer ->
+        consumer -> residual stays inside the 256 MB Infinity Cache was measured 4-15 % SLOWER at 1336 frames, twice; the whole
+        batch goes through every layer.)"""
+        return ops.global_avgpool(self._layers(self._stem(xp, h, w), 1, 4))
 
     def conv_plan(self, h: int, w: int):
         """Geometry of every conv launch of one forward, in launch order (algorithmic dims: the stem is the
