@@ -131,6 +131,31 @@ def test_spatial_cnn_batch_independence(cuda):
     assert torch.equal(feat_all[4:6], feat_2) and torch.equal(l_all[4:6], l_2)
 
 
+def test_spatial_cnn_bench_configuration_properties(cuda):
+    """BASELINE configs[1] at bench.py's full size (ResNet-50, bf16, 1336 frames of 224x224 per step: the 8-wave 256x256 /
+    256x128 tiles): size-independent properties instead of an oracle run -- a frame's feature does not depend on the batch it
+    rides in (bit-exact against batches of 8, which take other tile instantiations), the step is deterministic, and the bf16
+    features of sampled frames agree with the fp32 parity path."""
+    _, cfg = load_golden("cnn_resnet50_224")
+    m16 = _cnn_model(cfg, torch.bfloat16)
+    n = 1336
+    frames = synth.synthetic_frames(16, 224, 224, seed=5).to(cuda).repeat(n // 16 + 1, 1, 1, 1)[:n].contiguous()
+    frames[100:108] = synth.synthetic_frames(8, 224, 224, seed=6).to(cuda)          # break the periodicity in two places
+    frames[n - 8:] = synth.synthetic_frames(8, 224, 224, seed=7).to(cuda)
+    (_, _), (_, _), (_, _), (feat, livt) = m16.extract_u8(frames)
+    (_, _), (_, _), (_, _), (feat_b, livt_b) = m16.extract_u8(frames)
+    assert torch.equal(feat, feat_b) and torch.equal(livt, livt_b)
+    for s0 in (0, 100, n - 8):
+        (_, _), (_, _), (_, _), (f8, l8) = m16.extract_u8(frames[s0:s0 + 8].contiguous())
+        assert torch.equal(feat[s0:s0 + 8], f8) and torch.equal(livt[s0:s0 + 8], l8), s0
+    assert torch.equal(feat[0], feat[16]) and not torch.equal(feat[100], feat[116])  # same frame -> same feature, different -> different
+    m32 = _cnn_model(cfg, torch.float32)
+    (_, _), (_, _), (_, _), (f32_, l32) = m32.extract_u8(frames[n - 8:].contiguous())
+    rng = l32.abs().max().item()
+    assert (livt[n - 8:].float() - l32).abs().max().item() < 5e-2 * rng
+    assert (feat[n - 8:].float() - f32_).abs().max().item() < 5e-2 * f32_.abs().max().item()
+
+
 # ------------------------------------------------------------------------------------------ Swin + Q2L, MS-TCT
 Q2L = ["q2l_swinT_224_i", "q2l_swinB_224_v", "q2l_swinB_384_t"]
 MSTCT = ["mstct_tiny", "mstct_full_i", "mstct_full_ivt_ragged"]
