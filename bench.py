@@ -210,7 +210,17 @@ def temporal_bench(dev, do_cpu):
     return out
 
 
-def swin_bench(dev, batch=32):
+def device_frames(n, h, w, seed, dev, nbase=16):
+    """n uint8 frames on the device: `nbase` of them from the counter generator on the host (it makes ~2 M values/s), the others
+    derived on the device as base[i % nbase] XOR a per-group byte -- still uniform random bytes, no two frames equal"""
+    from computervision_codes_amd import synth
+    nbase = min(n, nbase)
+    base = synth.synthetic_frames(nbase, h, w, seed=seed).to(dev)
+    idx = torch.arange(n, device=dev)
+    return (base[idx % nbase] ^ ((idx // nbase * 37) % 256).to(torch.uint8)[:, None, None, None]).contiguous()
+
+
+def swin_bench(dev, batch=128):
     """BASELINE configs[2]: Swin-B + Q2L head, bf16, frames/s at 384x384 (reference-legal swin_B_384_22k) and 224x224."""
     from computervision_codes_amd import shapes, synth
     from computervision_codes_amd.spatial_transformer import build_q2l
@@ -219,7 +229,7 @@ def swin_bench(dev, batch=32):
         args = types.SimpleNamespace(backbone=name, img_size=img, hidden_dim=1024, loss_type="i")
         m = build_q2l(args, dtype=torch.bfloat16, device=str(dev)).eval()
         m.load_state_dict(synth.fill_from_shapes(shapes.q2l_param_shapes(name, img, 1024, "i"), seed=7))
-        frames = synth.synthetic_frames(batch, img, img, seed=7).to(dev)
+        frames = device_frames(batch, img, img, 7, dev)
         ms = _time_call(lambda: m(frames), iters=5)
         gf = (94.2 + 15.3) if img == 384 else (30.9 + 10.2)
         out[f"{name}"] = dict(frames_per_s=round(batch / ms * 1e3, 1), ms_per_batch=round(ms, 3), batch=batch,
@@ -256,13 +266,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    backend = os.environ.get("MT4_BENCH_BACKEND", "nccl")    # "gloo": rehearsal of the N>1 path with several ranks on ONE GPU
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL
+        else:
+            dist.init_process_group(backend)
 
     from computervision_codes_amd import shapes, synth
     from computervision_codes_amd.spatial_cnn import VideoNas
@@ -272,8 +287,9 @@ def main():
                                  train=False)
     model = VideoNas(args=args, dtype=dtype, device=str(dev)).eval()
     model.load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes(a.network), seed=1234))
-    # every rank gets its own disjoint frames (seeded by rank), resident in HBM before timing starts
-    frames = synth.synthetic_frames(a.batch, a.height, a.width, seed=1234 + rank).to(dev)
+    # every rank gets its own disjoint frames (seeded by rank), resident in HBM before timing starts.  64 frames come from the
+    # counter generator on the host, the rest of the batch is derived on the device (device_frames)
+    frames = device_frames(a.batch, a.height, a.width, 1234 + rank, dev, nbase=64)
 
     def barrier():
         if dist is not None:
@@ -289,7 +305,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(out[3][1]).all()
