@@ -2,7 +2,7 @@
 # round-final measurement set on the GPU box: bench line + per-layer table, rocprofv3 kernel stats, PMC traffic passes
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
+mkdir -p gpurun_out; rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/prof_final
 timeout -k 10 500 python bench.py --per-layer gpurun_out/layers_final.json > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
 echo bench done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o final -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-temporal > gpurun_out/prof_final.log 2>&1
