@@ -51,6 +51,7 @@ SIGNATURES = {
     "mt4_pack_stem_weight": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "mt4_preprocess_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _FLOAT3, _FLOAT3, _i32, _vp]),
     "mt4_pad_nchw_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_resize_pass_u8": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mt4_maxpool3x3s2_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mt4_global_avgpool_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_linear_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

@@ -72,3 +72,26 @@ def load_frames_u8(data_dir: str, video: str, frame_ids, height: int = 256, widt
                 im = im.resize((width, height), Image.BILINEAR)
             out[i] = np.asarray(im)
     return out
+
+
+def load_frames_device(data_dir: str, video: str, frame_ids, height: int = 256, width: int = 448, device="cuda"):
+    """Same bytes as `load_frames_u8`, as a uint8 [N,H,W,3] tensor on the GPU: the PNGs are decoded on the host at their native size
+    and `Resize((height,width))` runs on the device (`ops.resize_bilinear_u8`, byte-identical to Pillow's bilinear resize).  Frames
+    of one native size go through one launch pair; a video mixing sizes falls back to one group per size."""
+    import torch
+    from PIL import Image
+
+    from . import ops
+    raw = []
+    for fid in frame_ids:
+        with Image.open(os.path.join(data_dir, "data", video, "{}.png".format(str(int(fid)).zfill(6)))) as im:
+            raw.append(np.asarray(im.convert("RGB")))
+    out = torch.empty((len(raw), height, width, 3), dtype=torch.uint8, device=device)
+    groups: Dict[tuple, List[int]] = {}
+    for i, a in enumerate(raw):
+        groups.setdefault(a.shape[:2], []).append(i)
+    for (h0, w0), idx in groups.items():
+        x = torch.from_numpy(np.stack([raw[i] for i in idx])).to(device)
+        y = x if (h0, w0) == (height, width) else ops.resize_bilinear_u8(x, height, width)
+        out[torch.tensor(idx, device=device)] = y
+    return out

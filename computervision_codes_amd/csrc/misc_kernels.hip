@@ -174,6 +174,52 @@ extern "C" int mt4_global_avgpool_nhwc(const void* x, float* y, int32_t B, int32
     return mt4_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------ PIL-exact resize pass (uint8)
+// One separable pass of Pillow's `ImagingResample` for 8-bit images (`Image.resize(size, BILINEAR)`, which
+// `transforms.Resize((256,448))` of Spatial_cnn/dataloader.py:155-159 calls on the decoded PNG): out = clip8((2^21 + sum_i
+// in[lo + i] * kk[i]) >> 22) with the integer coefficient table (22 fractional bits) and [lo, n) bounds built by the host exactly
+// as Pillow's precompute_coeffs / normalize_coeffs_8bpc do.  axis 0: along width ([B][H][Win][C] -> [B][H][Wout][C]);
+// axis 1: along height ([B][Hin][W][C] -> [B][Hout][W][C]).  The horizontal result is rounded to uint8 before the vertical pass,
+// as in Pillow, so the two passes compose to the same bytes.
+__global__ void resize_pass_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const int* __restrict__ bounds,
+                                      const int* __restrict__ kk, int ksize, int B, int Hin, int Win, int Hout, int Wout, int C,
+                                      int axis) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * Hout * Wout * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    long long p = idx / C;
+    const int x = (int)(p % Wout);
+    p /= Wout;
+    const int y = (int)(p % Hout);
+    const int b = (int)(p / Hout);
+    const int o = axis == 0 ? x : y;
+    const int lo = bounds[2 * o], n = bounds[2 * o + 1];
+    const int* k = kk + (long long)o * ksize;
+    int ss = 1 << 21;
+    if (axis == 0) {
+        const uint8_t* src = in + (((long long)b * Hin + y) * Win + lo) * C + c;
+        for (int i = 0; i < n; ++i) ss += (int)src[(long long)i * C] * k[i];
+    } else {
+        const uint8_t* src = in + (((long long)b * Hin + lo) * Win + x) * C + c;
+        for (int i = 0; i < n; ++i) ss += (int)src[(long long)i * Win * C] * k[i];
+    }
+    ss >>= 22;
+    out[idx] = (uint8_t)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+}
+
+extern "C" int mt4_resize_pass_u8(const void* in, void* out, const int32_t* bounds, const int32_t* coeffs, int32_t ksize, int32_t B,
+                                  int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int32_t C, int32_t axis, void* stream) {
+    mt4_clear_error();
+    if (!in || !out || !bounds || !coeffs || ksize <= 0 || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C <= 0)
+        return MT4_EINVAL;
+    if ((axis == 0 && Hin != Hout) || (axis == 1 && Win != Wout) || (axis != 0 && axis != 1)) return MT4_EINVAL;
+    const long long total = (long long)B * Hout * Wout * C;
+    hipLaunchKernelGGL(resize_pass_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)in,
+                       (uint8_t*)out, bounds, coeffs, ksize, B, Hin, Win, Hout, Wout, C, axis);
+    return mt4_check_launch();
+}
+
 // ------------------------------------------------------------------------------------------------ linear heads (fp32)
 // one wave per output element row-dot: block = 4 waves, each wave computes y[b][n] for one n, looping n
 __global__ void linear_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,

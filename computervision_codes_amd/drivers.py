@@ -85,7 +85,7 @@ def spatial_cnn_test(argv=None) -> Dict[str, np.ndarray]:
         chunks = []
         for s in range(0, len(lab["ivt"]), F.batch):           # file order, no shuffle, drop_last False
             ids = lab["ivt"][s:s + F.batch, 0]
-            fr = torch.from_numpy(cholect.load_frames_u8(F.data_dir, v, ids, F.image_height, F.image_width)).cuda()
+            fr = cholect.load_frames_device(F.data_dir, v, ids, F.image_height, F.image_width)   # decode on the host, Resize on the GPU
             (_, li), (_, lv), (_, lt), (feat, livt) = model.extract_u8(fr)
             chunks.append(feat.float().cpu())
             for key, lg in (("i", li), ("v", lv), ("t", lt), ("ivt", livt)):
@@ -219,7 +219,7 @@ def spatial_cnn_train(argv=None) -> Dict[str, float]:
             for v in val_videos:
                 lv = labels[v]["ivt"]
                 for s0 in range(0, len(lv), F.batch):
-                    fr = torch.from_numpy(cholect.load_frames_u8(F.data_dir, v, lv[s0:s0 + F.batch, 0], F.image_height, F.image_width)).cuda()
+                    fr = cholect.load_frames_device(F.data_dir, v, lv[s0:s0 + F.batch, 0], F.image_height, F.image_width)
                     m.update(lv[s0:s0 + F.batch, 1:], _sigmoid(model.extract_u8(fr)[3][1]))
                 m.video_end()
             score = float(m.compute_video_AP()["mAP"]) if val_videos else 0.0
@@ -354,7 +354,7 @@ def spatial_transformer_test(argv=None) -> Dict[str, np.ndarray]:
         v, chunks = videos[vi], []
         ids_all = labels[v]["ivt"][:, 0]
         for s in range(0, len(ids_all), F.batch):
-            fr = torch.from_numpy(cholect.load_frames_u8(F.data_dir, v, ids_all[s:s + F.batch], F.img_size, F.img_size)).cuda()
+            fr = cholect.load_frames_device(F.data_dir, v, ids_all[s:s + F.batch], F.img_size, F.img_size)
             chunks.append(model(fr)[3][0].float().cpu())
         feats_local[featfile.video_key(v, "transformer")] = torch.vstack(chunks).numpy()
     merged = extract.gather_feats(feats_local)

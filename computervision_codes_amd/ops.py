@@ -135,6 +135,70 @@ def pad_nchw(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return out
 
 
+def pil_resize_tables(in_size: int, out_size: int):
+    """Pillow's `precompute_coeffs` (bilinear filter, support 1, widened by the scale when shrinking = its antialiasing) and
+    `normalize_coeffs_8bpc` (22 fractional bits) in the same float64 operation order -> (bounds int32 [out,2], coeffs int32 [out,ksize])"""
+    import math
+    import numpy as np
+    scale = float(in_size) / float(out_size)
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)          # C (int): truncation toward zero
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        w = []
+        ww = 0.0
+        for x in range(xmax):
+            t = (x + xmin - center + 0.5) * ss
+            if t < 0.0:
+                t = -t
+            v = 1.0 - t if t < 1.0 else 0.0
+            w.append(v)
+            ww += v
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+_RESIZE_TABLES = {}
+
+
+def resize_bilinear_u8(frames: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+    """uint8 [B,H,W,C] on the GPU -> uint8 [B,out_h,out_w,C], byte-identical to `PIL.Image.resize((out_w,out_h), BILINEAR)` of
+    every frame (horizontal pass, uint8 rounding, vertical pass: `mt4_resize_pass_u8`)."""
+    _need_cuda(frames)
+    assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.is_contiguous()
+    b, h, w, c = frames.shape
+    x = frames
+    for axis, (n_in, n_out) in enumerate(((w, out_w), (h, out_h))):
+        if n_in == n_out:
+            continue
+        key = (n_in, n_out, frames.device)
+        if key not in _RESIZE_TABLES:
+            bd, kk = pil_resize_tables(n_in, n_out)
+            _RESIZE_TABLES[key] = (torch.from_numpy(bd).to(frames.device), torch.from_numpy(kk).to(frames.device))
+        bd, kk = _RESIZE_TABLES[key]
+        hin, win = x.shape[1], x.shape[2]
+        hout, wout = (hin, n_out) if axis == 0 else (n_out, win)
+        y = torch.empty((b, hout, wout, c), dtype=torch.uint8, device=frames.device)
+        check(lib.mt4_resize_pass_u8(x.data_ptr(), y.data_ptr(), bd.data_ptr(), kk.data_ptr(), kk.shape[1], b, hin, win, hout, wout, c, axis,
+                                     _stream()), "mt4_resize_pass_u8")
+        x = y
+    return x
+
+
 def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
     _need_cuda(x)
     assert x.is_contiguous()

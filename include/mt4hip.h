@@ -104,6 +104,13 @@ int mt4_preprocess_u8(const uint8_t* frames, void* out, int32_t B, int32_t H, in
 /* same from already-normalised float32 NCHW [B][3][H][W] (the reference's module-call boundary) */
 int mt4_pad_nchw_f32(const float* x, void* out, int32_t B, int32_t H, int32_t W, int32_t dtype, void* stream);
 
+/* One separable pass of Pillow's 8-bit resize (`Image.resize(size, BILINEAR)` = `transforms.Resize((256,448))`,
+ * Spatial_cnn/dataloader.py:155-159, Spatial_transformer likewise): out = clip8((2^21 + sum_i in[lo+i] * coeffs[o][i]) >> 22).
+ * bounds [n_out][2] = (lo, count), coeffs [n_out][ksize] int32 with 22 fractional bits, both built by the host as Pillow's
+ * precompute_coeffs / normalize_coeffs_8bpc do (ops.pil_resize_tables).  axis 0: width ([B][H][Win][C] -> [B][H][Wout][C]),
+ * axis 1: height.  Bit-exact with Pillow when the horizontal pass runs first. */
+int mt4_resize_pass_u8(const void* in, void* out, const int32_t* bounds, const int32_t* coeffs, int32_t ksize, int32_t B, int32_t Hin,
+                       int32_t Win, int32_t Hout, int32_t Wout, int32_t C, int32_t axis, void* stream);
 /* MaxPool2d(3, stride 2, pad 1) channels-last (resnet.py:149). C*esize % 16 == 0. */
 int mt4_maxpool3x3s2_nhwc(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
                           void* stream);
