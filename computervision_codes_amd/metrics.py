@@ -1,14 +1,46 @@
 """Video-wise average precision, restating what the drivers use from the un-vendored `ivtmetrics 0.0.6`
 (`Spatial_cnn/run.py:331-338,426-451`): per video, per class AP (sklearn `average_precision_score`), NaN for classes
 without positives; `compute_video_AP` = nan-mean over videos per class, then nan-mean over classes.
-PARITY UNPINNED: ivtmetrics is not installed and the reference holds no fixture for it; the component
-disentangling (i/v/t from ivt via maps.txt) is not restated -- the drivers feed each head's own logits."""
+Component disentangling (`compute_video_AP('i'|'v'|'t'|'iv'|'it')` on the 100-way triplet scores, `run.py:438-444`): a component
+class takes the MAX over the triplets that contain it, for scores and labels alike, through the CholecT45/T50 triplet dictionary
+(the table of `Spatial_cnn/maps.txt`, which no reference code reads -- ivtmetrics bundles the same one).
+PARITY UNPINNED: ivtmetrics is not installed and the reference holds no fixture for it; pinned here against sklearn
+and hand-built cases only.  `ignore_null=True` (challenge protocol, off for every shipped recipe) is not restated."""
 from __future__ import annotations
 
 import warnings
 from typing import List
 
 import numpy as np
+
+
+# CholecT45/T50 triplet dictionary: triplet id -> (instrument, verb, target); iv = 10*i + v, it = 15*i + t (dataset label data)
+_TRIPLETS = (
+    (0,2,1), (0,2,0), (0,2,10), (0,0,3), (0,0,2), (0,0,4), (0,0,1), (0,0,0), (0,0,12), (0,0,8),
+    (0,0,10), (0,0,11), (0,0,13), (0,8,0), (0,1,2), (0,1,4), (0,1,1), (0,1,0), (0,1,12), (0,1,8),
+    (0,1,10), (0,1,11), (1,3,7), (1,3,5), (1,3,3), (1,3,2), (1,3,4), (1,3,1), (1,3,0), (1,3,8),
+    (1,3,10), (1,3,11), (1,2,9), (1,2,3), (1,2,2), (1,2,1), (1,2,0), (1,2,10), (1,0,1), (1,0,8),
+    (1,0,13), (1,1,2), (1,1,4), (1,1,0), (1,1,8), (1,1,10), (2,3,5), (2,3,3), (2,3,2), (2,3,4),
+    (2,3,1), (2,3,0), (2,3,8), (2,3,10), (2,5,5), (2,5,11), (2,2,5), (2,2,3), (2,2,2), (2,2,1),
+    (2,2,0), (2,2,10), (2,2,11), (2,1,0), (2,1,8), (3,3,10), (3,5,9), (3,5,5), (3,5,3), (3,5,2),
+    (3,5,1), (3,5,8), (3,5,10), (3,5,11), (3,2,1), (3,2,0), (3,2,10), (4,4,5), (4,4,3), (4,4,2),
+    (4,4,4), (4,4,1), (5,6,6), (5,2,2), (5,2,4), (5,2,1), (5,2,0), (5,2,10), (5,7,7), (5,7,4),
+    (5,7,8), (5,1,0), (5,1,8), (5,1,10), (0,9,14), (1,9,14), (2,9,14), (3,9,14), (4,9,14), (5,9,14),
+)
+
+
+def _component_index(component: str) -> np.ndarray:
+    t = np.array(_TRIPLETS, dtype=np.int64)
+    return {"i": t[:, 0], "v": t[:, 1], "t": t[:, 2], "iv": 10 * t[:, 0] + t[:, 1], "it": 15 * t[:, 0] + t[:, 2]}[component]
+
+
+def disentangle(x: np.ndarray, component: str) -> np.ndarray:
+    """[N,100] triplet scores or labels -> [N,K] of a component (K = 6, 10, 15, 26 iv pairs, 59 it pairs; classes in ascending id
+    order): max over the triplets that share the component value"""
+    if component == "ivt":
+        return x
+    idx = _component_index(component)
+    return np.stack([x[:, idx == c].max(axis=1) for c in np.unique(idx)], axis=1)
 
 
 class Recognition:
@@ -44,8 +76,13 @@ class Recognition:
                 out[c] = average_precision_score(t[:, c], p[:, c])
         return out
 
-    def compute_video_AP(self, component: str = "ivt"):
-        per_video = [self._ap_per_class(t, p) for t, p in zip(self.global_targets, self.global_predictions)]
+    def compute_video_AP(self, component: str = "ivt", ignore_null: bool = False):
+        if ignore_null:
+            raise NotImplementedError("challenge-protocol null filtering is not restated (off in every shipped recipe)")
+        if component != "ivt" and self.num_class != 100:
+            raise ValueError("component disentangling needs the 100-way triplet scores")
+        per_video = [self._ap_per_class(disentangle(t, component), disentangle(p, component))
+                     for t, p in zip(self.global_targets, self.global_predictions)]
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", category=RuntimeWarning)
             ap = np.nanmean(np.stack(per_video, 0), axis=0) if per_video else np.full(self.num_class, np.nan)

@@ -84,3 +84,28 @@ def test_checkpoint_interop_conventions():
     assert set(rep["used"]) == set(want) and all(torch.equal(after[k], mapped[k]) for k in want)
     kept = [k for k, _ in q2l if not k.startswith("backbone.0.")]
     assert kept and all(torch.equal(after[k], before[k]) for k in kept) and set(rep["kept"]) == set(kept)
+
+
+def test_recognition_component_disentangling():
+    """i / v / t / iv / it AP from the 100-way triplet scores: a component class = max over the triplets containing it"""
+    from computervision_codes_amd.metrics import Recognition, disentangle, _TRIPLETS
+    from sklearn.metrics import average_precision_score
+    assert len(_TRIPLETS) == 100 and _TRIPLETS[0] == (0, 2, 1) and _TRIPLETS[99] == (5, 9, 14)
+    rng = np.random.default_rng(0)
+    y = (rng.random((50, 100)) < 0.05).astype(np.float64)
+    p = rng.random((50, 100))
+    for comp, k in (("i", 6), ("v", 10), ("t", 15), ("iv", 26), ("it", 59)):
+        assert disentangle(p, comp).shape == (50, k)
+    # hand case: triplet 0 = (grasper, dissect?, ...) -> its instrument column is the max over all instrument-0 triplets
+    inst0 = [j for j, t in enumerate(_TRIPLETS) if t[0] == 0]
+    assert np.array_equal(disentangle(p, "i")[:, 0], p[:, inst0].max(1)) and np.array_equal(disentangle(y, "i")[:, 0], y[:, inst0].max(1))
+    m = Recognition(100)
+    m.update(y[:25], p[:25]); m.video_end()
+    m.update(y[25:], p[25:]); m.video_end()
+    got = m.compute_video_AP("v")
+    yv, pv = disentangle(y, "v"), disentangle(p, "v")
+    per_video = []
+    for sl in (slice(0, 25), slice(25, 50)):
+        per_video.append([average_precision_score(yv[sl, c], pv[sl, c]) if yv[sl, c].sum() > 0 else np.nan for c in range(10)])
+    want = np.nanmean(np.array(per_video), axis=0)
+    assert np.allclose(got["AP"], want, equal_nan=True) and abs(got["mAP"] - np.nanmean(want)) < 1e-12
