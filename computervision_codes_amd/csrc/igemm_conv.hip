@@ -102,7 +102,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 16, NT = WN / 16;
     constexpr int STAGE_BYTES = ROWS * 128;
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
     static_assert(BM % RPP == 0 && BN % RPP == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -503,9 +503,10 @@ struct TileCfg {
 // tile ids are 1-based in the C-ABI
 // ids 1-6: two operand stages; 7-12: deeper rings (3 for the 128-wide tiles, 4 for the small ones)
 // ids 13-16: 8-wave workgroups (one per CU): 256x128 with 2 / 3 stages, 256x256, 128x256 with 3 stages
+// ids 17-19: 16-wave workgroups (four waves per SIMD, 64x64 / 64x32 wave tiles): 256x256, 256x128 with 2 / 3 stages
 constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {64, 128}, {32, 64}, {32, 32},
                               {128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}, {128, 64},
-                              {256, 128}, {256, 128}, {256, 256}, {128, 256}};
+                              {256, 128}, {256, 128}, {256, 256}, {128, 256}, {256, 256}, {256, 128}, {256, 128}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <typename T, int BM, int BN, int WM_, int WN_, int STAGES, bool OUT_F32>
@@ -562,6 +563,9 @@ int launch_dtype(const ConvK& k, int tile, bool fast, hipStream_t s) {
         case 14: return launch_tile<T, 256, 128, 4, 2, 3, OUT_F32>(k, fast, s);
         case 15: return launch_tile<T, 256, 256, 2, 4, 2, OUT_F32>(k, fast, s);
         case 16: return launch_tile<T, 128, 256, 2, 4, 3, OUT_F32>(k, fast, s);
+        case 17: return launch_tile<T, 256, 256, 4, 4, 2, OUT_F32>(k, fast, s);
+        case 18: return launch_tile<T, 256, 128, 4, 4, 2, OUT_F32>(k, fast, s);
+        case 19: return launch_tile<T, 256, 128, 4, 4, 3, OUT_F32>(k, fast, s);
     }
     return MT4_EINVAL;
 }
@@ -576,7 +580,7 @@ int auto_tile(int M, int N, int nsteps, int es) {
     // 0.5-0.75x the operand bytes per FLOP through L2 -> LDS-DMA, whose issue cost is what the K-loop waits on
     if (es == 2 && N >= 256) {
         if (nsteps == 1 && tiles(13) >= fill) return 13;
-        if (nsteps >= 2 && tiles(15) >= 190) return 15;
+        if (nsteps >= 2 && tiles(15) >= 190) return 17;
     }
     if (es == 2 && N > 64 && N <= 128 && nsteps >= 4 && nsteps <= 8 && tiles(14) >= 8 * fill) return 14;   // many rounds: small tail
     if (nsteps == 1 && tiles(3) >= 4 * fill) return 3;   // single K-step: smallest footprint, most workgroups per CU
