@@ -87,6 +87,55 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// Narrow rows (G*C/V <= 32 chunks: Swin stage 1-2, C = 128 / 256 in bf16): LPR lanes per row, 64/LPR rows per wave, so that every
+// lane of the wave carries a 16-byte chunk (one row per wave left 48 / 32 of the 64 lanes idle and moved 256 B per wave-load).
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, T* __restrict__ y, int M_out, int C, int G,
+                                                               const int* __restrict__ map, int L_out, int L_in, float eps) {
+    constexpr int V = Vec<T>::N;
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int m = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const int j = lane % LPR;
+    const int N = G * C;
+    const int nch = N / V;
+    const bool ok = m < M_out && j < nch;
+    float v[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] = 0.f;
+    const int e = j * V;
+    if (ok) {
+        const int g = e / C;
+        long long src = m;
+        if (map) {
+            const int b = m / L_out, l = m - b * L_out;
+            src = (long long)b * L_in + map[l * G + g];
+        }
+        Vec<T>::load(x + src * C + (e - g * C), v);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < V; ++k) sum += v[k];
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)N;
+    float sq = 0.f;
+    if (j < nch) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) { const float d = v[k] - mean; sq += d * d; }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = rsqrtf(sq / (float)N + eps);
+    if (ok) {
+        float o[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = (v[k] - mean) * rstd * gamma[e + k] + beta[e + k];
+        Vec<T>::store(y + (long long)m * N + e, o);
+    }
+}
+
 extern "C" int mt4_layernorm(const void* x, const float* gamma, const float* beta, void* y, int32_t M_out, int32_t C, int32_t G,
                              const int32_t* map, int32_t L_out, int32_t L_in, float eps, int32_t dtype, void* stream) {
     mt4_clear_error();
@@ -101,6 +150,15 @@ extern "C" int mt4_layernorm(const void* x, const float* gamma, const float* bet
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(cdiv(M_out, 4)), block(256);
 #define LN_LAUNCH(TT, MC) hipLaunchKernelGGL((layernorm_kernel<TT, MC>), grid, block, 0, s, (const TT*)x, gamma, beta, (TT*)y, M_out, C, G, map, L_out, L_in, eps)
+    if (nch <= 32) {
+        const int lpr = nch <= 16 ? 16 : 32;
+        const dim3 g2(cdiv(M_out, 4 * (64 / lpr)));
+#define LN_NARROW(TT, LL) hipLaunchKernelGGL((layernorm_narrow_kernel<TT, LL>), g2, block, 0, s, (const TT*)x, gamma, beta, (TT*)y, M_out, C, G, map, L_out, L_in, eps)
+        if (dtype == MT4_BF16) { if (lpr == 16) LN_NARROW(u16, 16); else LN_NARROW(u16, 32); }
+        else { if (lpr == 16) LN_NARROW(float, 16); else LN_NARROW(float, 32); }
+#undef LN_NARROW
+        return mt4_check_launch();
+    }
     const int need = cdiv(nch, 64);
     if (dtype == MT4_BF16) {
         if (need <= 2) LN_LAUNCH(u16, 2); else if (need <= 4) LN_LAUNCH(u16, 4); else if (need <= 8) LN_LAUNCH(u16, 8); else LN_LAUNCH(u16, 16);
