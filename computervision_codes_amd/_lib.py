@@ -59,6 +59,7 @@ SIGNATURES = {
     "mt4_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                 C.c_float, _i32, _vp]),
     "mt4_window_attention_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _vp]),
+    "mt4_window_attention_rel_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _vp]),
     "mt4_patchify": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _FLOAT3, _FLOAT3, _i32, _vp]),
     "mt4_add_rowbcast": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i32, _i32, _i32, _vp]),
     "mt4_groupwise_linear": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

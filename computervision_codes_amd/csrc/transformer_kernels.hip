@@ -544,7 +544,13 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const u16* _
                                                                     const u16* __restrict__ v, u16* __restrict__ out,
                                                                     const float* __restrict__ bias, const float* __restrict__ mask, int N,
                                                                     int q_stride, int k_stride, int v_stride, int o_stride, int nW,
-                                                                    float scale) {
+                                                                    float scale, const float* __restrict__ rel_table,
+                                                                    const int* __restrict__ region, int ws) {
+    // rel_table != NULL: the [N][N] bias is never materialised -- bias(i,j) = table[h][(yi-yj+ws-1)*(2ws-1) + (xi-xj+ws-1)]
+    // (`swin_transformer.py:92-103,129-132`) is gathered from the head's (2ws-1)^2 table in LDS, and the shifted-window mask is
+    // (region[w][i] != region[w][j]) ? -100 : 0 (`:222-229`) from the per-token region ids of the window type.  With the
+    // expanded tables the kernel pulled 2 x N*N*4 bytes per (window, head) through L2 inside its softmax loop: 28 % of the
+    // time of an unshifted block and 60 % more in a shifted one.
     constexpr int NP = NT * 16;
     constexpr int NP2 = ((NT + 1) / 2) * 32;  // keys padded to whole 32-key MFMA blocks
     constexpr int QK_PITCH = 80;              // bytes per Q/K row (64 used)
@@ -553,6 +559,8 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const u16* _
     char* Qs = smem;
     char* Ks = smem + NP * QK_PITCH;
     char* Vt = smem + 2 * NP * QK_PITCH;
+    constexpr int VT_BYTES = 32 * ((((NT + 1) / 2) * 32 + 8) * 2);
+    float* Tb = (float*)(smem + 2 * NP * QK_PITCH + VT_BYTES);   // rel mode: [2T] table + -1e30 pad area, then key index, region id per token
     const int b = blockIdx.y, h = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, qd = lane >> 4;
@@ -577,6 +585,22 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const u16* _
 #pragma unroll
         for (int i = 0; i < 8; ++i) *(u16*)(Vt + (pc * 8 + i) * VT_PITCH + row * 2) = ve[i];
     }
+    const int T = (2 * ws - 1) * (2 * ws - 1);
+    int* Kidx = (int*)(Tb + 2 * T + 4);
+    int* Rid = Kidx + NP;
+    int mixed = 0;   // shifted block: does this window type hold more than one region?  (only the last row / column of windows do)
+    if (rel_table) {
+        for (int e = tid; e < 2 * T + 4; e += 256) Tb[e] = e < T ? rel_table[(long long)h * T + e] : -1e30f;
+        const int* rg = region ? region + (long long)(b % nW) * N : nullptr;
+        for (int e = tid; e < NP; e += 256) {
+            const int yj = e / ws, xj = e - yj * ws;
+            Kidx[e] = e < N ? yj * (2 * ws - 1) + xj : -T - 3;                // padded keys index the -1e30 area
+            const int r = (rg && e < N) ? rg[e] : (rg ? rg[0] : 0);
+            Rid[e] = r;
+            if (rg && r != rg[0]) mixed = 1;
+        }
+        mixed = __syncthreads_or(mixed);
+    }
     if (NP2 > NP) {  // zero the V^T columns of the padding half-block
         for (int e = tid; e < 32 * (NP2 - NP); e += 256) {
             const int d = e / (NP2 - NP), c = NP + e % (NP2 - NP);
@@ -595,18 +619,41 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const u16* _
             s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
         // bias (+ mask) rows are padded to [NP][NP] on the host: padded keys hold -1e30
-        const float* brow = bias + ((long long)h * NP + query) * NP + qd * 4;
+        const float* brow = bias ? bias + ((long long)h * NP + query) * NP + qd * 4 : nullptr;
         const float* mrow = mask ? mask + ((long long)(b % nW) * NP + query) * NP + qd * 4 : nullptr;
         float mx = -INFINITY;
+        if (rel_table) {
+            const int qq = query < N ? query : 0;
+            const int yi = qq / ws, xi = qq - yi * ws;
+            const int qbase = (yi + ws - 1) * (2 * ws - 1) + xi + ws - 1;
+            const int qrid = Rid[qq];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            const float4 bb = *(const float4*)(brow + kt * 16);
-            s[kt][0] += bb.x; s[kt][1] += bb.y; s[kt][2] += bb.z; s[kt][3] += bb.w;
-            if (mrow) {
-                const float4 mm = *(const float4*)(mrow + kt * 16);
-                s[kt][0] += mm.x; s[kt][1] += mm.y; s[kt][2] += mm.z; s[kt][3] += mm.w;
+            for (int kt = 0; kt < NT; ++kt) {
+                if ((ws & 3) == 0) {   // 4 consecutive keys share an image row: their table entries are 4 consecutive floats
+                    const float* tp = Tb + (qbase - Kidx[kt * 16 + qd * 4]);
+                    s[kt][0] += tp[0]; s[kt][1] += tp[-1]; s[kt][2] += tp[-2]; s[kt][3] += tp[-3];
+                } else {
+                    const int4 kk = *(const int4*)(Kidx + kt * 16 + qd * 4);
+                    s[kt][0] += Tb[qbase - kk.x]; s[kt][1] += Tb[qbase - kk.y]; s[kt][2] += Tb[qbase - kk.z]; s[kt][3] += Tb[qbase - kk.w];
+                }
+                if (mixed) {
+                    const int4 rr = *(const int4*)(Rid + kt * 16 + qd * 4);
+                    s[kt][0] += rr.x != qrid ? -100.f : 0.f; s[kt][1] += rr.y != qrid ? -100.f : 0.f;
+                    s[kt][2] += rr.z != qrid ? -100.f : 0.f; s[kt][3] += rr.w != qrid ? -100.f : 0.f;
+                }
+                mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
             }
-            mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const float4 bb = *(const float4*)(brow + kt * 16);
+                s[kt][0] += bb.x; s[kt][1] += bb.y; s[kt][2] += bb.z; s[kt][3] += bb.w;
+                if (mrow) {
+                    const float4 mm = *(const float4*)(mrow + kt * 16);
+                    s[kt][0] += mm.x; s[kt][1] += mm.y; s[kt][2] += mm.z; s[kt][3] += mm.w;
+                }
+                mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+            }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -646,21 +693,25 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const u16* _
     }
 }
 
-extern "C" int mt4_window_attention_bf16(const void* q, const void* k, const void* v, void* out, const float* bias_padded,
-                                         const float* mask_padded, int32_t B, int32_t H, int32_t N, int32_t q_stride, int32_t k_stride,
-                                         int32_t v_stride, int32_t o_stride, int32_t nW, float scale, void* stream) {
+static int window_attention_launch(const void* q, const void* k, const void* v, void* out, const float* bias_padded,
+                                   const float* mask_padded, const float* rel_table, const int32_t* region, int32_t ws, int32_t B, int32_t H,
+                                   int32_t N, int32_t q_stride, int32_t k_stride, int32_t v_stride, int32_t o_stride, int32_t nW, float scale,
+                                   void* stream) {
     mt4_clear_error();
-    if (!q || !k || !v || !out || !bias_padded || B <= 0 || H <= 0 || N <= 0 || N > 256) return MT4_EINVAL;
-    if (mask_padded && nW <= 0) return MT4_EINVAL;
+    if (!q || !k || !v || !out || (!bias_padded && !rel_table) || B <= 0 || H <= 0 || N <= 0 || N > 256) return MT4_EINVAL;
+    if ((mask_padded || region) && nW <= 0) return MT4_EINVAL;
+    if (rel_table && (ws <= 0 || ws * ws != N)) return MT4_EINVAL;
     if (B > 65535) return MT4_EUNSUPPORTED;
     if ((q_stride | k_stride | v_stride) % 8 || o_stride % 4 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) || ((uintptr_t)out & 7))
         return MT4_EALIGN;
     const int NT = (N + 15) / 16;
     const int NP = NT * 16, NP2 = ((NT + 1) / 2) * 32;
-    const size_t lds = (size_t)2 * NP * 80 + (size_t)32 * (NP2 + 8) * 2;
+    size_t lds = (size_t)2 * NP * 80 + (size_t)32 * (NP2 + 8) * 2;
+    if (rel_table) lds += ((size_t)2 * (2 * ws - 1) * (2 * ws - 1) + 4) * 4 + (size_t)2 * NP * 4;
+    if (!rel_table) ws = 1;
     const dim3 grid(H, B), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define WA(NTV) hipLaunchKernelGGL((window_attention_mfma_kernel<NTV>), grid, block, lds, s, (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, bias_padded, mask_padded, N, q_stride, k_stride, v_stride, o_stride, nW, scale)
+#define WA(NTV) hipLaunchKernelGGL((window_attention_mfma_kernel<NTV>), grid, block, lds, s, (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, bias_padded, mask_padded, N, q_stride, k_stride, v_stride, o_stride, nW, scale, rel_table, region, ws)
     switch (NT) {
         case 1: WA(1); break; case 2: WA(2); break; case 3: WA(3); break; case 4: WA(4); break;
         case 5: WA(5); break; case 6: WA(6); break; case 7: WA(7); break; case 8: WA(8); break;
@@ -669,4 +720,18 @@ extern "C" int mt4_window_attention_bf16(const void* q, const void* k, const voi
     }
 #undef WA
     return mt4_check_launch();
+}
+
+extern "C" int mt4_window_attention_bf16(const void* q, const void* k, const void* v, void* out, const float* bias_padded,
+                                         const float* mask_padded, int32_t B, int32_t H, int32_t N, int32_t q_stride, int32_t k_stride,
+                                         int32_t v_stride, int32_t o_stride, int32_t nW, float scale, void* stream) {
+    return window_attention_launch(q, k, v, out, bias_padded, mask_padded, nullptr, nullptr, 0, B, H, N, q_stride, k_stride, v_stride, o_stride,
+                                   nW, scale, stream);
+}
+
+extern "C" int mt4_window_attention_rel_bf16(const void* q, const void* k, const void* v, void* out, const float* rel_table,
+                                             const int32_t* region, int32_t ws, int32_t B, int32_t H, int32_t q_stride, int32_t k_stride,
+                                             int32_t v_stride, int32_t o_stride, int32_t nW, float scale, void* stream) {
+    return window_attention_launch(q, k, v, out, nullptr, nullptr, rel_table, region, ws, B, H, ws * ws, q_stride, k_stride, v_stride, o_stride,
+                                   nW, scale, stream);
 }

@@ -309,6 +309,26 @@ def window_attention_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, 
     return out
 
 
+def window_attention_rel_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, batch: int, heads: int, ws: int, q_stride: int,
+                              k_stride: int, v_stride: int, scale: float, rel_table: torch.Tensor,
+                              region: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """MFMA attention core of a Swin block from its relative-position table [heads, (2ws-1)^2] (fp32) and, for a shifted block, the
+    region ids [nW, ws*ws] (int32) of the window types -- no [N,N] bias / mask tensors (see mt4_window_attention_rel_bf16)"""
+    _need_cuda(q, k, v, rel_table, region)
+    n = ws * ws
+    assert q.dtype == torch.bfloat16 and rel_table.dtype == torch.float32 and tuple(rel_table.shape) == (heads, (2 * ws - 1) ** 2)
+    assert rel_table.is_contiguous()
+    nw = 1
+    if region is not None:
+        assert region.dtype == torch.int32 and region.is_contiguous() and region.shape[1] == n and batch % region.shape[0] == 0
+        nw = region.shape[0]
+    out = torch.empty((batch * n, heads * 32), dtype=torch.bfloat16, device=q.device)
+    check(lib.mt4_window_attention_rel_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), rel_table.data_ptr(),
+                                            region.data_ptr() if region is not None else None, ws, batch, heads, q_stride, k_stride, v_stride,
+                                            heads * 32, nw, scale, _stream()), "mt4_window_attention_rel_bf16")
+    return out
+
+
 def patchify(img: torch.Tensor, patch: int, dtype: torch.dtype, mean=None, std=None) -> torch.Tensor:
     """float32 NCHW [B,3,H,W] (normalised) or uint8 NHWC [B,H,W,3] -> [B*H/P*W/P, 3*P*P] rows"""
     _need_cuda(img)

@@ -53,8 +53,8 @@ def _rel_pos_index(ws: int) -> torch.Tensor:
     return rel.sum(-1)
 
 
-def _shift_mask(res: int, ws: int, shift: int) -> torch.Tensor:
-    """`swin_transformer.py:210-229`: [nW, N, N], 0 / -100.0"""
+def _shift_regions(res: int, ws: int, shift: int) -> torch.Tensor:
+    """`swin_transformer.py:210-221`: region id of every token of every window type, [nW, N]"""
     img = torch.zeros((res, res))
     cnt = 0
     for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
@@ -62,7 +62,12 @@ def _shift_mask(res: int, ws: int, shift: int) -> torch.Tensor:
             img[hs, wsl] = cnt
             cnt += 1
     nw = res // ws
-    mw = img.view(nw, ws, nw, ws).permute(0, 2, 1, 3).reshape(nw * nw, ws * ws)
+    return img.view(nw, ws, nw, ws).permute(0, 2, 1, 3).reshape(nw * nw, ws * ws)
+
+
+def _shift_mask(res: int, ws: int, shift: int) -> torch.Tensor:
+    """`swin_transformer.py:210-229`: [nW, N, N], 0 / -100.0"""
+    mw = _shift_regions(res, ws, shift)
     m = mw.unsqueeze(1) - mw.unsqueeze(2)
     return torch.where(m != 0, torch.full_like(m, -100.0), torch.zeros_like(m)).contiguous()
 
@@ -164,9 +169,10 @@ class Qeruy2Label:
                     qkv=self._lin(q + "attn.qkv.weight", q + "attn.qkv.bias"), proj=self._lin(q + "attn.proj.weight", q + "attn.proj.bias"),
                     fc1=self._lin(q + "mlp.fc1.weight", q + "mlp.fc1.bias"), fc2=self._lin(q + "mlp.fc2.weight", q + "mlp.fc2.bias"),
                     bias=bias, mask=_shift_mask(res, ws, shift).to(dev) if shift > 0 else None,
-                    # MFMA core (bf16, head dim 32): tables padded to 16-token tiles, padded keys masked out
-                    bias_p=ops.pad_attention_bias(bias) if self._mfma_attn(s) else None,
-                    mask_p=ops.pad_attention_bias(_shift_mask(res, ws, shift).to(dev), 0.0) if (shift > 0 and self._mfma_attn(s)) else None,
+                    # MFMA core (bf16, head dim 32): the (2ws-1)^2 table per head and the region ids of the window types; the
+                    # kernel gathers bias and mask from them in LDS
+                    rel=tbl.t().contiguous().float().to(dev) if self._mfma_attn(s) else None,
+                    region=_shift_regions(res, ws, shift).to(torch.int32).to(dev) if (shift > 0 and self._mfma_attn(s)) else None,
                     row_map=_window_row_map(res, ws, shift).to(dev)))
             st = dict(res=res, ws=ws, nh=nh, c=self.cfg["embed_dim"] * 2 ** s, blocks=blocks)
             if s < 3:
@@ -217,10 +223,10 @@ class Qeruy2Label:
         L, n, nwin = res * res, ws * ws, (res // ws) ** 2
         xw = ops.layernorm(x, *blk["norm1"], row_map=blk["row_map"], group=1, l_out=L, l_in=L)
         qkv = ops.linear(xw, *blk["qkv"])
-        if blk["bias_p"] is not None:
-            a = ops.window_attention_bf16(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch=batch * nwin, heads=nh, n=n, q_stride=3 * c,
-                                          k_stride=3 * c, v_stride=3 * c, scale=(c // nh) ** -0.5, bias_padded=blk["bias_p"],
-                                          mask_padded=blk["mask_p"])
+        if blk["rel"] is not None:
+            a = ops.window_attention_rel_bf16(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch=batch * nwin, heads=nh, ws=ws, q_stride=3 * c,
+                                              k_stride=3 * c, v_stride=3 * c, scale=(c // nh) ** -0.5, rel_table=blk["rel"],
+                                              region=blk["region"])
         else:
             a = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch=batch * nwin, heads=nh, nq=n, nk=n, hd=c // nh,
                               q_stride=3 * c, k_stride=3 * c, v_stride=3 * c, scale=(c // nh) ** -0.5, bias=blk["bias"], mask=blk["mask"])

@@ -154,6 +154,13 @@ int mt4_attention(const void* q, const void* k, const void* v, void* out, const 
 int mt4_window_attention_bf16(const void* q, const void* k, const void* v, void* out, const float* bias_padded,
                               const float* mask_padded, int32_t B, int32_t H, int32_t N, int32_t q_stride, int32_t k_stride,
                               int32_t v_stride, int32_t o_stride, int32_t nW, float scale, void* stream);
+/* The same core for a Swin block given its relative-position table instead of the expanded bias: rel_table [H][(2ws-1)^2] fp32
+ * (`relative_position_bias_table` transposed, swin_transformer.py:81-83), bias(i,j) = table[(yi-yj+ws-1)(2ws-1) + xi-xj+ws-1]
+ * (:92-103); region [nW][ws*ws] int32 = the shifted-window region id of every token of each window type (`img_mask` of :210-221
+ * after window_partition), mask = -100 where the ids differ (:222-229); NULL for an unshifted block.  N = ws*ws <= 256. */
+int mt4_window_attention_rel_bf16(const void* q, const void* k, const void* v, void* out, const float* rel_table, const int32_t* region,
+                                  int32_t ws, int32_t B, int32_t H, int32_t q_stride, int32_t k_stride, int32_t v_stride, int32_t o_stride,
+                                  int32_t nW, float scale, void* stream);
 
 /* Non-overlapping PxP patches as GEMM rows: out[(b*H/P + ph)*W/P + pw][c*P*P + kh*P + kw] (PatchEmbed.proj,
  * swin_transformer.py:435,446).  in: normalised float32 NCHW, or (from_u8) uint8 NHWC frames normalised on the fly. */

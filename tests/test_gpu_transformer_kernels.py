@@ -202,3 +202,25 @@ def test_window_attention_mfma_bf16(cuda, cfg):
     gen = ops.attention(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], batch=B, heads=H, nq=N, nk=N, hd=32, q_stride=3 * c, k_stride=3 * c, v_stride=3 * c,
                         scale=scale, bias=bias.to(cuda), mask=mask.to(cuda) if mask is not None else None)
     assert (out.float() - gen.float()).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("ws,H,res,shift", [(12, 4, 24, 6), (12, 4, 24, 0), (7, 8, 14, 3), (7, 3, 7, 0), (4, 2, 8, 2)])
+def test_window_attention_from_relative_table_equals_expanded_tables(cuda, ws, H, res, shift):
+    """the table / region-id form of the Swin core (`mt4_window_attention_rel_bf16`) against the same kernel fed with the expanded
+    [H,N,N] bias and [nW,N,N] mask the reference materialises (`swin_transformer.py:92-103,129-132,210-229`): bit-identical"""
+    from computervision_codes_amd import ops
+    from computervision_codes_amd.spatial_transformer import _rel_pos_index, _shift_mask, _shift_regions
+    N, nwin = ws * ws, (res // ws) ** 2
+    B = 2 * nwin
+    c = H * 32
+    qkv = _rand((B * N, 3 * c), 71, 2.0).to(torch.bfloat16).to(cuda)
+    table = _rand(((2 * ws - 1) ** 2, H), 72)                                   # the reference's parameter layout [T, heads]
+    bias = table[_rel_pos_index(ws).view(-1)].view(N, N, H).permute(2, 0, 1).contiguous()
+    mask = _shift_mask(res, ws, shift) if shift else None
+    scale = 32 ** -0.5
+    kw = dict(batch=B, heads=H, q_stride=3 * c, k_stride=3 * c, v_stride=3 * c, scale=scale)
+    ref = ops.window_attention_bf16(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], n=N, bias_padded=ops.pad_attention_bias(bias.to(cuda)),
+                                    mask_padded=ops.pad_attention_bias(mask.to(cuda), 0.0) if shift else None, **kw)
+    got = ops.window_attention_rel_bf16(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], ws=ws, rel_table=table.t().contiguous().to(cuda),
+                                        region=_shift_regions(res, ws, shift).to(torch.int32).to(cuda) if shift else None, **kw)
+    assert torch.equal(got, ref)
