@@ -201,11 +201,13 @@ __global__ __launch_bounds__(256) void wgrad_conv2d_f32_kernel(const float* __re
     long long me = mb + a.rows_per_split;
     if (me > a.M) me = a.M;
     const int HoWo = a.Ho * a.Wo;
-    for (long long m0 = mb; m0 < me; m0 += KT) {
+    // software pipeline: the global loads of chunk c+1 are in flight while chunk c runs its MFMAs (the loop was one exposed HBM
+    // latency per 32 pixels)
+    float4 ry[2], rx[2];
+    auto fetch = [&](long long m0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = sr + 16 * i;
-            const long long m = m0 + r;
+            const long long m = m0 + sr + 16 * i;
             float4 vy = make_float4(0, 0, 0, 0), vx = make_float4(0, 0, 0, 0);
             if (m < me) {
                 if (co0 + sc < a.Cout) vy = *(const float4*)(dy + m * a.Cout + co0 + sc);
@@ -218,10 +220,20 @@ __global__ __launch_bounds__(256) void wgrad_conv2d_f32_kernel(const float* __re
                         vx = *(const float4*)(x + (((long long)b * a.H + hi) * a.W + wi) * a.Cin + xci);
                 }
             }
-            *(float4*)(sdy + r * LDP + sc) = vy;
-            *(float4*)(sx + r * LDP + sc) = vx;
+            ry[i] = vy;
+            rx[i] = vx;
+        }
+    };
+    fetch(mb);
+    for (long long m0 = mb; m0 < me; m0 += KT) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = sr + 16 * i;
+            *(float4*)(sdy + r * LDP + sc) = ry[i];
+            *(float4*)(sx + r * LDP + sc) = rx[i];
         }
         __syncthreads();
+        if (m0 + KT < me) fetch(m0 + KT);
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {
             const int row = kk * 4 + (lane >> 4);
