@@ -231,3 +231,14 @@ def test_mstct_fp32_vs_reference_golden(cuda, name):
     assert _maxerr(flat[:: max(1, flat.numel() // 8192)], z["concat_sample"]) < 1e-3
     out2 = m.forward_btd(x.to(cuda))              # frame-major entry (feature-file layout): same numbers
     assert torch.equal(out2[gi][0], y)
+
+
+def test_spatial_cnn_multi_stream_extract_is_byte_identical(cuda):
+    """`extract_u8(frames, streams=2)`: parts of the batch on their own HIP streams -- same bytes as the single-stream call"""
+    _, cfg = load_golden("cnn_resnet50_224")
+    m = _cnn_model(cfg, torch.bfloat16)
+    frames = synth.synthetic_frames(12, 96, 128, seed=9).to(cuda)
+    a = m.extract_u8(frames)
+    for ns in (2, 3):
+        b = m.extract_u8(frames, streams=ns)
+        assert torch.equal(a[3][0], b[3][0]) and all(torch.equal(x[1], y[1]) for x, y in zip(a, b))
