@@ -582,7 +582,7 @@ int auto_tile(int M, int N, int nsteps, int es) {
         if (nsteps == 1 && tiles(13) >= fill) return 13;
         if (nsteps >= 2 && tiles(15) >= 190) return 17;
     }
-    if (es == 2 && N > 64 && N <= 128 && nsteps >= 4 && nsteps <= 8 && tiles(14) >= 8 * fill) return 14;   // many rounds: small tail
+    if (es == 2 && N > 64 && N <= 128 && nsteps >= 4 && tiles(19) >= 8 * fill) return 19;   // 16-wave 256x128, 3 stages; many rounds: small tail
     if (nsteps == 1 && tiles(3) >= 4 * fill) return 3;   // single K-step: smallest footprint, most workgroups per CU
     if (N > 64) {
         if (nsteps >= 4 && tiles(1) >= fill) return 1;
