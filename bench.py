@@ -222,20 +222,25 @@ def device_frames(n, h, w, seed, dev, nbase=16):
 
 
 def swin_bench(dev, batch=128):
-    """BASELINE configs[2]: Swin-B + Q2L head, bf16, frames/s at 384x384 (reference-legal swin_B_384_22k) and 224x224."""
+    """BASELINE configs[2]: Swin-B + the CholecT50 triplet head = `loss_type all` (four Q2L decoders over the shared transformer +
+    the KD mixing), bf16, frames/s at 384x384 (reference-legal swin_B_384_22k) and 224x224; the single-decoder teacher
+    configuration (`loss_type i`, what Scripts/train_fold1.sh trains) beside it."""
     from computervision_codes_amd import shapes, synth
     from computervision_codes_amd.spatial_transformer import build_q2l
     out = {}
     for name, img in (("swin_B_384_22k", 384), ("swin_B_224_22k", 224)):
-        args = types.SimpleNamespace(backbone=name, img_size=img, hidden_dim=1024, loss_type="i")
-        m = build_q2l(args, dtype=torch.bfloat16, device=str(dev)).eval()
-        m.load_state_dict(synth.fill_from_shapes(shapes.q2l_param_shapes(name, img, 1024, "i"), seed=7))
-        frames = device_frames(batch, img, img, 7, dev)
-        ms = _time_call(lambda: m(frames), iters=5)
-        gf = (94.2 + 15.3) if img == 384 else (30.9 + 10.2)
-        out[f"{name}"] = dict(frames_per_s=round(batch / ms * 1e3, 1), ms_per_batch=round(ms, 3), batch=batch,
-                              mfma_frac=round(gf * 1e9 * batch / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
-        del m
+        for lt in ("all", "i"):
+            args = types.SimpleNamespace(backbone=name, img_size=img, hidden_dim=1024, loss_type=lt)
+            m = build_q2l(args, dtype=torch.bfloat16, device=str(dev)).eval()
+            m.load_state_dict(synth.fill_from_shapes(shapes.q2l_param_shapes(name, img, 1024, lt), seed=7))
+            frames = device_frames(batch, img, img, 7, dev)
+            tf = [synth.synthetic_features(batch, 512, seed=7 + k)[0].to(dev) for k in (1, 2, 3)] if lt == "all" else []
+            ms = _time_call(lambda: m(frames, *tf), iters=5)
+            ndec = 4 if lt == "all" else 1
+            gf = (94.2 + 15.3 * ndec) if img == 384 else (30.9 + 10.2 * ndec)
+            out[f"{name}_{lt}"] = dict(frames_per_s=round(batch / ms * 1e3, 1), ms_per_batch=round(ms, 3), batch=batch, decoders=ndec,
+                                       mfma_frac=round(gf * 1e9 * batch / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
+            del m
     return out
 
 
@@ -245,8 +250,8 @@ def spatial_train_bench(dev):
     from computervision_codes_amd import shapes, synth
     from computervision_codes_amd.spatial_cnn_train import SpatialCnnTrainer
     out = {}
-    for net in ("resnet18", "resnet50"):
-        B, H, W = 8, 256, 448
+    for net, B in (("resnet18", 8), ("resnet50", 8), ("resnet50", 64)):
+        H, W = 256, 448
         tr = SpatialCnnTrainer(net, lr=0.01, device=str(dev)).load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes(net), seed=5))
         frames = synth.synthetic_frames(B, H, W, seed=1).to(dev)
         z = torch.cat([torch.from_numpy((synth.uniform01(5, i, B * k) < 0.15).reshape(B, k).astype(np.float32)) for i, k in
