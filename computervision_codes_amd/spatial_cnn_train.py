@@ -39,8 +39,11 @@ class _Unit:
 
 class SpatialCnnTrainer:
     def __init__(self, network: str = "resnet50", lr: float = 0.01, weight_decay: float = 1e-5, rates: Sequence[float] = (1.0, 1.0, 1.0),
-                 temp: float = 4.0, device: str = "cuda", process_group=None):
+                 temp: float = 4.0, device: str = "cuda", process_group=None, overlap: bool = True):
         self.network, self.lr, self.wd, self.rates, self.temp = network, lr, weight_decay, tuple(rates), float(temp)
+        self.overlap = overlap            # DDP: all-reduce each gradient bucket as soon as the backward has written it (eager steps)
+        self._pending: list = []
+        self._capturing = False
         self.dev, self.pg = torch.device(device), process_group
         self.C = resnet_feat_dim(network)
         self._table = spatial_cnn_shapes(network)
@@ -87,7 +90,10 @@ class SpatialCnnTrainer:
             return (p.view(shape), g.view(shape)) if shape else (p, g)
 
         trained = set()
+        self._ranges: Dict[str, list] = {}     # flat-buffer range of every gradient bucket: "stem", "layer1".."layer4", "heads"
         for conv, bn, ci, co, k, s, pad in specs:
+            bucket = conv.split(".")[2] if ".layer" in conv else "stem"
+            self._ranges.setdefault(bucket, [off, off])
             u = _Unit()
             u.name, u.bn, u.cin, u.cout, u.k, u.stride, u.pad = conv, bn, ci, co, k, s, pad
             kp = ops.packed_k(ci, k, k, F32)
@@ -104,8 +110,10 @@ class SpatialCnnTrainer:
             self.nbt[bn] = int(sd[bn + ".num_batches_tracked"])
             u.wt, u.phase_w = None, None
             self.units[conv] = u
+            self._ranges[bucket][1] = off
             trained |= {conv + ".weight", bn + ".weight", bn + ".bias", bn + ".running_mean", bn + ".running_var", bn + ".num_batches_tracked"}
         self.lin: Dict[str, tuple] = {}
+        self._ranges["heads"] = [off, total]
         for name, co, ci in lin:
             kp = ops.packed_k(ci, 1, 1, F32)
             w, gw = take(co * kp, (co, kp))
@@ -280,7 +288,11 @@ class SpatialCnnTrainer:
             if g is None:
                 from .graph import GraphedForward
                 keep = {n: (u.rmean.clone(), u.rvar.clone()) for n, u in self.units.items()}   # warm-up + capture runs must not count
-                g = self._graphs[key] = GraphedForward(lambda f, zz, *t: self._fwd_bwd(f, zz, t[:3], t[3:]), [frames, z, *tp, *tf])
+                self._capturing = True
+                try:
+                    g = self._graphs[key] = GraphedForward(lambda f, zz, *t: self._fwd_bwd(f, zz, t[:3], t[3:]), [frames, z, *tp, *tf])
+                finally:
+                    self._capturing = False
                 for n, u in self.units.items():
                     u.rmean.copy_(keep[n][0])
                     u.rvar.copy_(keep[n][1])
@@ -335,7 +347,7 @@ class SpatialCnnTrainer:
                     x = self._fwd_unit(U[q + "conv3"], o, residual=idt, saved=saved)
                 else:
                     x = self._fwd_unit(U[q + "conv2"], o, residual=idt, saved=saved)
-                blocks.append((first, has_ds, bott))
+                blocks.append((first, has_ds, bott, li))
         Bh, Hh, Wh, _ = x.shape
         feat = ops.global_avgpool(x)                                               # [B, C]
         # ---- heads, KD branch
@@ -364,9 +376,10 @@ class SpatialCnnTrainer:
         for n, (m, t) in enumerate(zip(("mi", "mv", "mt"), tf)):
             dte = dtau[:, n:n + 1].expand(B, C).contiguous()                        # d(tea_n)[b][:] = dtau[b][n]
             self._linear_bwd(m, dte, t, need_dx=False)
+        self._reduce_bucket("heads")
         # ---- backward through the trunk
         dx = ops.avgpool_bwd(dfeat, Bh, Hh * Wh, C).view(Bh, Hh, Wh, C)
-        for first, has_ds, bott in reversed(blocks):
+        for bi_, (first, has_ds, bott, li) in reversed(list(enumerate(blocks))):
             recs = saved[first:first + (1 if has_ds else 0) + (3 if bott else 2)]
             main = recs[1:] if has_ds else recs
             d, dres = self._bwd_unit(main[-1], dx, want_dres=True)                  # last conv: ReLU gate after the residual add
@@ -377,9 +390,26 @@ class SpatialCnnTrainer:
                 dx, _ = self._bwd_unit(main[0], d, residual_for_dx=d_id)
             else:
                 dx, _ = self._bwd_unit(main[0], d, residual_for_dx=dres)
+            if bi_ == 0 or blocks[bi_ - 1][3] != li:      # first block of the layer done: the layer's gradients are complete
+                self._reduce_bucket(f"layer{li}")
         da0 = ops.maxpool3x3s2_bwd(a0, dx)
         self._bwd_unit(saved[0], da0, need_dx=False)
+        self._reduce_bucket("stem")
         return col_loss, soft, kdl
+
+    def _ddp_world(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _reduce_bucket(self, name: str):
+        """DDP overlap: the bucket's all-reduce is enqueued behind the kernels that wrote it and runs while the backward
+        of the earlier layers continues; `apply_update` waits for all of them.  Not inside a hipGraph capture."""
+        if not self.overlap or self._capturing or self._ddp_world() == 1:
+            return
+        import torch.distributed as dist
+        a, b = self._ranges[name]
+        if b > a:
+            self._pending.append(dist.all_reduce(self.G[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _col_scale(self, B: int) -> torch.Tensor:
         if B not in self._col_scales:
@@ -391,6 +421,12 @@ class SpatialCnnTrainer:
         return {u.bn: a.permute(0, 3, 1, 2).cpu() for (u, _, _, _, _, a, relu) in self.last_saved if relu}
 
     def apply_update(self):
-        scale = allreduce_sum_flat(self.G, self.pg)
+        if self._pending:                                   # buckets were reduced during the backward
+            for h in self._pending:
+                h.wait()
+            self._pending = []
+            scale = 1.0 / self._ddp_world()
+        else:
+            scale = allreduce_sum_flat(self.G, self.pg)
         ops.sgd_step(self.P, self.G, self.lr, self.wd, scale)
         self._refresh_transposed()

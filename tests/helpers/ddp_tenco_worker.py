@@ -1,0 +1,35 @@
+"""worker of tests/test_gpu_ddp.py: one DDP step of the TCN trainer, one video per rank (both ranks on cuda:0, gloo transport)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+import torch.distributed as dist
+from computervision_codes_amd import shapes, synth
+from computervision_codes_amd.tenco_train import TencoTrainer
+
+CFG = dict(num_layers_PG=3, num_layers_R=2, num_R=3, num_f_maps=64, dim=32)
+
+
+def video(rank, T=37):
+    x = synth.synthetic_features(T, CFG["dim"], seed=200 + rank)
+    labels = {s: torch.from_numpy((synth.uniform01(300 + rank, i, T * k) < 0.1).reshape(T, k).astype(np.int64))
+              for i, (s, k) in enumerate((("", 100), ("_i", 6), ("_v", 10), ("_t", 15)))}
+    return x, labels
+
+
+def trainer():
+    sd = synth.fill_from_shapes(shapes.tenco_shapes(CFG["num_layers_PG"], CFG["num_layers_R"], CFG["num_R"], CFG["num_f_maps"], CFG["dim"], 100, fpn=True), seed=8)
+    return TencoTrainer(CFG["num_layers_PG"], CFG["num_layers_R"], CFG["num_R"], CFG["num_f_maps"], CFG["dim"], lr=0.05, weight_decay=1e-5).load_state_dict(sd)
+
+
+if __name__ == "__main__":
+    out_dir = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    tr = trainer()
+    x, labels = video(rank)
+    tr.train_step(x.cuda(), labels)
+    if rank == 0:
+        torch.save(tr.state_dict(), os.path.join(out_dir, "ddp_tenco.pth"))
+    dist.barrier()
+    dist.destroy_process_group()
