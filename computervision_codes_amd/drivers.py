@@ -9,8 +9,7 @@ import argparse
 import os
 import pickle
 import time
-import types
-from typing import Dict, List
+from typing import Dict
 
 import numpy as np
 import torch

@@ -7,7 +7,7 @@ single pickle the temporal stage reads.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Iterable, List, Mapping, Sequence
+from typing import Callable, Dict, List, Mapping, Sequence
 
 import numpy as np
 import torch

@@ -12,7 +12,7 @@
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Sequence
 
 import torch
 
@@ -166,8 +166,7 @@ class SpatialCnnTrainer:
                             u.phase_w[(ph, pw)] = (packed, len(sel[ph]), len(sel[pw]))
                         else:                                                             # in place: captured graphs keep the address
                             u.phase_w[(ph, pw)][0].copy_(packed)
-        for name, (w, b, gw, gb, co, ci) in self.lin.items():
-            pass   # linear data gradients use transpose_pack on the fly (small)
+        # (the linear layers' data gradients transpose their small weights on the fly in _linear_bwd)
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         out = dict(self._extra)

@@ -13,7 +13,7 @@ Per Swin block (`swin_transformer.py:234-271`): 7 launches --
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 

@@ -12,7 +12,7 @@ dilated k3 conv + bias + ReLU, then 1x1 conv + bias + residual.  The four 1x1 he
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import torch
 
