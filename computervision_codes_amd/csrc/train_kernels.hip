@@ -17,7 +17,9 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // time in chunks of 32 rows; wave w owns output rows [16w, 16w+16) x 64 columns.
 __global__ __launch_bounds__(256) void wgrad_conv1d_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                float* __restrict__ dw, int B, int T, int Cout, int Cin, int taps,
-                                                               int dil, int pad, int Kpad, int accumulate) {
+                                                               int dil, int pad, int Kpad, int accumulate, long long rows_per_split) {
+    // gridDim.z > 1: the time range is split over workgroups that add their partial tile with fp32 atomics (dW zeroed by the host
+    // wrapper unless accumulating) -- a 512 x 1536 weight has only 192 tiles, one per CU with nothing to overlap its load latency
     constexpr int KT = 32, LDP = 68;  // 64 columns + 4 pad floats: the 4 k-rows of a fragment read hit distinct banks
     __shared__ __attribute__((aligned(16))) float sdy[KT * LDP];
     __shared__ __attribute__((aligned(16))) float sx[KT * LDP];
@@ -33,12 +35,14 @@ __global__ __launch_bounds__(256) void wgrad_conv1d_f32_kernel(const float* __re
     f32x4 acc[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const long long M = (long long)B * T;
-    for (long long m0 = 0; m0 < M; m0 += KT) {
+    const long long Mall = (long long)B * T;
+    const long long mb = (long long)blockIdx.z * rows_per_split;
+    const long long M = mb + rows_per_split < Mall ? mb + rows_per_split : Mall;
+    float4 ry[2], rx[2];
+    auto fetch = [&](long long m0) {   // the next chunk's loads fly while the current chunk runs its MFMAs
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = sr + 16 * i;
-            const long long m = m0 + r;
+            const long long m = m0 + sr + 16 * i;
             float4 vy = make_float4(0, 0, 0, 0), vx = make_float4(0, 0, 0, 0);
             if (m < M) {
                 if (co0 + sc < Cout) vy = *(const float4*)(dy + m * Cout + co0 + sc);   // Cout % 4 == 0 (host check)
@@ -46,10 +50,20 @@ __global__ __launch_bounds__(256) void wgrad_conv1d_f32_kernel(const float* __re
                 const int ts = t + shift;
                 if (xcol_ok && (unsigned)ts < (unsigned)T) vx = *(const float4*)(x + ((long long)b * T + ts) * Cin + xci);
             }
-            *(float4*)(sdy + r * LDP + sc) = vy;
-            *(float4*)(sx + r * LDP + sc) = vx;
+            ry[i] = vy;
+            rx[i] = vx;
+        }
+    };
+    fetch(mb);
+    for (long long m0 = mb; m0 < M; m0 += KT) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = sr + 16 * i;
+            *(float4*)(sdy + r * LDP + sc) = ry[i];
+            *(float4*)(sx + r * LDP + sc) = rx[i];
         }
         __syncthreads();
+        if (m0 + KT < M) fetch(m0 + KT);
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {
             const int row = kk * 4 + (lane >> 4);
@@ -72,7 +86,8 @@ __global__ __launch_bounds__(256) void wgrad_conv1d_f32_kernel(const float* __re
             const int co = co0 + wave * 16 + (lane >> 4) * 4 + e;
             if (co >= Cout) continue;
             float* p = dw + (long long)co * Kpad + k;
-            *p = accumulate ? *p + acc[n][e] : acc[n][e];
+            if (gridDim.z > 1) atomicAdd(p, acc[n][e]);
+            else *p = accumulate ? *p + acc[n][e] : acc[n][e];
         }
     }
 }
@@ -83,9 +98,18 @@ extern "C" int mt4_wgrad_conv1d_f32(const float* dy, const float* x, float* dw_p
     if (!dy || !x || !dw_packed || B <= 0 || T <= 0 || Cout <= 0 || Cin <= 0 || taps <= 0 || dil <= 0 || pad < 0) return MT4_EINVAL;
     if (Cin % 4 || Cout % 4 || (((uintptr_t)dy | (uintptr_t)x) & 15)) return MT4_EALIGN;
     const int Kpad = (int)mt4_conv_packed_k(Cin, 1, taps, MT4_F32);
-    const dim3 grid(cdiv(Kpad, 64), cdiv(Cout, 64));
-    hipLaunchKernelGGL(wgrad_conv1d_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, dw_packed, B, T, Cout, Cin, taps, dil, pad,
-                       Kpad, accumulate);
+    const long long M = (long long)B * T;
+    const int tiles = cdiv(Kpad, 64) * cdiv(Cout, 64);
+    long long splits = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU in total
+    const long long max_splits = (M + 255) / 256;              // at least 256 rows per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const long long rps = ((M + splits - 1) / splits + 31) / 32 * 32;
+    splits = (M + rps - 1) / rps;
+    hipStream_t s = (hipStream_t)stream;
+    if (splits > 1 && !accumulate && hipMemsetAsync(dw_packed, 0, (size_t)Cout * Kpad * sizeof(float), s) != hipSuccess) return mt4_check_launch();
+    const dim3 grid(cdiv(Kpad, 64), cdiv(Cout, 64), (unsigned)splits);
+    hipLaunchKernelGGL(wgrad_conv1d_f32_kernel, grid, dim3(256), 0, s, dy, x, dw_packed, B, T, Cout, Cin, taps, dil, pad, Kpad, accumulate, rps);
     return mt4_check_launch();
 }
 
