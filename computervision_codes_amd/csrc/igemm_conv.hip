@@ -87,6 +87,8 @@ struct ConvK {
     unsigned x_bytes, w_bytes;  // buffer sizes for the LDS-DMA range check (FAST path; < 2 GiB)
     unsigned x_bias;            // (pad_h*W + pad_w)*Cin*esize: how far a padded corner reaches in front of x
     int w_row_bytes;        // nsteps*128
+    int nt_epi;             // residual rows are loaded and bf16 output rows stored non-temporally (each is touched once by this launch;
+                            // same-box A/B on the ResNet-50 bench: +2.6 % frames/s).  MT4_NO_NT=1 switches it off
 };
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool FAST, bool OUT_F32>
@@ -391,7 +393,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
                     orow[it] = m;
                     if (a.res) {
                         const char* rp = a.res + ((long long)m * a.res_ld + n) * ES;
-                        if constexpr (RB == 16) rres[it] = *(const uint4*)rp;
+                        if constexpr (RB == 16) {   // read once: non-temporal
+                            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                            if (a.nt_epi) { const u32x4 t = __builtin_nontemporal_load((const u32x4*)rp); rres[it] = make_uint4(t.x, t.y, t.z, t.w); }
+                            else rres[it] = *(const uint4*)rp;
+                        }
                         else { const uint2 r2 = *(const uint2*)rp; rres[it] = make_uint4(r2.x, r2.y, 0, 0); }
                     }
                 }
@@ -454,8 +460,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
                 if constexpr (OUT_F32) {
                     *(float4*)(a.y + o * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
-                    *(uint4*)(a.y + o * 2) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                                        pack_bf16x2(v[6], v[7]));
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                    if (a.nt_epi) __builtin_nontemporal_store(ov, (u32x4*)(a.y + o * 2));
+                    else *(uint4*)(a.y + o * 2) = make_uint4(ov.x, ov.y, ov.z, ov.w);
                 }
             }
         }
@@ -515,6 +523,7 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     ConvK kk = k;
     kk.n_tiles = cdiv(k.Cout, BN);
     kk.total_tiles = m_tiles * kk.n_tiles;
+    kk.nt_epi = getenv("MT4_NO_NT") == nullptr ? 1 : 0;
     // LDS: two operand stages, or ONE when the whole K fits a single step (then only the epilogue staging may need
     // more than a stage): the short-K layers are memory-bound and want as many workgroups per CU as possible
     constexpr int stage = (BM + BN) * 128;
