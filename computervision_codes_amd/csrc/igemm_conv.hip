@@ -593,10 +593,10 @@ int auto_tile(int M, int N, int nsteps, int es) {
     // 8-wave 256-row tiles (bf16, profiles/r01_tile_tuning_8wave.txt): one workgroup per CU with the same 2 waves per SIMD, but
     // 0.5-0.75x the operand bytes per FLOP through L2 -> LDS-DMA, whose issue cost is what the K-loop waits on
     if (es == 2 && N >= 256) {
-        if (nsteps == 1 && tiles(13) >= fill) return 13;
-        if (nsteps >= 2 && tiles(15) >= 190) return 17;
+        if (nsteps == 1 && tiles(13) >= fill) { static const int t1 = getenv("MT4_TILE1STEP") ? atoi(getenv("MT4_TILE1STEP")) : 13; return t1; }
+        if (nsteps >= 2 && tiles(15) >= 190) { static const int t256 = getenv("MT4_TILE256") ? atoi(getenv("MT4_TILE256")) : 17; return t256; }
     }
-    if (es == 2 && N > 64 && N <= 128 && nsteps >= 4 && tiles(19) >= 8 * fill) return 19;   // 16-wave 256x128, 3 stages; many rounds: small tail
+    if (es == 2 && N > 64 && N <= 128 && nsteps >= 4 && tiles(19) >= 8 * fill) { static const int t128 = getenv("MT4_TILE128") ? atoi(getenv("MT4_TILE128")) : 19; if (t128) return t128; }   // 16-wave 256x128, 3 stages; many rounds: small tail
     if (nsteps == 1 && tiles(3) >= 4 * fill) return 3;   // single K-step: smallest footprint, most workgroups per CU
     if (N > 64) {
         if (nsteps >= 4 && tiles(1) >= fill) return 1;
