@@ -33,6 +33,7 @@ class ConvDesc(C.Structure):
         ("dil_h", C.c_int32), ("dil_w", C.c_int32),
         ("relu", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile", C.c_int32),
         ("out_row_map_len", C.c_int32), ("y_ld", C.c_int32), ("res_ld", C.c_int32), ("out_rows_per_image", C.c_int32),
+        ("x_pixel_stride", C.c_int32),
     ]
 
 
@@ -50,6 +51,7 @@ SIGNATURES = {
     "mt4_pack_conv_weight": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mt4_pack_stem_weight": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "mt4_preprocess_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _FLOAT3, _FLOAT3, _i32, _vp]),
+    "mt4_preprocess_u8_s2d": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _FLOAT3, _FLOAT3, _vp]),
     "mt4_pad_nchw_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_resize_pass_u8": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mt4_maxpool3x3s2_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

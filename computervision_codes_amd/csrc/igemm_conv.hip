@@ -83,7 +83,8 @@ struct ConvK {
     int y_ld, res_ld;    // row pitch (elements) of y / residual; Cout when dense
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, sh, sw, ph, pw, dh, dw, relu;  // relu: 0 none, 1 ReLU, 2 GELU(erf)
     int M, HoWo, CPT, SPT, taps, nsteps, n_tiles, total_tiles;
-    long long x_img_bytes;  // H*W*Cin*esize
+    long long x_img_bytes;  // H*W*pix_bytes
+    int pix_bytes;          // bytes between neighbouring pixels of x: Cin*esize, or less when a K-row spans several pixels (x_pixel_stride)
     unsigned x_bytes, w_bytes;  // buffer sizes for the LDS-DMA range check (FAST path; < 2 GiB)
     unsigned x_bias;            // (pad_h*W + pad_w)*Cin*esize: how far a padded corner reaches in front of x
     int w_row_bytes;        // nsteps*128
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
                 const int wo = rem - ho * a.Wo;
                 hi0 = ho * a.sh - a.ph;
                 wi0 = wo * a.sw - a.pw;
-                base = (long long)b * a.x_img_bytes + (long long)(hi0 * a.W + wi0) * (a.Cin * ES);
+                base = (long long)b * a.x_img_bytes + (long long)(hi0 * a.W + wi0) * a.pix_bytes;
             }
             xoff[i] = (int)base + gch * 16 + (int)a.x_bias;   // >= 0
             if (ok) {
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
         }
         int f_kh = 0, f_kw = 0, f_cs = 0;
         auto issue = [&](int step, int stage) {
-            const int delta = (f_kh * a.dh * a.W + f_kw * a.dw) * (a.Cin * ES) + f_cs * 128;   // wave-uniform
+            const int delta = (f_kh * a.dh * a.W + f_kw * a.dw) * a.pix_bytes + f_cs * 128;   // wave-uniform
             const unsigned bits = (hmask >> f_kh) & (wmask >> f_kw);   // bit 8*i: row i valid for this tap
             if (++f_cs == a.SPT) {
                 f_cs = 0;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
                 const int hi = px_hi0[i] + dhi, wi = px_wi0[i] + dwi;
                 const bool ok = tap_ok && px_ok[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (ok) v = *(const uint4*)(px_base[i] + (long long)(hi * a.W + wi) * (a.Cin * ES) + choff);
+                if (ok) v = *(const uint4*)(px_base[i] + (long long)(hi * a.W + wi) * a.pix_bytes + choff);
                 stg[i] = v;
             }
 #pragma unroll
@@ -681,11 +682,17 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     k.taps = d->KH * d->KW;
     k.nsteps = cdiv(k.taps * k.CPT, 8);
     k.w_row_bytes = k.nsteps * 128;
-    k.x_img_bytes = (long long)k.H * k.W * d->Cin * es;
-    const long long xb = (long long)d->B * d->H * d->W * d->Cin * es, wb = (long long)d->Cout * k.w_row_bytes;
+    // x_pixel_stride (elements, 0 = Cin): a K-row of Cin elements may span several pixels of a narrower image -- the ResNet stem on
+    // the space-to-depth frame reads 4 pixels x 16 channels = one 128-byte run per kernel row (overlapping between neighbouring outputs)
+    const int pix = (d->x_pixel_stride > 0 ? d->x_pixel_stride : d->Cin) * es;
+    if (pix % 16 != 0 || pix > d->Cin * es) return MT4_EALIGN;
+    if (pix != d->Cin * es && (d->KW != 1 || d->pad_w != 0 || d->pad_h != 0)) return MT4_EUNSUPPORTED;
+    k.pix_bytes = pix;
+    k.x_img_bytes = (long long)k.H * k.W * pix;
+    const long long xb = (long long)d->B * d->H * d->W * pix, wb = (long long)d->Cout * k.w_row_bytes;
     // FAST = LDS-DMA staging: whole 128-byte K-steps per tap, 32-bit buffer offsets, one validity bit per kh / kw
     const bool fast = (k.CPT % 8) == 0 && xb < 0x70000000LL && wb < 0x7fffffffLL && d->KH <= 8 && d->KW <= 8;
-    k.x_bias = (unsigned)(((long long)d->pad_h * d->W + d->pad_w) * d->Cin * es);
+    k.x_bias = (unsigned)(((long long)d->pad_h * d->W + d->pad_w) * pix);
     k.x_bytes = (unsigned)(xb < 0x7fffffffLL ? xb : 0);
     k.w_bytes = (unsigned)(wb < 0x7fffffffLL ? wb : 0);
     k.SPT = fast ? k.CPT / 8 : 1;

@@ -81,6 +81,50 @@ extern "C" int mt4_pad_nchw_f32(const float* x, void* out, int32_t B, int32_t H,
     return stem_input_launch(x, out, B, H, W, nullptr, nullptr, dtype, false, (hipStream_t)stream);
 }
 
+// Space-to-depth form of the same input (bf16, even H and W): out [B][(H+6)/2][(W+6)/2][16], channel (dy*2+dx)*3 + c of pixel (y, x) =
+// normalised frame pixel (2y+dy-3, 2x+dx-3), zero outside the frame and in channels 12..15.  The 7x7/2 stem is then a 4x4/1 conv whose
+// kernel row is 4 pixels x 16 channels = ONE contiguous 128-byte run: it goes through the LDS-DMA path of mt4_conv_nhwc (x_pixel_stride).
+__global__ void stem_input_s2d_kernel(const uint8_t* __restrict__ in, u16* __restrict__ out, int B, int H, int W, int Hs, int Ws, float m0,
+                                      float m1, float m2, float s0, float s1, float s2) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one space-to-depth pixel (32 bytes) per thread
+    const long long total = (long long)B * Hs * Ws;
+    if (idx >= total) return;
+    const int xs = (int)(idx % Ws);
+    const long long t = idx / Ws;
+    const int ys = (int)(t % Hs);
+    const int b = (int)(t / Hs);
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int h = 2 * ys + dy - 3, w = 2 * xs + dx - 3;
+            if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+                const uint8_t* p = in + (((long long)b * H + h) * W + w) * 3;
+                v[(dy * 2 + dx) * 3 + 0] = ((float)p[0] / 255.0f - m0) / s0;
+                v[(dy * 2 + dx) * 3 + 1] = ((float)p[1] / 255.0f - m1) / s1;
+                v[(dy * 2 + dx) * 3 + 2] = ((float)p[2] / 255.0f - m2) / s2;
+            }
+        }
+    uint4* o = (uint4*)(out + idx * 16);
+    o[0] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    o[1] = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), 0u, 0u);
+}
+
+extern "C" int mt4_preprocess_u8_s2d(const uint8_t* frames, void* out, int32_t B, int32_t H, int32_t W, const float mean[3],
+                                     const float std[3], void* stream) {
+    mt4_clear_error();
+    if (!frames || !out || !mean || !std || B <= 0 || H <= 0 || W <= 0) return MT4_EINVAL;
+    if ((H | W) & 1) return MT4_EUNSUPPORTED;
+    const int Hs = (H + 6) / 2, Ws = (W + 6) / 2;
+    const long long total = (long long)B * Hs * Ws;
+    hipLaunchKernelGGL(stem_input_s2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frames, (u16*)out, B, H,
+                       W, Hs, Ws, mean[0], mean[1], mean[2], std[0], std[1], std[2]);
+    return mt4_check_launch();
+}
+
 // ------------------------------------------------------------------------------------------------ maxpool 3x3/2 pad 1
 template <typename T>
 __global__ void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {

@@ -66,11 +66,17 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
               residual: Optional[torch.Tensor] = None, relu: bool = False, out_dtype: Optional[torch.dtype] = None,
               out: Optional[torch.Tensor] = None, tile: int = 0, act: Optional[str] = None,
               out_row_map: Optional[torch.Tensor] = None, y_ld: int = 0, res_ld: int = 0, out_hw: Optional[Tuple[int, int]] = None,
-              out_rows_per_image: int = 0) -> torch.Tensor:
-    """y = act(conv(x, w) + bias [+ residual]); x [B,H,W,Cin] contiguous channels-last storage."""
+              out_rows_per_image: int = 0, run_pixels: int = 1) -> torch.Tensor:
+    """y = act(conv(x, w) + bias [+ residual]); x [B,H,W,Cin] contiguous channels-last storage.
+    run_pixels > 1: a tap reads a contiguous run of that many pixels (Cin_eff = run_pixels * x.shape[-1]; kw must be 1, no padding,
+    pass out_hw): the space-to-depth stem."""
     _need_cuda(x, w_packed, bias, residual)
     assert x.dim() == 4 and x.is_contiguous()
     b, h, w_, cin = x.shape
+    pix = 0
+    if run_pixels > 1:
+        assert kw == 1 and pad == (0, 0) and out_hw is not None
+        pix, cin = cin, cin * run_pixels
     cout = w_packed.shape[0]
     ho = conv_out_size(h, kh, stride[0], pad[0], dil[0])
     wo = conv_out_size(w_, kw, stride[1], pad[1], dil[1])
@@ -102,7 +108,7 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
                  out_row_map.data_ptr() if out_row_map is not None else None,
                  b, h, w_, cin, ho, wo, cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1],
                  act_code, dt_code(x.dtype), dt_code(od), tile, out_row_map.numel() if out_row_map is not None else 0, y_ld, res_ld,
-                 out_rows_per_image)
+                 out_rows_per_image, pix)
     check(lib.mt4_conv_nhwc(C.byref(d), _stream()), "mt4_conv_nhwc")
     return out
 
@@ -121,6 +127,33 @@ def preprocess_u8(frames: torch.Tensor, mean, std, dtype: torch.dtype) -> torch.
     check(lib.mt4_preprocess_u8(frames.data_ptr(), out.data_ptr(), b, h, w, _lib._FLOAT3(*mean), _lib._FLOAT3(*std),
                                 dt_code(dtype), _stream()), "mt4_preprocess_u8")
     return out
+
+
+def preprocess_u8_s2d(frames: torch.Tensor, mean, std) -> torch.Tensor:
+    """uint8 [B,H,W,3] (H, W even) -> normalised bf16 space-to-depth image of the 3-padded frame: [B,(H+6)/2,(W+6)/2,16] with channel
+    (dy*2+dx)*3 + c = pixel (2y+dy-3, 2x+dx-3), channels 12..15 zero (`mt4_preprocess_u8_s2d`): a 7x7/2 kernel row becomes 4 pixels x
+    16 channels = one 128-byte run"""
+    _need_cuda(frames)
+    assert frames.dtype == torch.uint8 and frames.is_contiguous() and frames.shape[-1] == 3
+    b, h, w, _ = frames.shape
+    assert h % 2 == 0 and w % 2 == 0
+    out = torch.empty((b, (h + 6) // 2, (w + 6) // 2, 16), dtype=torch.bfloat16, device=frames.device)
+    check(lib.mt4_preprocess_u8_s2d(frames.data_ptr(), out.data_ptr(), b, h, w, _lib._FLOAT3(*mean), _lib._FLOAT3(*std), _stream()),
+          "mt4_preprocess_u8_s2d")
+    return out
+
+
+def stem_s2d_weight(w_oihw: torch.Tensor, scale: Optional[torch.Tensor]) -> torch.Tensor:
+    """ResNet stem weight [64,3,7,7] -> packed bf16 rows for the space-to-depth stem: a 4x1 kernel over runs of 4 pixels x 16 channels,
+    element kw'*16 + (dy*2+dx)*3 + c of kernel row kh' = w[c][2kh'+dy][2kw'+dx] (zero beyond the 7x7 support)"""
+    co = w_oihw.shape[0]
+    w8 = torch.zeros((co, 3, 8, 8), dtype=torch.float32, device=w_oihw.device)
+    w8[:, :, :7, :7] = w_oihw.float()
+    w8 = w8.view(co, 3, 4, 2, 4, 2)                                  # [co][c][kh'][dy][kw'][dx]
+    run = torch.zeros((co, 4, 4, 16), dtype=torch.float32, device=w_oihw.device)   # [co][kh'][kw'][(dy,dx,c) + 4 zero]
+    run[..., :12] = w8.permute(0, 2, 4, 3, 5, 1).reshape(co, 4, 4, 12)
+    oihw = run.view(co, 4, 64).permute(0, 2, 1).reshape(co, 64, 4, 1).contiguous()  # "Cin" = 64-element run, KH = 4, KW = 1
+    return pack_conv_weight(oihw, scale, torch.bfloat16)
 
 
 def pad_nchw(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

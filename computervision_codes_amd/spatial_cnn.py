@@ -81,6 +81,11 @@ class VideoNas:
         pre = "basemodel.basemodel."
         p: Dict[str, object] = {}
         p["stem"] = self._fold(pre + "conv1", pre + "bn1", stem=True)
+        import os
+        if self.dtype == torch.bfloat16 and not os.environ.get("MT4_NO_S2D"):   # space-to-depth stem (even frame sizes): one 128-byte run per kernel row, LDS-DMA path
+            sd, dev = self._sd, self.device
+            scale = (sd[pre + "bn1.weight"].double() / torch.sqrt(sd[pre + "bn1.running_var"].double() + 1e-5)).float().to(dev)
+            p["stem_s2d"] = ops.stem_s2d_weight(sd[pre + "conv1.weight"].float().to(dev), scale)
         bottleneck = self.network == "resnet50"
         for li, n in enumerate(_DEPTHS[self.network], start=1):
             for b in range(n):
@@ -192,6 +197,14 @@ class VideoNas:
 
     __call__ = forward
 
+    def _trunk_u8(self, frames_u8: torch.Tensor) -> torch.Tensor:
+        _, h, w, _ = frames_u8.shape
+        if "stem_s2d" in self._p and h % 2 == 0 and w % 2 == 0:
+            xs = ops.preprocess_u8_s2d(frames_u8, IMAGENET_MEAN, IMAGENET_STD)
+            y = ops.conv_nhwc(xs, self._p["stem_s2d"], self._p["stem"][1], kh=4, kw=1, relu=True, run_pixels=4, out_hw=(h // 2, w // 2))
+            return ops.global_avgpool(self._layers(ops.maxpool3x3s2(y), 1, 4))
+        return self.trunk_from_padded(ops.preprocess_u8(frames_u8, IMAGENET_MEAN, IMAGENET_STD, self.dtype), h, w)
+
     def extract_u8(self, frames_u8: torch.Tensor, streams: int = 1):
         """Fused input path: uint8 frames [B,H,W,3] -> (ToTensor+Normalize on the GPU) -> forward.
         streams > 1: the batch is cut into that many contiguous parts which run on their own HIP streams -- frames are independent,
@@ -199,7 +212,7 @@ class VideoNas:
         the parts' results are byte-identical to the single-stream call."""
         _, h, w, _ = frames_u8.shape
         if streams <= 1 or frames_u8.shape[0] < 2 * streams:
-            return self._finish(self.trunk_from_padded(ops.preprocess_u8(frames_u8, IMAGENET_MEAN, IMAGENET_STD, self.dtype), h, w))
+            return self._finish(self._trunk_u8(frames_u8))
         main = torch.cuda.current_stream()
         if len(self._streams) < streams:
             self._streams += [torch.cuda.Stream() for _ in range(streams - len(self._streams))]
@@ -211,7 +224,7 @@ class VideoNas:
             st.wait_stream(main)
             with torch.cuda.stream(st):
                 part = frames_u8[cuts[i]:cuts[i + 1]]
-                f = self.trunk_from_padded(ops.preprocess_u8(part, IMAGENET_MEAN, IMAGENET_STD, self.dtype), h, w)
+                f = self._trunk_u8(part)
             feats.append(f)
         for i in range(streams):
             main.wait_stream(self._streams[i])

@@ -77,6 +77,9 @@ typedef struct mt4_conv_desc {
     int32_t res_ld;     /* row pitch of residual in elements (0 = Cout) */
     int32_t out_rows_per_image; /* with out_row_map: rows per image on the OUTPUT side (0 = out_row_map_len); > len scatters
                                    the result into a larger image (sub-pixel phases of a strided conv's data gradient) */
+    int32_t x_pixel_stride;     /* elements between neighbouring pixels of x (0 = Cin).  < Cin: the Cin elements of a tap are a
+                                   contiguous run over several pixels of a narrower image (KW = 1, no padding; the caller pads x so
+                                   that every run stays inside it): the ResNet stem on the space-to-depth frame, 4 x 16 channels */
 } mt4_conv_desc;
 
 int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream);
@@ -103,6 +106,11 @@ int mt4_preprocess_u8(const uint8_t* frames, void* out, int32_t B, int32_t H, in
                       const float std[3], int32_t dtype, void* stream);
 /* same from already-normalised float32 NCHW [B][3][H][W] (the reference's module-call boundary) */
 int mt4_pad_nchw_f32(const float* x, void* out, int32_t B, int32_t H, int32_t W, int32_t dtype, void* stream);
+/* The same frames as a normalised bf16 space-to-depth image of the 3-padded frame, [B][(H+6)/2][(W+6)/2][16] (H, W even): channel
+ * (dy*2+dx)*3 + c of pixel (y, x) = frame pixel (2y+dy-3, 2x+dx-3), channels 12..15 zero.  The 7x7/2 stem (resnet.py:145) becomes a
+ * 4x1 kernel over contiguous runs of 4 pixels (mt4_conv_desc.x_pixel_stride = 16, Cin = 64) and runs through the LDS-DMA path. */
+int mt4_preprocess_u8_s2d(const uint8_t* frames, void* out, int32_t B, int32_t H, int32_t W, const float mean[3], const float std[3],
+                          void* stream);
 
 /* One separable pass of Pillow's 8-bit resize (`Image.resize(size, BILINEAR)` = `transforms.Resize((256,448))`,
  * Spatial_cnn/dataloader.py:155-159, Spatial_transformer likewise): out = clip8((2^21 + sum_i in[lo+i] * coeffs[o][i]) >> 22).

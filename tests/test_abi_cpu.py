@@ -54,4 +54,4 @@ def test_ops_refuse_cpu_tensors():
 def test_struct_layout_matches_header():
     from computervision_codes_amd import _lib
     # 6 pointers + 23 int32 (+4 tail padding)
-    assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 24 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 24 * 4   # 6 pointers + 24 int32 fields

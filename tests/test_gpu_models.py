@@ -242,3 +242,22 @@ def test_spatial_cnn_multi_stream_extract_is_byte_identical(cuda):
     for ns in (2, 3):
         b = m.extract_u8(frames, streams=ns)
         assert torch.equal(a[3][0], b[3][0]) and all(torch.equal(x[1], y[1]) for x, y in zip(a, b))
+
+
+def test_space_to_depth_stem_equals_padded_stem(cuda):
+    """bf16 throughput path: the stem on the space-to-depth frame (4x1 kernel over 128-byte runs, LDS-DMA staging) against the stem on
+    the padded pixel-pair frame (register staging): same products, another summation order -> equal to bf16 rounding of the output"""
+    from computervision_codes_amd import ops
+    from computervision_codes_amd.synth import IMAGENET_MEAN, IMAGENET_STD
+    _, cfg = load_golden("cnn_resnet50_224")
+    m = _cnn_model(cfg, torch.bfloat16)
+    for (h, w) in ((224, 224), (64, 96), (256, 448)):
+        fr = synth.synthetic_frames(3, h, w, seed=h).to(cuda)
+        xs = ops.preprocess_u8_s2d(fr, IMAGENET_MEAN, IMAGENET_STD)
+        y_new = ops.conv_nhwc(xs, m._p["stem_s2d"], m._p["stem"][1], kh=4, kw=1, relu=True, run_pixels=4, out_hw=(h // 2, w // 2))
+        xp = ops.preprocess_u8(fr, IMAGENET_MEAN, IMAGENET_STD, torch.bfloat16)
+        b, hp, wp_, _ = xp.shape
+        y_old = torch.empty_like(y_new)
+        ops.conv_nhwc(xp.view(b, hp, wp_ // 2, 8), m._p["stem"][0], m._p["stem"][1], kh=7, kw=4, stride=(2, 1), relu=True, out=y_old)
+        d = (y_new.float() - y_old.float()).abs().max().item()
+        assert d <= 2 ** -7 * max(1.0, y_old.float().abs().max().item()), (h, w, d)
