@@ -512,10 +512,11 @@ struct TileCfg {
 // tile ids are 1-based in the C-ABI
 // ids 1-6: two operand stages; 7-12: deeper rings (3 for the 128-wide tiles, 4 for the small ones)
 // ids 13-16: 8-wave workgroups (one per CU): 256x128 with 2 / 3 stages, 256x256, 128x256 with 3 stages
+// id 20: 256x64 for the 64-channel layers (8 waves)
 // ids 17-19: 16-wave workgroups (four waves per SIMD, 64x64 / 64x32 wave tiles): 256x256, 256x128 with 2 / 3 stages
 constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {64, 128}, {32, 64}, {32, 32},
                               {128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}, {128, 64},
-                              {256, 128}, {256, 128}, {256, 256}, {128, 256}, {256, 256}, {256, 128}, {256, 128}};
+                              {256, 128}, {256, 128}, {256, 256}, {128, 256}, {256, 256}, {256, 128}, {256, 128}, {256, 64}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <typename T, int BM, int BN, int WM_, int WN_, int STAGES, bool OUT_F32>
@@ -581,6 +582,7 @@ int launch_dtype(const ConvK& k, int tile, bool fast, hipStream_t s) {
         case 17: return launch_tile<T, 256, 256, 4, 4, 2, OUT_F32>(k, fast, s);
         case 18: return launch_tile<T, 256, 128, 4, 4, 2, OUT_F32>(k, fast, s);
         case 19: return launch_tile<T, 256, 128, 4, 4, 3, OUT_F32>(k, fast, s);
+        case 20: return launch_tile<T, 256, 64, 4, 2, 2, OUT_F32>(k, fast, s);
     }
     return MT4_EINVAL;
 }
@@ -604,6 +606,8 @@ int auto_tile(int M, int N, int nsteps, int es) {
         if (tiles(4) >= fill) return 4;
         if (tiles(1) >= fill) return 1;
     } else if (N > 32) {
+        // 64-channel layers at many rounds: 256 pixels x 64 channels, 8 waves (+2.8 % frames/s, same-box A/B; MT4_TILE64=0 disables)
+        { static const int t64 = getenv("MT4_TILE64") ? atoi(getenv("MT4_TILE64")) : 20; if (t64 && es == 2 && tiles(20) >= 8 * fill) return t64; }
         if (tiles(2) >= fill) return 2;
         if (tiles(3) >= fill) return 3;
     }

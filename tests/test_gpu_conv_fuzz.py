@@ -21,7 +21,7 @@ def _case(rng):
     if (h + 2 * ph - dh * (k - 1) - 1) < 0 or (w + 2 * pw - dw * (kw - 1) - 1) < 0:
         ph, pw = dh * (k - 1), dw * (kw - 1)
     return dict(b=b, h=h, w=w, cin=cin, cout=cout, kh=k, kw=kw, s=(sh, sw), p=(ph, pw), d=(dh, dw),
-                tile=int(rng.integers(0, 20)), res=bool(rng.integers(0, 2)), act=str(rng.choice(["none", "relu", "gelu"])))
+                tile=int(rng.integers(0, 21)), res=bool(rng.integers(0, 2)), act=str(rng.choice(["none", "relu", "gelu"])))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -61,7 +61,7 @@ def test_conv_nhwc_auto_tile(cuda, shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", list(range(1, 20)))
+@pytest.mark.parametrize("tile", list(range(1, 21)))
 def test_conv_nhwc_every_tile(cuda, tile, dtype):
     # M = 2*13*11 = 286 (ragged vs every BM), N = 96 (ragged vs 64/128), both K modes
     _conv_case(cuda, 2, 13, 11, 64, 96, 3, 3, (1, 1), (1, 1), (1, 1), dtype, relu=False, use_res=False, tile=tile, seed=5)
