@@ -599,8 +599,9 @@ int auto_tile(int M, int N, int nsteps, int es) {
         if (nsteps == 1 && tiles(13) >= fill) { static const int t1 = getenv("MT4_TILE1STEP") ? atoi(getenv("MT4_TILE1STEP")) : 13; return t1; }
         if (nsteps >= 2 && tiles(15) >= 190) { static const int t256 = getenv("MT4_TILE256") ? atoi(getenv("MT4_TILE256")) : 17; return t256; }
     }
+    if (es == 2 && N > 64 && N <= 128 && nsteps < 4 && tiles(20) >= 8 * fill) { static const int t128s = getenv("MT4_TILE128S") ? atoi(getenv("MT4_TILE128S")) : 20; if (t128s) return t128s; }   // short K: 256x64 (Swin stage-1 proj)
     if (es == 2 && N > 64 && N <= 128 && nsteps >= 4 && tiles(19) >= 8 * fill) { static const int t128 = getenv("MT4_TILE128") ? atoi(getenv("MT4_TILE128")) : 19; if (t128) return t128; }   // 16-wave 256x128, 3 stages; many rounds: small tail
-    if (nsteps == 1 && tiles(3) >= 4 * fill) return 3;   // single K-step: smallest footprint, most workgroups per CU
+    if (nsteps == 1 && tiles(3) >= 4 * fill) { static const int t1s = getenv("MT4_TILE1STEP_SMALL") ? atoi(getenv("MT4_TILE1STEP_SMALL")) : 3; return t1s; }   // single K-step: smallest footprint, most workgroups per CU
     if (N > 64) {
         if (nsteps >= 4 && tiles(1) >= fill) return 1;
         if (tiles(4) >= fill) return 4;
