@@ -595,7 +595,7 @@ int auto_tile(int M, int N, int nsteps, int es) {
     const long long fill = 256;  // one workgroup per CU
     // 8-wave 256-row tiles (bf16, profiles/r01_tile_tuning_8wave.txt): one workgroup per CU with the same 2 waves per SIMD, but
     // 0.5-0.75x the operand bytes per FLOP through L2 -> LDS-DMA, whose issue cost is what the K-loop waits on
-    if (es == 2 && N >= 256) {
+    if (es == 2 && N >= 256) {   // (fp32 launches are bound by the fp32 MFMA rate: the same tiles change nothing there, same-box A/B)
         if (nsteps == 1 && tiles(13) >= fill) { static const int t1 = getenv("MT4_TILE1STEP") ? atoi(getenv("MT4_TILE1STEP")) : 13; return t1; }
         if (nsteps >= 2 && tiles(15) >= 190) { static const int t256 = getenv("MT4_TILE256") ? atoi(getenv("MT4_TILE256")) : 17; return t256; }
     }
