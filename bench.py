@@ -244,6 +244,21 @@ def swin_bench(dev, batch=128):
     return out
 
 
+def parity_mode_bench(dev, network, h, w, batch=256):
+    """the same extractor in the fp32 parity mode (fp32 I/O, exact-fp32 MFMA chain: what the 1e-3 logit parity is claimed for)"""
+    from computervision_codes_amd import shapes, synth
+    from computervision_codes_amd.spatial_cnn import VideoNas
+    args = types.SimpleNamespace(network=network, loss_type="all", student_dim=shapes.resnet_feat_dim(network), teacher_dim=1536, train=False)
+    m = VideoNas(args=args, dtype=torch.float32, device=str(dev)).eval()
+    m.load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes(network), seed=1234))
+    frames = device_frames(batch, h, w, 99, dev)
+    ms = _time_call(lambda: m.extract_u8(frames), iters=5)
+    per_launch = time_conv_kernels(m, frames)
+    tf = conv_flops_per_frame(m, h, w) * batch / (sum(per_launch) * 1e-3) / 1e12
+    return dict(frames_per_s=round(batch / ms * 1e3, 1), ms_per_batch=round(ms, 3), batch=batch, dtype="f32",
+                conv_tflops=round(tf, 1), f32_mfma_frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
+
+
 def spatial_train_bench(dev):
     """BASELINE configs[4] on one GPU: the student distillation step (`Spatial_cnn/run.py -t`, fp32, batch 8 of 256x448 frames as in
     Scripts/train_fold1.sh) -- forward, hard+soft+KD losses, backward, SGD; hipGraph replay of forward+backward."""
@@ -365,6 +380,7 @@ def main():
             res["temporal"] = temporal_bench(dev, do_cpu=not a.no_cpu_baseline)
             res["swin_q2l"] = swin_bench(dev)
             res["spatial_train"] = spatial_train_bench(dev)
+            res["parity_mode_f32"] = parity_mode_bench(dev, a.network, a.height, a.width)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_spatial(a.network, a.height, a.width, 1234)
             res["gpu_over_cpu"] = round(fps / res["cpu_baseline"]["value"], 1)
