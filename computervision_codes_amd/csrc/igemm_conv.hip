@@ -246,9 +246,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
         auto issue = [&](int step, int stage) {
             const int delta = (f_kh * a.dh * a.W + f_kw * a.dw) * a.pix_bytes + f_cs * 128;   // wave-uniform
             const unsigned bits = (hmask >> f_kh) & (wmask >> f_kw);   // bit 8*i: row i valid for this tap
-            if (++f_cs == a.SPT) {
-                f_cs = 0;
-                if (++f_kw == a.KW) { f_kw = 0; ++f_kh; }
+            // K walk order: taps fastest, the 128-byte channel slice slowest (the packed weights are tap-major, so the weight K-step
+            // is tap*SPT + slice).  Consecutive K-steps then read the same cache lines of x shifted by one pixel / one image row
+            // and the re-read comes 1-3 steps later instead of SPT*taps later (+1.2 % frames/s, same-box A/B).
+            const int wstep = (f_kh * a.KW + f_kw) * a.SPT + f_cs;
+            if (++f_kw == a.KW) {
+                f_kw = 0;
+                if (++f_kh == a.KH) { f_kh = 0; ++f_cs; }
             }
             // (keep the K position in SGPRs: without this hipcc carries it in VGPRs and multiplies with v_mul_lo_u32)
             f_cs = __builtin_amdgcn_readfirstlane(f_cs);
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
 #pragma unroll
             for (int i = 0; i < NLD_X; ++i) vx[i] = ((bits >> (8 * i)) & 1u) ? (unsigned)xoff[i] : OOB;
             lds_dma16_group<NLD_X, RPP * 128>(rsx, vx, (unsigned)__builtin_amdgcn_readfirstlane(delta), dst);
-            lds_dma16_group<NLD_W, RPP * 128>(rsw, woff, (unsigned)__builtin_amdgcn_readfirstlane(step * 128), dst + BM * 128);
+            lds_dma16_group<NLD_W, RPP * 128>(rsw, woff, (unsigned)__builtin_amdgcn_readfirstlane(wstep * 128), dst + BM * 128);
         };
         // Ring of STAGES operand stages, DMA issued STAGES-1 K-steps ahead.  After computing step s the groups of steps
         // s+1 .. s+STAGES-1 are outstanding (fewer at the tail); only the OLDEST must have landed, so the wait leaves the
