@@ -321,10 +321,10 @@ extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* 
     int threads = ((Nq * cfgs[ci][1] + 63) / 64) * 64;
     if (threads > 256) threads = 256;
     // a launch that cannot fill the chip (one short sequence: MS-TCT's global block has T = 256 queries x 8 heads) takes 8 lanes per
-    // query and one wave per workgroup instead: 8x less serial work per lane and up to 32x more workgroups
+    // query instead: 8x less serial work per lane, 8x more workgroups (workgroup size: 64/128/256 threads within 2 %, A/B)
     if (hd <= 64 && (long long)cdiv(Nq, threads / cfgs[ci][1]) * H * B < 128) {   // (measured: 103 -> 72 us at hd 32, 94 -> 88 at hd 48; slower for hd >= 72)
         for (int i = 7; i < 12; ++i)
-            if (cfgs[i][0] * 8 >= hd) { ci = i; threads = 64; break; }
+            if (cfgs[i][0] * 8 >= hd) { static const int thr = getenv("MT4_ATT_THREADS") ? atoi(getenv("MT4_ATT_THREADS")) : 256; ci = i; threads = thr; break; }
     }
     const int DPL = cfgs[ci][0], LPQ = cfgs[ci][1];
     const int row = LPQ * (DPL + 4);
