@@ -166,6 +166,9 @@ def temporal_bench(dev, do_cpu):
         rec = dict(ms_per_video=round(lat, 4), ms_per_video_eager=round(eager, 4), T=c["T"], algorithmic_MB=round(alg_bytes / 1e6, 1),
                    hbm_frac=round(alg_bytes / (lat * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                    f32_mfma_frac=round(flops / (lat * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+        mb = VideoNas(args, 11, 10, c["num_R"], 512, c["dim"], 100, dtype=torch.bfloat16).eval().load_state_dict(sd)
+        gb = GraphedForward(lambda xx: mb(xx, False), [x])
+        rec["ms_per_video_bf16"] = round(_time_call(lambda: gb(x)), 4)   # throughput mode; the fp32 line above is the parity mode
         if do_cpu:
             from oracle import tenco as o_tenco
             xc = x.cpu()

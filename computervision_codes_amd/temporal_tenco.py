@@ -28,7 +28,10 @@ class VideoNas:
     """
 
     def __init__(self, args, num_layers_PG, num_layers_R, num_R, num_f_maps, dim, num_classes, num_i=6, num_v=10,
-                 num_t=15, device: str = "cuda"):
+                 num_t=15, device: str = "cuda", dtype: torch.dtype = torch.float32):
+        """dtype float32: the parity mode (exact-fp32 MFMA chain); bfloat16: throughput mode (bf16 weights / activations, fp32
+        accumulate and epilogue, fp32 logits)"""
+        self.dtype = dtype
         if getattr(args, "output", False) or getattr(args, "hier", False):
             raise NotImplementedError("--output / --hier are never set by the shipped scripts (Scripts/*.sh)")
         self.args = args
@@ -72,7 +75,7 @@ class VideoNas:
 
         def pk(name):  # Conv1d weight [Cout,Cin,k] -> OIHW [Cout,Cin,1,k] -> packed
             w = self._sd[name + ".weight"].to(dev)
-            p[name + ".w"] = ops.pack_conv_weight(w.unsqueeze(2), None, torch.float32)
+            p[name + ".w"] = ops.pack_conv_weight(w.unsqueeze(2), None, self.dtype)
             p[name + ".b"] = self._sd[name + ".bias"].to(dev).contiguous()
 
         stages = [("PG", self.num_layers_PG)] + [(f"Rs.{r}", self.num_layers_R) for r in range(self.num_R)]
@@ -87,7 +90,7 @@ class VideoNas:
             pk("fpn.latlayer1")
             w = torch.cat([self._sd[f"conv_out{s}.weight"] for s in ("", "_i", "_v", "_t")], 0).to(dev)
             b = torch.cat([self._sd[f"conv_out{s}.bias"] for s in ("", "_i", "_v", "_t")], 0).to(dev)
-            p["heads.w"] = ops.pack_conv_weight(w.unsqueeze(2), None, torch.float32)
+            p["heads.w"] = ops.pack_conv_weight(w.unsqueeze(2), None, self.dtype)
             p["heads.b"] = b.contiguous()
         self._p = p
 
@@ -115,7 +118,7 @@ class VideoNas:
             raise RuntimeError("load_state_dict first")
         assert x.dim() == 3 and x.shape[2] == self.D and x.dtype == torch.float32
         b, t, _ = x.shape
-        x4 = x.contiguous().view(b, 1, t, self.D)
+        x4 = x.contiguous().to(self.dtype).view(b, 1, t, self.D)
         f = self._stage(self._c1(x4, "PG.conv_1x1"), "PG", self.num_layers_PG)
         f_list = [f]
         out_list: List[torch.Tensor] = []
@@ -124,7 +127,7 @@ class VideoNas:
         out_t: List[torch.Tensor] = []
         as_ref = lambda y: y.view(b, t, -1).permute(0, 2, 1)  # [B,1,T,K] -> [B,K,T] view
         if not self.use_fpn:
-            out_list.append(as_ref(self._c1(f, "PG.conv_out")))
+            out_list.append(as_ref(ops.conv_nhwc(f, self._p["PG.conv_out.w"], self._p["PG.conv_out.b"], kh=1, kw=1, out_dtype=torch.float32)))
         # per-stage conv_out logits are computed and discarded by the reference (network.py:133,160): skipped
         for r in range(self.num_R):
             f = self._stage(f, f"Rs.{r}", self.num_layers_R)
@@ -137,7 +140,7 @@ class VideoNas:
             f_list = [p1, p2, p3, p4]
             k0, k1, k2, k3 = self.head_sizes
             for lvl in f_list:
-                y = as_ref(ops.conv_nhwc(lvl, self._p["heads.w"], self._p["heads.b"], kh=1, kw=1))
+                y = as_ref(ops.conv_nhwc(lvl, self._p["heads.w"], self._p["heads.b"], kh=1, kw=1, out_dtype=torch.float32))
                 out_list.append(y[:, :k0])
                 out_i.append(y[:, k0:k0 + k1])
                 out_v.append(y[:, k0 + k1:k0 + k1 + k2])
