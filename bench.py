@@ -355,8 +355,16 @@ def main():
                 traffic = rec["hbm_bytes_per_step"] * max(1, a.streams) if rec else None   # PMC figure is per stream part
             except Exception:
                 traffic = None
+        mfma_util = None   # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GPU cycles) of the same launches (tools/collect_mfma_util.py), offline like traffic
+        ufile = os.path.join(ROOT, "profiles", "mfma_util.json")
+        if os.path.exists(ufile):
+            try:
+                rec = json.load(open(ufile)).get(f"{a.network}_{a.dtype}_b{a.batch}_{a.height}x{a.width}")
+                mfma_util = rec["mfma_util"] if rec else None
+            except Exception:
+                mfma_util = None
         roofline = dict(bound="mfma", kernel="igemm_conv_kernel (all conv launches of one step)", achieved=round(achieved, 2),
-                        peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
+                        peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic, mfma_util_pmc=mfma_util,
                         launches_per_step=len(per_launch), conv_ms_per_step=round(conv_ms, 4),
                         gflop_per_frame=round(flops_frame / 1e9, 3), traffic_unit="HBM bytes per step (all conv launches)",
                         note="launch durations from a single-stream pass over one stream's part of the step (HIP events on the launch stream)")

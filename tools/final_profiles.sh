@@ -12,3 +12,7 @@ echo fetch done
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-temporal > gpurun_out/pmc_write.log 2>&1
 echo write done
 python tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 54 resnet50_bf16_b1336_224x224 gpurun_out/traffic.json
+rm -rf gpurun_out/pmc_mfma
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma -- python3 bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-temporal > gpurun_out/pmc_mfma.log 2>&1
+echo mfma done
+python tools/collect_mfma_util.py gpurun_out/pmc_mfma 54 resnet50_bf16_b1336_224x224 gpurun_out/mfma_util.json
