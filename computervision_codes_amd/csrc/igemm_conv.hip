@@ -217,8 +217,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
             const int mm = ok ? m : 0;
             int hi0 = 0, wi0 = 0;
             long long base;
-            if (a.HoWo == 1) {
-                base = (long long)mm * a.x_img_bytes;
+            if (a.HoWo == 1) {   // one output pixel per image (the pure-GEMM remap, or a padded kernel over a 1x1 image)
+                hi0 = -a.ph;
+                wi0 = -a.pw;
+                base = (long long)mm * a.x_img_bytes + (long long)(hi0 * a.W + wi0) * a.pix_bytes;
             } else {
                 const int b = mm / a.HoWo;
                 const int rem = mm - b * a.HoWo;
@@ -507,6 +509,211 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 patch kernel
+// 3x3 / stride 1 / pad 1 / dense NHWC bf16: the generic kernel above re-fetches the pixel tile for each of the 9 taps (9 x BM rows
+// through L2 -> LDS per 64-channel slice), and the K-loop of the N <= 128 layers waits on exactly that fill.  Here the INPUT PATCH
+// of the pixel tile is staged once per slice: output pixels are linear in (b, h, w) and so are input pixels (same H x W), so tap
+// (kh, kw) of tile row r is patch row r + kh*W + kw of the linear pixel range [m0 - W - 1, m0 + BM + W + 1).  A tap that leaves the
+// image (wraps to the neighbouring row / image in linear space) is zeroed on the pixel fragment: 9 validity bits per lane and
+// m-tile, one v_bfe + 8 v_and per m-tile and K-step.  Fill per slice: (BM + 2W + 2) + 9*BN rows instead of 9*(BM + BN).
+// Same K walk (slice outer, taps inner) and the same MFMA chain as the generic kernel: results are bit-identical.
+// Weight K-steps (BN rows x 128 B) run through a ring of WS stages, issued WS-1 steps ahead: a K-step of the narrow tiles is shorter
+// than the L2 -> LDS latency, so one step of prefetch distance leaves every step waiting for its weights.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WS>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_patch_kernel(const ConvK a, const int pra, const int npatch) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int NTH = NW * 64;
+    constexpr int RPP = NTH / 8;
+    constexpr int NLD_W = BN / RPP;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int WSTAGE = BN * 128;
+    static_assert(BN % RPP == 0 && WM % 16 == 0 && WN % 16 == 0 && MT <= 4, "tile shape");
+    static_assert(WS >= 2 && WS <= 4, "weight ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int r16 = lane & 15, q = lane >> 4;
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x;
+        const int q8 = nb >> 3, r8 = nb & 7;
+        const int xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+    }
+    const int tile_m = bid / a.n_tiles;
+    const int tile_n = bid - tile_m * a.n_tiles;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int ld_row = tid >> 3, ld_chunk = tid & 7;
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = n0 + wave_n * WN + i * 16 + q * 4;
+        f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (a.bias && n < a.Cout) { const float4 t = *(const float4*)(a.bias + n); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = b4;
+    }
+
+    // tap validity of this lane's pixel in each m-tile: bit kh*3+kw
+    int vm[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        int m = m0 + wave_m * WM + j * 16 + r16;
+        m = m < a.M ? m : a.M - 1;
+        const int rem = m % a.HoWo;
+        const int ho = rem / a.W;
+        const int wo = rem - ho * a.W;
+        const int wv = (wo > 0 ? 1 : 0) | 2 | (wo < a.W - 1 ? 4 : 0);
+        vm[j] = (ho > 0 ? wv : 0) | (wv << 3) | (ho < a.H - 1 ? wv << 6 : 0);
+    }
+
+    const int shift = (a.W + 1) * a.pix_bytes;   // the patch starts W+1 pixels in front of the tile's first pixel
+    const v4u rsx = make_srd(a.x - shift, a.x_bytes + (unsigned)shift);
+    const v4u rsw = make_srd(a.w, a.w_bytes);
+    constexpr unsigned OOB = 0x80000000u;
+    const int gch = ld_chunk ^ (ld_row & 7);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int patch_bytes = pra * 128;
+    const unsigned w_base = lds_base + npatch * patch_bytes;
+    const int npp = (pra + RPP - 1) / RPP;   // DMA pieces per patch (<= 9: one rides along with each tap's weight step)
+    unsigned woff[NLD_W];
+#pragma unroll
+    for (int i = 0; i < NLD_W; ++i) {
+        const int n = n0 + ld_row + RPP * i;
+        woff[i] = n < a.Cout ? (unsigned)(n * a.w_row_bytes + gch * 16) : OOB;
+    }
+    auto issue_patch = [&](int piece, int cs, int buf) {
+        if (piece * RPP + wave_u * 8 < pra) {   // wave-uniform: the last piece covers only the allocated rows
+            const int p = m0 + piece * RPP + ld_row;   // linear pixel index + (W+1)
+            const unsigned v[1] = {p >= a.W + 1 ? (unsigned)(p * a.pix_bytes + gch * 16) : OOB};
+            lds_dma16_group<1, 0>(rsx, v, (unsigned)__builtin_amdgcn_readfirstlane(cs * 128),
+                                  lds_base + buf * patch_bytes + piece * (RPP * 128) + wave_u * 1024);
+        }
+    };
+    auto issue_w = [&](int wstep, int stage) {
+        lds_dma16_group<NLD_W, RPP * 128>(rsw, woff, (unsigned)__builtin_amdgcn_readfirstlane(wstep * 128), w_base + stage * WSTAGE + wave_u * 1024);
+    };
+    const int rd_w = (wave_n * WN + r16) * 128;
+    auto compute = [&](const char* pb, const char* wb, int toff, int tap) {
+        const int prow = wave_m * WM + r16 + toff;
+        unsigned msk[MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) msk[j] = (unsigned)__builtin_amdgcn_sbfe(vm[j], (unsigned)tap, 1u);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int swx = ((kk * 4 + q) ^ (prow & 7)) << 4;
+            const int sww = ((kk * 4 + q) ^ (r16 & 7)) << 4;
+            uint4 fx[MT], fw[NT];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) fx[j] = *(const uint4*)(pb + (prow + j * 16) * 128 + swx);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) fw[i] = *(const uint4*)(wb + rd_w + i * 16 * 128 + sww);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) { fx[j].x &= msk[j]; fx[j].y &= msk[j]; fx[j].z &= msk[j]; fx[j].w &= msk[j]; }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[i]), __builtin_bit_cast(bf16x8_t, fx[j]),
+                                                                        acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int SPT = a.SPT;
+    const int nsteps = 9 * SPT;
+    // K-step s = (slice s / 9, tap s % 9); packed weights are tap-major: weight K-step = tap*SPT + slice
+    int i_tap = 0, i_cs = 0, i_stage = 0;   // position of the next weight issue
+    auto issue_next_w = [&]() {
+        issue_w(i_tap * SPT + i_cs, i_stage);
+        if (++i_tap == 9) { i_tap = 0; ++i_cs; }
+        i_stage = i_stage + 1 == WS ? 0 : i_stage + 1;
+    };
+    auto wait_allowed = [&](int n) {   // at most n of this wave's DMA instructions stay in flight (they retire in issue order)
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        }
+    };
+    static_assert((WS - 2) * (NLD_W + 1) <= 6, "wait_allowed covers up to 6 instructions in flight");
+    for (int piece = 0; piece < npp; ++piece) issue_patch(piece, 0, 0);
+#pragma unroll
+    for (int s0 = 0; s0 < WS - 1; ++s0)
+        if (s0 < nsteps) issue_next_w();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int step = 0, cur = 0;
+    int c_prev = 0;   // DMA instructions this wave issued in the previous iteration (WS == 4 keeps two iterations in flight)
+#pragma unroll 1
+    for (int cs = 0; cs < SPT; ++cs) {
+        const char* pb = smem + (cs & (npatch - 1)) * patch_bytes;
+        int kh = 0, kw = 0;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++step) {
+            // weights of K-step step+WS-1, plus one piece of the next slice's patch (taps 0..npp-1; npp <= 11-WS, so the last piece has
+            // left the in-flight window by the end of tap 8)
+            int c_now = 0;
+            if (step + WS - 1 < nsteps) { issue_next_w(); c_now = NLD_W; }
+            if (cs + 1 < SPT && tap < npp && tap * RPP + wave_u * 8 < pra) { issue_patch(tap, cs + 1, (cs + 1) & 1); ++c_now; }
+            compute(pb, smem + npatch * patch_bytes + cur * WSTAGE, kh * a.W + kw, tap);
+            if (++kw == 3) { kw = 0; ++kh; }
+            cur = cur + 1 == WS ? 0 : cur + 1;
+            c_now = __builtin_amdgcn_readfirstlane(c_now);
+            wait_allowed(WS == 2 ? 0 : WS == 3 ? c_now : c_now + c_prev);
+            c_prev = c_now;
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: (bias in the accumulators) ReLU, fp32 tile -> LDS rows -> 16-byte bf16 vectors
+    constexpr int ROWB = BN * 4 + 16;
+    constexpr int PASSES = BN >= 256 ? 4 : 2;
+    static_assert(MT % PASSES == 0, "passes split the m-tiles of a wave");
+    constexpr int MTP = MT / PASSES, WMP = WM / PASSES, BMP = BM / PASSES;
+    constexpr int TPR = BN / 8, RPI = NTH / TPR;
+    constexpr int ITERS = (BMP + RPI - 1) / RPI;
+    const int rc = tid % TPR, rr = tid / TPR;
+    const int n = n0 + rc * 8;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        if (p) __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < MTP; ++jj) {
+            const int lrow = wave_m * WMP + jj * 16 + r16;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) *(f32x4*)(smem + lrow * ROWB + (wave_n * WN + i * 16 + q * 4) * 4) = acc[i][p * MTP + jj];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int lrow = rr + it * RPI;
+            const int m = m0 + (lrow / WMP) * WM + p * WMP + (lrow % WMP);
+            if (lrow >= BMP || m >= a.M || n >= a.Cout) continue;
+            float v[8];
+            *(float4*)&v[0] = *(const float4*)(smem + lrow * ROWB + rc * 32);
+            *(float4*)&v[4] = *(const float4*)(smem + lrow * ROWB + rc * 32 + 16);
+            if (a.relu == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            char* yp = a.y + ((long long)m * a.y_ld + n) * 2;
+            if (a.nt_epi) __builtin_nontemporal_store(ov, (u32x4*)yp);
+            else *(uint4*)yp = make_uint4(ov.x, ov.y, ov.z, ov.w);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 namespace {
 
@@ -518,9 +725,12 @@ struct TileCfg {
 // ids 13-16: 8-wave workgroups (one per CU): 256x128 with 2 / 3 stages, 256x256, 128x256 with 3 stages
 // id 20: 256x64 for the 64-channel layers (8 waves)
 // ids 17-19: 16-wave workgroups (four waves per SIMD, 64x64 / 64x32 wave tiles): 256x256, 256x128 with 2 / 3 stages
+// ids 21-26: the 3x3 patch kernel (bf16, stride 1, pad 1, Cin % 64 == 0): 256x64 (8 waves, 4-deep weight ring), 256x128 (16 waves, 3),
+//            256x256 (16 waves, 2); 24-26: 256x64 with 2, 256x128 with 4 / 2 weight stages (tuning)
 constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {64, 128}, {32, 64}, {32, 32},
                               {128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}, {128, 64},
-                              {256, 128}, {256, 128}, {256, 256}, {128, 256}, {256, 256}, {256, 128}, {256, 128}, {256, 64}};
+                              {256, 128}, {256, 128}, {256, 256}, {128, 256}, {256, 256}, {256, 128}, {256, 128}, {256, 64},
+                              {256, 64}, {256, 128}, {256, 256}, {256, 64}, {256, 128}, {256, 128}};   // 21-26: 3x3 patch kernel (conv3x3_patch_kernel)
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <typename T, int BM, int BN, int WM_, int WN_, int STAGES, bool OUT_F32>
@@ -587,6 +797,55 @@ int launch_dtype(const ConvK& k, int tile, bool fast, hipStream_t s) {
         case 18: return launch_tile<T, 256, 128, 4, 4, 2, OUT_F32>(k, fast, s);
         case 19: return launch_tile<T, 256, 128, 4, 4, 3, OUT_F32>(k, fast, s);
         case 20: return launch_tile<T, 256, 64, 4, 2, 2, OUT_F32>(k, fast, s);
+    }
+    return MT4_EINVAL;
+}
+
+
+// geometry the patch kernel covers (everything else runs the generic kernel)
+bool patch3x3_ok(const mt4_conv_desc* d, const ConvK& k, bool fast) {
+    return fast && d->dtype == MT4_BF16 && d->out_dtype == MT4_BF16 && d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 &&
+           d->dil_h == 1 && d->dil_w == 1 && d->pad_h == 1 && d->pad_w == 1 && d->Ho == d->H && d->Wo == d->W && k.pix_bytes == d->Cin * 2 &&
+           !d->residual && !d->out_row_map && d->relu <= 1 && (d->Cout % 8) == 0 && k.nsteps == 9 * k.SPT &&
+           (long long)k.x_bytes + (long long)(2 * d->W + 1024) * k.pix_bytes < 0x7fffffffLL;
+}
+
+template <int BM, int BN, int WM_, int WN_, int WS>
+int launch_patch3x3(const ConvK& k, hipStream_t s) {
+    ConvK kk = k;
+    kk.n_tiles = cdiv(k.Cout, BN);
+    kk.total_tiles = cdiv(k.M, BM) * kk.n_tiles;
+    kk.nt_epi = getenv("MT4_NO_NT") == nullptr ? 1 : 0;
+    {
+        const char* e = getenv("MT4_NT_MIN_MB");
+        const long long min_mb = e ? atoi(e) : 200;
+        if ((long long)k.M * k.Cout * 2 < min_mb * 1000000LL) kk.nt_epi = 0;
+    }
+    constexpr int threads = WM_ * WN_ * 64;
+    constexpr int rpp = threads / 8;
+    const int pra = (BM + 2 * k.W + 2 + 7) / 8 * 8;
+    const int npatch = k.SPT > 1 ? 2 : 1;
+    constexpr int epi = BM / (BN >= 256 ? 4 : 2) * (BN * 4 + 16);
+    int lds = npatch * pra * 128 + WS * BN * 128;
+    if (lds < epi) lds = epi;
+    if (lds > 160 * 1024 || cdiv(pra, rpp) > 11 - WS) return MT4_EUNSUPPORTED;
+    auto fn = conv3x3_patch_kernel<BM, BN, WM_, WN_, WS>;
+    if (lds > 65536) {
+        static bool raised = false;
+        if (!raised) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+    }
+    hipLaunchKernelGGL(fn, dim3(kk.total_tiles), dim3(threads), lds, s, kk, pra, npatch);
+    return mt4_check_launch();
+}
+
+int launch_patch_tile(const ConvK& k, int tile, hipStream_t s) {
+    switch (tile) {
+        case 21: return launch_patch3x3<256, 64, 4, 2, 4>(k, s);
+        case 22: return launch_patch3x3<256, 128, 4, 4, 3>(k, s);
+        case 23: return launch_patch3x3<256, 256, 4, 4, 2>(k, s);
+        case 24: return launch_patch3x3<256, 64, 4, 2, 2>(k, s);
+        case 25: return launch_patch3x3<256, 128, 4, 4, 4>(k, s);
+        case 26: return launch_patch3x3<256, 128, 4, 4, 2>(k, s);
     }
     return MT4_EINVAL;
 }
@@ -707,8 +966,28 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     k.SPT = fast ? k.CPT / 8 : 1;
     int tile = d->tile;
     if (tile < 0 || tile > kNumTiles) return MT4_EINVAL;
-    if (tile == 0) tile = auto_tile(k.M, k.Cout, k.nsteps, d->dtype == MT4_F32 ? 4 : 2);
     hipStream_t s = (hipStream_t)stream;
+    if (tile >= 21) {   // explicit request for the 3x3 patch kernel
+        if (!patch3x3_ok(d, k, fast)) return MT4_EUNSUPPORTED;
+        return launch_patch_tile(k, tile, s);
+    }
+    if (tile == 0 && patch3x3_ok(d, k, fast) && (long long)cdiv(k.M, 256) * cdiv(k.Cout, 256) >= 256) {
+        // 3x3 stride-1 layers at many rounds of the chip: the patch kernel (same-box sweep at 1336 frames,
+        // profiles/r01_tile_tuning_patch3x3.txt: layer1 conv2 0.457 -> 0.374 ms, layer2 0.344 -> 0.336, layer3 0.251 -> 0.246, layer4 even;
+        // ResNet-50 bench, 4 alternating runs each: 67.17 k -> 68.19 k frames/s).  MT4_PATCH3X3: 0 = generic tiles only,
+        // 1 = patch kernel for Cout <= 64 and the two-stage generic 256x128 tile for Cout <= 128 (68.02 k), 2 = default
+        static const int mode = getenv("MT4_PATCH3X3") ? atoi(getenv("MT4_PATCH3X3")) : 2;
+        int pt = 0;
+        if (mode == 1) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? 18 : 0;
+        else if (mode >= 2) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? 26 : 23;
+        if (pt >= 21) {
+            const int rc = launch_patch_tile(k, pt, s);
+            if (rc != MT4_EUNSUPPORTED) return rc;   // (patch too large for LDS: generic tiles)
+        } else if (pt) {
+            tile = pt;
+        }
+    }
+    if (tile == 0) tile = auto_tile(k.M, k.Cout, k.nsteps, d->dtype == MT4_F32 ? 4 : 2);
     if (d->dtype == MT4_F32) return launch_dtype<float, true>(k, tile, fast, s);
     if (d->out_dtype == MT4_F32) return launch_dtype<u16, true>(k, tile, fast, s);
     return launch_dtype<u16, false>(k, tile, fast, s);

@@ -51,7 +51,48 @@ CONV_SHAPES = [
     (1, 1, 40, 48, 100, 1, 1, (1, 1), (0, 0), (1, 1)),      # GENERIC path (Cin*es % 128 != 0), Cout % 4 == 0 but ragged
     (3, 1, 33, 32, 131, 1, 1, (1, 1), (0, 0), (1, 1)),      # Cout % 4 != 0 -> scalar epilogue
     (2, 7, 7, 512, 512, 3, 3, (1, 1), (1, 1), (1, 1)),      # layer4 shape, long K
+    (70, 1, 1, 64, 64, 3, 3, (1, 1), (1, 1), (1, 1)),       # padded kernel over 1x1 images: only the centre tap is inside
 ]
+
+
+PATCH_SHAPES = [
+    # B, H, W, Cin, Cout: 3x3 / stride 1 / pad 1 bf16 layers of the ResNet trunks and ragged variants
+    (3, 56, 56, 64, 64),      # layer1 conv2: one channel slice, several rows of the image per tile
+    (5, 28, 28, 128, 128),    # layer2: two slices (double-buffered patch)
+    (9, 14, 14, 256, 256),    # layer3: a tile spans more than one image
+    (11, 7, 7, 512, 512),     # layer4: 5 images per tile, 8 slices
+    (2, 13, 17, 64, 72),      # odd sizes, ragged M, Cout not a multiple of the tile
+    (1, 3, 90, 64, 40),       # wide rows: patch of 256 + 182 rows, 7 DMA pieces
+    (300, 1, 1, 64, 64),      # 1x1 images: only the centre tap is ever valid
+    (4, 2, 2, 192, 136),      # three slices, tiny images
+]
+
+
+@pytest.mark.parametrize("tile", [21, 22, 23, 24, 25, 26])
+@pytest.mark.parametrize("shape", PATCH_SHAPES)
+def test_conv3x3_patch_kernel(cuda, shape, tile):
+    """the 3x3 patch kernel (input patch staged once per channel slice, tap validity masked on the fragments) walks K in the
+    generic kernel's order with the same MFMA chain: bit-identical to it, and within bf16 tolerance of F.conv2d"""
+    from computervision_codes_amd import ops
+    B, H, W, Cin, Cout = shape
+    for relu in (False, True):
+        _conv_case(cuda, B, H, W, Cin, Cout, 3, 3, (1, 1), (1, 1), (1, 1), torch.bfloat16, relu=relu, use_res=False, tile=tile, seed=21 + relu)
+    x = _rand((B, H, W, Cin), 31).to(cuda, torch.bfloat16)
+    wp = ops.pack_conv_weight(_rand((Cout, Cin, 3, 3), 32, 0.05).to(cuda), None, torch.bfloat16)
+    bias = _rand((Cout,), 33, 0.1).to(cuda)
+    ref = ops.conv_nhwc(x, wp, bias, kh=3, kw=3, pad=(1, 1), relu=True, tile=2)
+    got = ops.conv_nhwc(x, wp, bias, kh=3, kw=3, pad=(1, 1), relu=True, tile=tile)
+    assert torch.equal(ref.view(torch.int16), got.view(torch.int16))
+
+
+def test_conv3x3_patch_kernel_refuses_other_geometry(cuda):
+    from computervision_codes_amd import ops
+    x = _rand((1, 8, 8, 64), 1).to(cuda, torch.bfloat16)
+    wp = ops.pack_conv_weight(_rand((64, 64, 3, 3), 2, 0.05).to(cuda), None, torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        ops.conv_nhwc(x, wp, None, kh=3, kw=3, stride=(2, 2), pad=(1, 1), tile=21)
+    with pytest.raises(RuntimeError):
+        ops.conv_nhwc(x.float(), ops.pack_conv_weight(_rand((64, 64, 3, 3), 2, 0.05).to(cuda), None, torch.float32), None, kh=3, kw=3, pad=(1, 1), tile=22)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
