@@ -524,12 +524,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_patch_kernel(c
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int NTH = NW * 64;
     constexpr int RPP = NTH / 8;
-    constexpr int NLD_W = BN / RPP;
+    constexpr int NLD_W = BN >= RPP ? BN / RPP : 1;   // (BN < RPP: only the first BN/8 waves stage weight rows)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 16, NT = WN / 16;
     constexpr int WSTAGE = BN * 128;
-    static_assert(BN % RPP == 0 && WM % 16 == 0 && WN % 16 == 0 && MT <= 4, "tile shape");
-    static_assert(WS >= 2 && WS <= 4, "weight ring depth");
+    static_assert((BN % RPP == 0 || RPP % BN == 0) && WM % 16 == 0 && WN % 16 == 0 && MT <= 4, "tile shape");
+    static_assert((WS >= 2 && WS <= 4) || WS == 9, "weight ring depth (9: all taps of a single-slice layer resident, no barrier in the K loop)");
+    constexpr bool RESIDENT = WS == 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -596,6 +597,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_patch_kernel(c
         }
     };
     auto issue_w = [&](int wstep, int stage) {
+        if (BN >= RPP || wave_u * 8 < BN)
         lds_dma16_group<NLD_W, RPP * 128>(rsw, woff, (unsigned)__builtin_amdgcn_readfirstlane(wstep * 128), w_base + stage * WSTAGE + wave_u * 1024);
     };
     const int rd_w = (wave_n * WN + r16) * 128;
@@ -644,10 +646,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_patch_kernel(c
             default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
         }
     };
-    static_assert((WS - 2) * (NLD_W + 1) <= 6, "wait_allowed covers up to 6 instructions in flight");
+    static_assert(RESIDENT || (WS - 2) * (NLD_W + 1) <= 6, "wait_allowed covers up to 6 instructions in flight");
     for (int piece = 0; piece < npp; ++piece) issue_patch(piece, 0, 0);
 #pragma unroll
-    for (int s0 = 0; s0 < WS - 1; ++s0)
+    for (int s0 = 0; s0 < (RESIDENT ? 9 : WS - 1); ++s0)
         if (s0 < nsteps) issue_next_w();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -662,17 +664,22 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_patch_kernel(c
             // weights of K-step step+WS-1, plus one piece of the next slice's patch (taps 0..npp-1; npp <= 11-WS, so the last piece has
             // left the in-flight window by the end of tap 8)
             int c_now = 0;
-            if (step + WS - 1 < nsteps) { issue_next_w(); c_now = NLD_W; }
-            if (cs + 1 < SPT && tap < npp && tap * RPP + wave_u * 8 < pra) { issue_patch(tap, cs + 1, (cs + 1) & 1); ++c_now; }
+            if constexpr (!RESIDENT) {
+                if (step + WS - 1 < nsteps) { issue_next_w(); c_now = NLD_W; }
+                if (cs + 1 < SPT && tap < npp && tap * RPP + wave_u * 8 < pra) { issue_patch(tap, cs + 1, (cs + 1) & 1); ++c_now; }
+            }
             compute(pb, smem + npatch * patch_bytes + cur * WSTAGE, kh * a.W + kw, tap);
             if (++kw == 3) { kw = 0; ++kh; }
             cur = cur + 1 == WS ? 0 : cur + 1;
-            c_now = __builtin_amdgcn_readfirstlane(c_now);
-            wait_allowed(WS == 2 ? 0 : WS == 3 ? c_now : c_now + c_prev);
-            c_prev = c_now;
-            __syncthreads();
+            if constexpr (!RESIDENT) {
+                c_now = __builtin_amdgcn_readfirstlane(c_now);
+                wait_allowed(WS == 2 ? 0 : WS == 3 ? c_now : c_now + c_prev);
+                c_prev = c_now;
+                __syncthreads();
+            }
         }
     }
+    if constexpr (RESIDENT) __syncthreads();   // (the epilogue reuses the operand LDS)
 
     // ---- epilogue: (bias in the accumulators) ReLU, fp32 tile -> LDS rows -> 16-byte bf16 vectors
     constexpr int ROWB = BN * 4 + 16;
@@ -725,12 +732,14 @@ struct TileCfg {
 // ids 13-16: 8-wave workgroups (one per CU): 256x128 with 2 / 3 stages, 256x256, 128x256 with 3 stages
 // id 20: 256x64 for the 64-channel layers (8 waves)
 // ids 17-19: 16-wave workgroups (four waves per SIMD, 64x64 / 64x32 wave tiles): 256x256, 256x128 with 2 / 3 stages
-// ids 21-26: the 3x3 patch kernel (bf16, stride 1, pad 1, Cin % 64 == 0): 256x64 (8 waves, 4-deep weight ring), 256x128 (16 waves, 3),
-//            256x256 (16 waves, 2); 24-26: 256x64 with 2, 256x128 with 4 / 2 weight stages (tuning)
+// ids 21-32: the 3x3 patch kernel (bf16, stride 1, pad 1, Cin % 64 == 0), BM x BN / waves / weight stages:
+//   21: 256x64/8/4   22: 256x128/16/3   23: 256x256/16/2   24: 256x64/8/2   25: 256x128/16/4   26: 256x128/16/2
+//   27: 256x64/8/all 9 taps resident   28: 512x64/16/resident   29: 128x64/4/2   30: 128x128/4/2   31: 256x64/4/2   32: 256x128/8/2
+//   (auto: 24, 30, 23 by Cout; the others are the tuning record: deeper rings and the barrier-free resident variants are slower)
 constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {64, 128}, {32, 64}, {32, 32},
                               {128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}, {128, 64},
                               {256, 128}, {256, 128}, {256, 256}, {128, 256}, {256, 256}, {256, 128}, {256, 128}, {256, 64},
-                              {256, 64}, {256, 128}, {256, 256}, {256, 64}, {256, 128}, {256, 128}};   // 21-26: 3x3 patch kernel (conv3x3_patch_kernel)
+                              {256, 64}, {256, 128}, {256, 256}, {256, 64}, {256, 128}, {256, 128}, {256, 64}, {512, 64}, {128, 64}, {128, 128}, {256, 64}, {256, 128}};   // 21-32: 3x3 patch kernel (conv3x3_patch_kernel)
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <typename T, int BM, int BN, int WM_, int WN_, int STAGES, bool OUT_F32>
@@ -828,7 +837,8 @@ int launch_patch3x3(const ConvK& k, hipStream_t s) {
     constexpr int epi = BM / (BN >= 256 ? 4 : 2) * (BN * 4 + 16);
     int lds = npatch * pra * 128 + WS * BN * 128;
     if (lds < epi) lds = epi;
-    if (lds > 160 * 1024 || cdiv(pra, rpp) > 11 - WS) return MT4_EUNSUPPORTED;
+    if (WS == 9 && k.SPT != 1) return MT4_EUNSUPPORTED;
+    if (lds > 160 * 1024 || (k.SPT > 1 && cdiv(pra, rpp) > 11 - WS)) return MT4_EUNSUPPORTED;   // (next-slice patch pieces ride along with taps 0..)
     auto fn = conv3x3_patch_kernel<BM, BN, WM_, WN_, WS>;
     if (lds > 65536) {
         static bool raised = false;
@@ -846,6 +856,12 @@ int launch_patch_tile(const ConvK& k, int tile, hipStream_t s) {
         case 24: return launch_patch3x3<256, 64, 4, 2, 2>(k, s);
         case 25: return launch_patch3x3<256, 128, 4, 4, 4>(k, s);
         case 26: return launch_patch3x3<256, 128, 4, 4, 2>(k, s);
+        case 27: return launch_patch3x3<256, 64, 4, 2, 9>(k, s);
+        case 28: return launch_patch3x3<512, 64, 8, 2, 9>(k, s);
+        case 29: return launch_patch3x3<128, 64, 2, 2, 2>(k, s);
+        case 30: return launch_patch3x3<128, 128, 2, 2, 2>(k, s);
+        case 31: return launch_patch3x3<256, 64, 4, 1, 2>(k, s);
+        case 32: return launch_patch3x3<256, 128, 4, 2, 2>(k, s);
     }
     return MT4_EINVAL;
 }
@@ -973,13 +989,15 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     }
     if (tile == 0 && patch3x3_ok(d, k, fast) && (long long)cdiv(k.M, 256) * cdiv(k.Cout, 256) >= 256) {
         // 3x3 stride-1 layers at many rounds of the chip: the patch kernel (same-box sweep at 1336 frames,
-        // profiles/r01_tile_tuning_patch3x3.txt: layer1 conv2 0.457 -> 0.374 ms, layer2 0.344 -> 0.336, layer3 0.251 -> 0.246, layer4 even;
-        // ResNet-50 bench, 4 alternating runs each: 67.17 k -> 68.19 k frames/s).  MT4_PATCH3X3: 0 = generic tiles only,
-        // 1 = patch kernel for Cout <= 64 and the two-stage generic 256x128 tile for Cout <= 128 (68.02 k), 2 = default
-        static const int mode = getenv("MT4_PATCH3X3") ? atoi(getenv("MT4_PATCH3X3")) : 2;
+        // profiles/r01_tile_tuning_patch3x3.txt: layer1 conv2 0.462 -> 0.375 ms (256x64), layer2 0.343 -> 0.300 (128x128, 4 waves with 64x64
+        // wave tiles), layer3 0.242 -> 0.244 and layer4 0.232 -> 0.230 (256x256: even); ResNet-50 bench, alternating runs on one box:
+        // 67.8 k frames/s generic, 68.5 k mode 2, 69.0 k mode 3).  MT4_PATCH3X3: 0 = generic tiles only, 1 = patch kernel for Cout <= 64 and the
+        // two-stage generic 256x128 tile for Cout <= 128, 2 = patch tiles 24 / 26 / 23, 3 = default: 24 / 30 / 23
+        static const int mode = getenv("MT4_PATCH3X3") ? atoi(getenv("MT4_PATCH3X3")) : 3;
         int pt = 0;
         if (mode == 1) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? 18 : 0;
-        else if (mode >= 2) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? 26 : 23;
+        else if (mode == 2) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? 26 : 23;
+        else if (mode >= 3) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? 30 : 23;
         if (pt >= 21) {
             const int rc = launch_patch_tile(k, pt, s);
             if (rc != MT4_EUNSUPPORTED) return rc;   // (patch too large for LDS: generic tiles)

@@ -68,13 +68,34 @@ PATCH_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [21, 22, 23, 24, 25, 26])
+PATCH_TILES = {  # id: (BM, BN, waves, weight stages)   (igemm_conv.hip launch_patch_tile)
+    21: (256, 64, 8, 4), 22: (256, 128, 16, 3), 23: (256, 256, 16, 2), 24: (256, 64, 8, 2), 25: (256, 128, 16, 4), 26: (256, 128, 16, 2),
+    27: (256, 64, 8, 9), 28: (512, 64, 16, 9), 29: (128, 64, 4, 2), 30: (128, 128, 4, 2), 31: (256, 64, 4, 2), 32: (256, 128, 8, 2)}
+
+
+def _patch_tile_fits(tile, W, Cin):
+    """launch_patch3x3's own rule: the patch (double-buffered over channel slices) + the weight ring fit 160 KB of LDS, the next
+    slice's patch pieces fit the taps they ride along with, and the weights-resident variants take single-slice layers only"""
+    bm, bn, waves, ws = PATCH_TILES[tile]
+    spt = Cin // 64
+    pra = (bm + 2 * W + 2 + 7) // 8 * 8
+    lds = (2 if spt > 1 else 1) * pra * 128 + ws * bn * 128
+    if ws == 9 and spt != 1:
+        return False
+    return lds <= 160 * 1024 and (spt == 1 or -(-pra // (waves * 8)) <= 11 - ws)
+
+
+@pytest.mark.parametrize("tile", sorted(PATCH_TILES))
 @pytest.mark.parametrize("shape", PATCH_SHAPES)
 def test_conv3x3_patch_kernel(cuda, shape, tile):
     """the 3x3 patch kernel (input patch staged once per channel slice, tap validity masked on the fragments) walks K in the
     generic kernel's order with the same MFMA chain: bit-identical to it, and within bf16 tolerance of F.conv2d"""
     from computervision_codes_amd import ops
     B, H, W, Cin, Cout = shape
+    if not _patch_tile_fits(tile, W, Cin):   # (auto selection falls back to the generic tiles in these cases)
+        with pytest.raises(RuntimeError):
+            _conv_case(cuda, B, H, W, Cin, Cout, 3, 3, (1, 1), (1, 1), (1, 1), torch.bfloat16, relu=False, use_res=False, tile=tile, seed=21)
+        return
     for relu in (False, True):
         _conv_case(cuda, B, H, W, Cin, Cout, 3, 3, (1, 1), (1, 1), (1, 1), torch.bfloat16, relu=relu, use_res=False, tile=tile, seed=21 + relu)
     x = _rand((B, H, W, Cin), 31).to(cuda, torch.bfloat16)
