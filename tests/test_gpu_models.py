@@ -262,6 +262,29 @@ def test_spatial_cnn_multi_stream_extract_is_byte_identical(cuda):
         assert torch.equal(a[3][0], b[3][0]) and all(torch.equal(x[1], y[1]) for x, y in zip(a, b))
 
 
+def test_stem_patch_kernel_bit_identical(cuda):
+    """the stem patch kernel (tile 33: the tile's span of the space-to-depth frame and the whole weight matrix staged once, no barrier in
+    the K loop) walks K like the generic kernel on the same frame: identical bytes; frames too small for it are refused"""
+    from computervision_codes_amd import ops
+    from computervision_codes_amd.synth import IMAGENET_MEAN, IMAGENET_STD
+    _, cfg = load_golden("cnn_resnet50_224")
+    m = _cnn_model(cfg, torch.bfloat16)
+    for (b, h, w) in ((5, 224, 224), (3, 64, 96), (2, 256, 448), (7, 32, 34), (1, 32, 32), (12, 224, 224)):   # (12 frames: 588 tiles, the persistent form walks 2 per workgroup)
+        fr = synth.synthetic_frames(b, h, w, seed=h + w).to(cuda)
+        xs = ops.preprocess_u8_s2d(fr, IMAGENET_MEAN, IMAGENET_STD)
+        kw = dict(kh=4, kw=1, relu=True, run_pixels=4, out_hw=(h // 2, w // 2))
+        ref = ops.conv_nhwc(xs, m._p["stem_s2d"], m._p["stem"][1], tile=20, **kw)
+        got = ops.conv_nhwc(xs, m._p["stem_s2d"], m._p["stem"][1], tile=33, **kw)
+        per = ops.conv_nhwc(xs, m._p["stem_s2d"], m._p["stem"][1], tile=34, **kw)   # persistent form
+        assert torch.equal(ref.view(torch.int16), per.view(torch.int16)), (b, h, w)
+        auto = ops.conv_nhwc(xs, m._p["stem_s2d"], m._p["stem"][1], **kw)
+        assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), (b, h, w)
+        assert torch.equal(ref.view(torch.int16), auto.view(torch.int16)), (b, h, w)
+    xs = ops.preprocess_u8_s2d(synth.synthetic_frames(2, 16, 16, seed=1).to(cuda), IMAGENET_MEAN, IMAGENET_STD)   # 8x8 outputs per image
+    with pytest.raises(RuntimeError):
+        ops.conv_nhwc(xs, m._p["stem_s2d"], m._p["stem"][1], kh=4, kw=1, relu=True, run_pixels=4, out_hw=(8, 8), tile=33)
+
+
 def test_space_to_depth_stem_equals_padded_stem(cuda):
     """bf16 throughput path: the stem on the space-to-depth frame (4x1 kernel over 128-byte runs, LDS-DMA staging) against the stem on
     the padded pixel-pair frame (register staging): same products, another summation order -> equal to bf16 rounding of the output"""
