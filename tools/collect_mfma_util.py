@@ -8,15 +8,17 @@ per dispatch summed over the 8 XCDs (value / launch duration = 18.3-19.4 cycles 
 duration in shader-clock cycles is value / 8.  utilisation = busy / (1024 SIMDs x cycles)."""
 import collections, csv, glob, json, os, sys
 
+CONV_KERNELS = ("igemm_conv_kernel", "conv3x3_patch_kernel", "stem_patch_kernel", "stem_patch_persistent_kernel")   # everything mt4_conv_nhwc launches
+
 N_SIMD = 256 * 4
 N_XCD = 8
 
 
 def per_dispatch(d):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)   # (the newest pass)
     out = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
-        if "igemm_conv_kernel" not in r["Kernel_Name"]:
+        if not any(k in r["Kernel_Name"] for k in CONV_KERNELS):
             continue
         rec = out.setdefault(int(r["Dispatch_Id"]), collections.defaultdict(list))
         rec[r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -5,11 +5,13 @@ Per MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH
 (16 B/lane) coalesced stream -- doubled here; WRITE_SIZE is exact for 16-B-per-lane stores."""
 import collections, csv, glob, json, os, sys
 
+CONV_KERNELS = ("igemm_conv_kernel", "conv3x3_patch_kernel", "stem_patch_kernel", "stem_patch_persistent_kernel")   # everything mt4_conv_nhwc launches
+
 def per_dispatch(d, counter):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)   # (the newest pass)
     out = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter and "igemm_conv_kernel" in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in CONV_KERNELS):
             out[int(r["Dispatch_Id"])] = out.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
     return list(out.values())
 
