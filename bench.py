@@ -363,7 +363,7 @@ def main():
                 mfma_util = rec["mfma_util"] if rec else None
             except Exception:
                 mfma_util = None
-        roofline = dict(bound="mfma", kernel="igemm_conv_kernel (all conv launches of one step)", achieved=round(achieved, 2),
+        roofline = dict(bound="mfma", kernel="mt4_conv_nhwc launches of one step (igemm_conv_kernel, conv3x3_patch_kernel, stem_patch_kernel)", achieved=round(achieved, 2),
                         peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic, mfma_util_pmc=mfma_util,
                         launches_per_step=len(per_launch), conv_ms_per_step=round(conv_ms, 4),
                         gflop_per_frame=round(flops_frame / 1e9, 3), traffic_unit="HBM bytes per step (all conv launches)",
