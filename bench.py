@@ -262,6 +262,17 @@ def parity_mode_bench(dev, network, h, w, batch=256):
                 conv_tflops=round(tf, 1), f32_mfma_frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
 
 
+def native_resolution_bench(dev, model, streams, batch=584):
+    """the bench's extractor on the reference's own frame size, Resize((256, 448)) (`Spatial_cnn/dataloader.py:155`): 584 frames per stream
+    are the pixels of 1336 frames of 224x224.  18.69 GFLOP per frame."""
+    frames = device_frames(batch * max(1, streams), 256, 448, 77, dev)
+    ms = _time_call(lambda: model.extract_u8(frames, streams=streams), iters=5)
+    fl = conv_flops_per_frame(model, 256, 448)
+    n = batch * max(1, streams)
+    return dict(frames_per_s=round(n / ms * 1e3, 1), ms_per_step=round(ms, 3), frames_per_step=n, gflop_per_frame=round(fl / 1e9, 2),
+                mfma_frac=round(fl * n / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
+
+
 def spatial_train_bench(dev):
     """BASELINE configs[4] on one GPU: the student distillation step (`Spatial_cnn/run.py -t`, fp32, batch 8 of 256x448 frames as in
     Scripts/train_fold1.sh) -- forward, hard+soft+KD losses, backward, SGD; hipGraph replay of forward+backward."""
@@ -389,6 +400,8 @@ def main():
         }
         if world == 1 and not a.no_temporal:
             res["temporal"] = temporal_bench(dev, do_cpu=not a.no_cpu_baseline)
+            if dtype == torch.bfloat16 and a.network == "resnet50":
+                res["native_256x448"] = native_resolution_bench(dev, model, a.streams)
             res["swin_q2l"] = swin_bench(dev)
             res["spatial_train"] = spatial_train_bench(dev)
             res["parity_mode_f32"] = parity_mode_bench(dev, a.network, a.height, a.width)
