@@ -85,7 +85,8 @@ struct ConvK {
     int M, HoWo, CPT, SPT, taps, nsteps, n_tiles, total_tiles;
     long long x_img_bytes;  // H*W*pix_bytes
     int pix_bytes;          // bytes between neighbouring pixels of x: Cin*esize, or less when a K-row spans several pixels (x_pixel_stride)
-    unsigned x_bytes, w_bytes;  // buffer sizes for the LDS-DMA range check (FAST path; < 2 GiB)
+    unsigned x_bytes, w_bytes;  // buffer sizes for the LDS-DMA range check (patch kernels: x < 2 GiB; weights < 2 GiB)
+    long long x_total_bytes;    // B*H*W*pix_bytes (the generic FAST path addresses x relative to a per-tile origin)
     unsigned x_bias;            // (pad_h*W + pad_w)*Cin*esize: how far a padded corner reaches in front of x
     int w_row_bytes;        // nsteps*128
     int nt_epi;             // residual rows are loaded and bf16 output rows stored non-temporally (each is touched once by this launch;
@@ -200,7 +201,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
         // The x descriptor starts x_bias bytes BEFORE the tensor, x_bias = the farthest a padded corner reaches back:
         // per-lane offsets (pixel (hi0,wi0) + x_bias) are then never negative, and the wave-uniform tap/channel step rides in
         // the instruction's soffset (not range-checked).  Bytes in front of x are never fetched: their taps are invalid.
-        const v4u rsx = make_srd(a.x - a.x_bias, a.x_bytes + a.x_bias);
+        // 32-bit buffer offsets are taken from a per-workgroup origin (the image of the tile's first pixel), so the tensor itself may be
+        // larger than 2 GiB: only the bytes one tile spans (a few images) must fit the offset range (host-checked)
+        const long long org = (long long)(m0 / a.HoWo) * a.x_img_bytes;
+        const long long left = a.x_total_bytes - org + a.x_bias;
+        const v4u rsx = make_srd(a.x - a.x_bias + org, (unsigned)(left < 0x7fffffffLL ? left : 0x7fffffffLL));
         const v4u rsw = make_srd(a.w, a.w_bytes);
         constexpr unsigned OOB = 0x80000000u;
         const int gch = ld_chunk ^ (ld_row & 7);
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
                 wi0 = wo * a.sw - a.pw;
                 base = (long long)b * a.x_img_bytes + (long long)(hi0 * a.W + wi0) * a.pix_bytes;
             }
-            xoff[i] = (int)base + gch * 16 + (int)a.x_bias;   // >= 0
+            xoff[i] = (int)(base - org) + gch * 16 + (int)a.x_bias;   // >= 0
             if (ok) {
                 for (int kh = 0; kh < a.KH; ++kh)
                     if ((unsigned)(hi0 + kh * a.dh) < (unsigned)a.H) hmask |= 1u << (8 * i + kh);
@@ -1120,7 +1125,7 @@ bool patch3x3_ok(const mt4_conv_desc* d, const ConvK& k, bool fast) {
     return fast && d->dtype == MT4_BF16 && d->out_dtype == MT4_BF16 && d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 &&
            d->dil_h == 1 && d->dil_w == 1 && d->pad_h == 1 && d->pad_w == 1 && d->Ho == d->H && d->Wo == d->W && k.pix_bytes == d->Cin * 2 &&
            !d->residual && !d->out_row_map && d->relu <= 1 && (d->Cout % 8) == 0 && k.nsteps == 9 * k.SPT &&
-           (long long)k.x_bytes + (long long)(2 * d->W + 1024) * k.pix_bytes < 0x7fffffffLL;
+           k.x_total_bytes + (long long)(2 * d->W + 1024) * k.pix_bytes < 0x7fffffffLL;
 }
 
 template <int BM, int BN, int WM_, int WN_, int WS>
@@ -1176,7 +1181,7 @@ bool stem_patch_ok(const mt4_conv_desc* d, const ConvK& k, bool fast) {
     return fast && d->dtype == MT4_BF16 && d->out_dtype == MT4_BF16 && d->KW == 1 && d->KH <= 8 && d->Cin == 64 && k.pix_bytes == 32 &&
            d->stride_h == 1 && d->stride_w == 1 && d->dil_h == 1 && d->dil_w == 1 && d->pad_h == 0 && d->pad_w == 0 &&
            d->W == d->Wo + 3 && d->H == d->Ho + d->KH - 1 && !d->residual && !d->out_row_map && d->relu <= 1 && d->Cout <= 64 &&
-           (d->Cout % 8) == 0 && k.HoWo >= 256 && k.nsteps == d->KH && k.x_bytes < 0x70000000u;
+           (d->Cout % 8) == 0 && k.HoWo >= 256 && k.nsteps == d->KH && k.x_total_bytes < 0x70000000LL;
 }
 
 int launch_stem_patch(const ConvK& k, hipStream_t s) {
@@ -1349,7 +1354,12 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     k.x_img_bytes = (long long)k.H * k.W * pix;
     const long long xb = (long long)d->B * d->H * d->W * pix, wb = (long long)d->Cout * k.w_row_bytes;
     // FAST = LDS-DMA staging: whole 128-byte K-steps per tap, 32-bit buffer offsets, one validity bit per kh / kw
-    const bool fast = (k.CPT % 8) == 0 && xb < 0x70000000LL && wb < 0x7fffffffLL && d->KH <= 8 && d->KW <= 8;
+    // (x: offsets are relative to the image of a tile's first pixel; a tile of <= 256 output pixels spans at most 256/HoWo + 2 images)
+    const long long tile_span = ((long long)(256 / k.HoWo) + 2) * k.x_img_bytes +
+                                ((long long)(d->KH - 1) * d->dil_h * d->W + (long long)(d->KW - 1) * d->dil_w) * pix + (long long)k.CPT * 16 + 4096;
+    const bool fast = (k.CPT % 8) == 0 && tile_span + (((long long)d->pad_h * d->W + d->pad_w) * pix) < 0x70000000LL && wb < 0x7fffffffLL &&
+                      d->KH <= 8 && d->KW <= 8;
+    k.x_total_bytes = xb;
     k.x_bias = (unsigned)(((long long)d->pad_h * d->W + d->pad_w) * pix);
     k.x_bytes = (unsigned)(xb < 0x7fffffffLL ? xb : 0);
     k.w_bytes = (unsigned)(wb < 0x7fffffffLL ? wb : 0);

@@ -106,6 +106,27 @@ def test_conv3x3_patch_kernel(cuda, shape, tile):
     assert torch.equal(ref.view(torch.int16), got.view(torch.int16))
 
 
+def test_conv_input_larger_than_2gib(cuda):
+    """the LDS-DMA path addresses x with 32-bit offsets from a per-tile origin: a 2.3 GB input gives the bytes of its two halves run
+    separately (1x1 GEMM rows, 3x3 pad 1, strided 1x1), and takes the same time class as the halves (not the register-staged path)"""
+    from computervision_codes_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(3)
+    B = 1440
+    x = (torch.rand((B, 56, 56, 256), device=cuda, generator=g) - 0.5).to(torch.bfloat16)
+    assert x.numel() * 2 > 2 ** 31
+    for (cout, k, stride, pad) in ((64, 1, 1, 0), (64, 3, 1, 1), (128, 1, 2, 0)):
+        wp = ops.pack_conv_weight(_rand((cout, 256, k, k), 41, 0.05).to(cuda), None, torch.bfloat16)
+        bias = _rand((cout,), 42, 0.1).to(cuda)
+        kw = dict(kh=k, kw=k, stride=(stride, stride), pad=(pad, pad), relu=True)
+        whole = ops.conv_nhwc(x, wp, bias, **kw)
+        h = B // 2
+        lo = ops.conv_nhwc(x[:h].contiguous(), wp, bias, **kw)
+        hi = ops.conv_nhwc(x[h:].contiguous(), wp, bias, **kw)
+        assert torch.equal(whole[:h].view(torch.int16), lo.view(torch.int16)) and torch.equal(whole[h:].view(torch.int16), hi.view(torch.int16)), (cout, k)
+        del whole, lo, hi
+    torch.cuda.empty_cache()
+
+
 def test_conv3x3_patch_kernel_refuses_other_geometry(cuda):
     from computervision_codes_amd import ops
     x = _rand((1, 8, 8, 64), 1).to(cuda, torch.bfloat16)
