@@ -273,6 +273,25 @@ def native_resolution_bench(dev, model, streams, batch=584):
                 mfma_frac=round(fl * n / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
 
 
+def student_resnet18_bench(dev, streams):
+    """the extractor with the reference's own student network (`--network resnet18 --student_dim 512`, Scripts/test_fold1.sh) at both
+    frame sizes; 3.63 GFLOP per 224x224 frame"""
+    from computervision_codes_amd import shapes, synth
+    from computervision_codes_amd.spatial_cnn import VideoNas
+    args = types.SimpleNamespace(network="resnet18", loss_type="all", student_dim=512, teacher_dim=1536, train=False)
+    m = VideoNas(args=args, dtype=torch.bfloat16, device=str(dev)).eval()
+    m.load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes("resnet18"), seed=1234))
+    out = {}
+    for (h, w, batch) in ((224, 224, 1336), (256, 448, 584)):
+        n = batch * max(1, streams)
+        frames = device_frames(n, h, w, 55, dev)
+        ms = _time_call(lambda: m.extract_u8(frames, streams=streams), iters=5)
+        fl = conv_flops_per_frame(m, h, w)
+        out[f"{h}x{w}"] = dict(frames_per_s=round(n / ms * 1e3, 1), ms_per_step=round(ms, 3), frames_per_step=n,
+                                gflop_per_frame=round(fl / 1e9, 2), mfma_frac=round(fl * n / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
+    return out
+
+
 def spatial_train_bench(dev):
     """BASELINE configs[4] on one GPU: the student distillation step (`Spatial_cnn/run.py -t`, fp32, batch 8 of 256x448 frames as in
     Scripts/train_fold1.sh) -- forward, hard+soft+KD losses, backward, SGD; hipGraph replay of forward+backward."""
@@ -402,6 +421,7 @@ def main():
             res["temporal"] = temporal_bench(dev, do_cpu=not a.no_cpu_baseline)
             if dtype == torch.bfloat16 and a.network == "resnet50":
                 res["native_256x448"] = native_resolution_bench(dev, model, a.streams)
+                res["student_resnet18"] = student_resnet18_bench(dev, a.streams)
             res["swin_q2l"] = swin_bench(dev)
             res["spatial_train"] = spatial_train_bench(dev)
             res["parity_mode_f32"] = parity_mode_bench(dev, a.network, a.height, a.width)

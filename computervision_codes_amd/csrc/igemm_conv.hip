@@ -521,6 +521,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
 // (kh, kw) of tile row r is patch row r + kh*W + kw of the linear pixel range [m0 - W - 1, m0 + BM + W + 1).  A tap that leaves the
 // image (wraps to the neighbouring row / image in linear space) is zeroed on the pixel fragment: 9 validity bits per lane and
 // m-tile, one v_bfe + 8 v_and per m-tile and K-step.  Fill per slice: (BM + 2W + 2) + 9*BN rows instead of 9*(BM + BN).
+// Epilogue: bias (in the accumulators) + optional residual + optional ReLU.
 // Same K walk (slice outer, taps inner) and the same MFMA chain as the generic kernel: results are bit-identical.
 // Weight K-steps (BN rows x 128 B) run through a ring of WS stages, issued WS-1 steps ahead: a K-step of the narrow tiles is shorter
 // than the L2 -> LDS latency, so one step of prefetch distance leaves every step waiting for its weights.
@@ -695,8 +696,21 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_patch_kernel(c
     constexpr int ITERS = (BMP + RPI - 1) / RPI;
     const int rc = tid % TPR, rr = tid / TPR;
     const int n = n0 + rc * 8;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
+        // residual rows of the pass (the second conv of a BasicBlock) go in flight before the LDS hand-off, like in the generic kernel
+        u32x4 rres[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int lrow = rr + it * RPI;
+            const int m = m0 + (lrow / WMP) * WM + p * WMP + (lrow % WMP);
+            rres[it] = (u32x4){0u, 0u, 0u, 0u};
+            if (a.res && lrow < BMP && m < a.M && n < a.Cout) {
+                const u32x4* rp = (const u32x4*)(a.res + ((long long)m * a.res_ld + n) * 2);
+                rres[it] = a.nt_epi ? __builtin_nontemporal_load(rp) : *rp;
+            }
+        }
         if (p) __syncthreads();
 #pragma unroll
         for (int jj = 0; jj < MTP; ++jj) {
@@ -713,11 +727,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_patch_kernel(c
             float v[8];
             *(float4*)&v[0] = *(const float4*)(smem + lrow * ROWB + rc * 32);
             *(float4*)&v[4] = *(const float4*)(smem + lrow * ROWB + rc * 32 + 16);
+            if (a.res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += __uint_as_float(rres[it][e] << 16);
+                    v[2 * e + 1] += __uint_as_float(rres[it][e] & 0xffff0000u);
+                }
+            }
             if (a.relu == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
             char* yp = a.y + ((long long)m * a.y_ld + n) * 2;
             if (a.nt_epi) __builtin_nontemporal_store(ov, (u32x4*)yp);
@@ -1124,7 +1144,7 @@ int launch_dtype(const ConvK& k, int tile, bool fast, hipStream_t s) {
 bool patch3x3_ok(const mt4_conv_desc* d, const ConvK& k, bool fast) {
     return fast && d->dtype == MT4_BF16 && d->out_dtype == MT4_BF16 && d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 &&
            d->dil_h == 1 && d->dil_w == 1 && d->pad_h == 1 && d->pad_w == 1 && d->Ho == d->H && d->Wo == d->W && k.pix_bytes == d->Cin * 2 &&
-           !d->residual && !d->out_row_map && d->relu <= 1 && (d->Cout % 8) == 0 && k.nsteps == 9 * k.SPT &&
+           !d->out_row_map && d->relu <= 1 && (d->Cout % 8) == 0 && k.nsteps == 9 * k.SPT && (!d->residual || (k.res_ld * 2) % 16 == 0) &&
            k.x_total_bytes + (long long)(2 * d->W + 1024) * k.pix_bytes < 0x7fffffffLL;
 }
 
@@ -1382,12 +1402,13 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
         // profiles/r01_tile_tuning_patch3x3.txt: layer1 conv2 0.462 -> 0.375 ms (256x64), layer2 0.343 -> 0.300 (128x128, 4 waves with 64x64
         // wave tiles), layer3 0.242 -> 0.244 and layer4 0.232 -> 0.230 (256x256: even); ResNet-50 bench, alternating runs on one box:
         // 67.8 k frames/s generic, 68.5 k mode 2, 69.0 k mode 3).  MT4_PATCH3X3: 0 = generic tiles only, 1 = patch kernel for Cout <= 64 and the
-        // two-stage generic 256x128 tile for Cout <= 128, 2 = patch tiles 24 / 26 / 23, 3 = default: 24 / 30 / 23
+        // two-stage generic 256x128 tile for Cout <= 128, 2 = patch tiles 24 / 26 / 23, 3 = default: 24 / 30 (32 for rows wider than 31) / 23
         static const int mode = getenv("MT4_PATCH3X3") ? atoi(getenv("MT4_PATCH3X3")) : 3;
         int pt = 0;
         if (mode == 1) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? 18 : 0;
         else if (mode == 2) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? 26 : 23;
-        else if (mode >= 3) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? 30 : 23;
+        else if (mode >= 3) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? (d->W <= 31 ? 30 : 32) : 23;   // (128-row tiles only while the 2W+2 halo stays small:
+                                                                                                    //  W = 56 at 256x448 frames: t30 0.475 ms, t32 0.310, generic 0.325)
         if (pt >= 21) {
             const int rc = launch_patch_tile(k, pt, s);
             if (rc != MT4_EUNSUPPORTED) return rc;   // (patch too large for LDS: generic tiles)

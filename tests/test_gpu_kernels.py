@@ -97,12 +97,16 @@ def test_conv3x3_patch_kernel(cuda, shape, tile):
             _conv_case(cuda, B, H, W, Cin, Cout, 3, 3, (1, 1), (1, 1), (1, 1), torch.bfloat16, relu=False, use_res=False, tile=tile, seed=21)
         return
     for relu in (False, True):
-        _conv_case(cuda, B, H, W, Cin, Cout, 3, 3, (1, 1), (1, 1), (1, 1), torch.bfloat16, relu=relu, use_res=False, tile=tile, seed=21 + relu)
+        _conv_case(cuda, B, H, W, Cin, Cout, 3, 3, (1, 1), (1, 1), (1, 1), torch.bfloat16, relu=relu, use_res=relu, tile=tile, seed=21 + relu)
     x = _rand((B, H, W, Cin), 31).to(cuda, torch.bfloat16)
     wp = ops.pack_conv_weight(_rand((Cout, Cin, 3, 3), 32, 0.05).to(cuda), None, torch.bfloat16)
     bias = _rand((Cout,), 33, 0.1).to(cuda)
     ref = ops.conv_nhwc(x, wp, bias, kh=3, kw=3, pad=(1, 1), relu=True, tile=2)
     got = ops.conv_nhwc(x, wp, bias, kh=3, kw=3, pad=(1, 1), relu=True, tile=tile)
+    assert torch.equal(ref.view(torch.int16), got.view(torch.int16))
+    res = _rand((B, H, W, Cout), 34).to(cuda, torch.bfloat16)   # the second conv of a BasicBlock: + identity, then ReLU
+    ref = ops.conv_nhwc(x, wp, bias, kh=3, kw=3, pad=(1, 1), residual=res, relu=True, tile=2)
+    got = ops.conv_nhwc(x, wp, bias, kh=3, kw=3, pad=(1, 1), residual=res, relu=True, tile=tile)
     assert torch.equal(ref.view(torch.int16), got.view(torch.int16))
 
 
