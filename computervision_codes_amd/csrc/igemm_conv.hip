@@ -1192,7 +1192,6 @@ int launch_patch_tile(const ConvK& k, int tile, hipStream_t s) {
         case 31: return launch_patch3x3<256, 64, 4, 1, 2>(k, s);
         case 32: return launch_patch3x3<256, 128, 4, 2, 2>(k, s);
     }
-    (void)0;
     return MT4_EINVAL;
 }
 
