@@ -1065,10 +1065,13 @@ struct TileCfg {
 //   21: 256x64/8/4   22: 256x128/16/3   23: 256x256/16/2   24: 256x64/8/2   25: 256x128/16/4   26: 256x128/16/2
 //   27: 256x64/8/all 9 taps resident   28: 512x64/16/resident   29: 128x64/4/2   30: 128x128/4/2   31: 256x64/4/2   32: 256x128/8/2
 //   (auto: 24, 30, 23 by Cout; the others are the tuning record: deeper rings and the barrier-free resident variants are slower)
-constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {64, 128}, {32, 64}, {32, 32},
-                              {128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}, {128, 64},
-                              {256, 128}, {256, 128}, {256, 256}, {128, 256}, {256, 256}, {256, 128}, {256, 128}, {256, 64},
-                              {256, 64}, {256, 128}, {256, 256}, {256, 64}, {256, 128}, {256, 128}, {256, 64}, {512, 64}, {128, 64}, {128, 128}, {256, 64}, {256, 128}, {256, 64}, {256, 64}};   // 33 / 34: stem patch kernel, persistent form; 21-32: 3x3 patch kernel (conv3x3_patch_kernel)
+constexpr TileCfg kTiles[] = {
+    {128, 128}, {128, 64}, {64, 64}, {64, 128}, {32, 64}, {32, 32},                                  // 1-6
+    {128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}, {128, 64},                                  // 7-12
+    {256, 128}, {256, 128}, {256, 256}, {128, 256}, {256, 256}, {256, 128}, {256, 128}, {256, 64},   // 13-20
+    {256, 64}, {256, 128}, {256, 256}, {256, 64}, {256, 128}, {256, 128},                            // 21-26: conv3x3_patch_kernel
+    {256, 64}, {512, 64}, {128, 64}, {128, 128}, {256, 64}, {256, 128},                              // 27-32: conv3x3_patch_kernel
+    {256, 64}, {256, 64}};                                                                           // 33 / 34: stem patch kernel, persistent form
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <typename T, int BM, int BN, int WM_, int WN_, int STAGES, bool OUT_F32>
@@ -1252,7 +1255,12 @@ int launch_stem_patch_persistent(const ConvK& k, hipStream_t s) {
     const int lds = k.KH * 64 * 128 + 2 * pbuf;
     if (lds > 160 * 1024) return MT4_EUNSUPPORTED;
     const int per_cu = (160 * 1024) / lds >= 2 ? 2 : 1;
-    static const int cus = []() { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    static const int cus = []() {
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
     int grid = cus * per_cu;
     if (grid > kk.total_tiles) grid = kk.total_tiles;
     auto fn = stem_patch_persistent_kernel<BM, 4, 2>;
@@ -1264,6 +1272,9 @@ int launch_stem_patch_persistent(const ConvK& k, hipStream_t s) {
     return mt4_check_launch();
 }
 
+// tuning override: integer value of an environment variable, read once per call site
+#define MT4_ENV_INT(name, dflt) ([]() { static const int v = getenv(name) ? atoi(getenv(name)) : (dflt); return v; }())
+
 int auto_tile(int M, int N, int nsteps, int es) {
     // Measured on MI355X over the ResNet-50 layer set (tools/tune_conv.py, profiles/r01_tile_tuning.txt):
     // long-K layers want the 128x128 tile (most MFMA per LDS byte); short-K (memory-bound) layers want the
@@ -1273,19 +1284,29 @@ int auto_tile(int M, int N, int nsteps, int es) {
     // 8-wave 256-row tiles (bf16, profiles/r01_tile_tuning_8wave.txt): one workgroup per CU with the same 2 waves per SIMD, but
     // 0.5-0.75x the operand bytes per FLOP through L2 -> LDS-DMA, whose issue cost is what the K-loop waits on
     if (es == 2 && N >= 256) {   // (fp32 launches are bound by the fp32 MFMA rate: the same tiles change nothing there, same-box A/B)
-        if (nsteps == 1 && tiles(13) >= fill) { static const int t1 = getenv("MT4_TILE1STEP") ? atoi(getenv("MT4_TILE1STEP")) : 13; return t1; }
-        if (nsteps >= 2 && tiles(15) >= 190) { static const int t256 = getenv("MT4_TILE256") ? atoi(getenv("MT4_TILE256")) : 17; return t256; }
+        if (nsteps == 1 && tiles(13) >= fill) return MT4_ENV_INT("MT4_TILE1STEP", 13);
+        if (nsteps >= 2 && tiles(15) >= 190) return MT4_ENV_INT("MT4_TILE256", 17);
     }
-    if (es == 2 && N > 64 && N <= 128 && nsteps < 4 && tiles(20) >= 8 * fill) { static const int t128s = getenv("MT4_TILE128S") ? atoi(getenv("MT4_TILE128S")) : 20; if (t128s) return t128s; }   // short K: 256x64 (Swin stage-1 proj)
-    if (es == 2 && N > 64 && N <= 128 && nsteps >= 4 && tiles(19) >= 8 * fill) { static const int t128 = getenv("MT4_TILE128") ? atoi(getenv("MT4_TILE128")) : 19; if (t128) return t128; }   // 16-wave 256x128, 3 stages; many rounds: small tail
-    if (nsteps == 1 && tiles(3) >= 4 * fill) { static const int t1s = getenv("MT4_TILE1STEP_SMALL") ? atoi(getenv("MT4_TILE1STEP_SMALL")) : 3; return t1s; }   // single K-step: smallest footprint, most workgroups per CU
+    if (es == 2 && N > 64 && N <= 128 && nsteps < 4 && tiles(20) >= 8 * fill) {   // short K: 256x64 (Swin stage-1 proj)
+        const int t = MT4_ENV_INT("MT4_TILE128S", 20);
+        if (t) return t;
+    }
+    if (es == 2 && N > 64 && N <= 128 && nsteps >= 4 && tiles(19) >= 8 * fill) {   // 16-wave 256x128, 3 stages; many rounds: small tail
+        const int t = MT4_ENV_INT("MT4_TILE128", 19);
+        if (t) return t;
+    }
+    // single K-step: smallest footprint, most workgroups per CU
+    if (nsteps == 1 && tiles(3) >= 4 * fill) return MT4_ENV_INT("MT4_TILE1STEP_SMALL", 3);
     if (N > 64) {
         if (nsteps >= 4 && tiles(1) >= fill) return 1;
         if (tiles(4) >= fill) return 4;
         if (tiles(1) >= fill) return 1;
     } else if (N > 32) {
         // 64-channel layers at many rounds: 256 pixels x 64 channels, 8 waves (+2.8 % frames/s, same-box A/B; MT4_TILE64=0 disables)
-        { static const int t64 = getenv("MT4_TILE64") ? atoi(getenv("MT4_TILE64")) : 20; if (t64 && es == 2 && tiles(20) >= 8 * fill) return t64; }
+        {
+            const int t64 = MT4_ENV_INT("MT4_TILE64", 20);
+            if (t64 && es == 2 && tiles(20) >= 8 * fill) return t64;
+        }
         if (tiles(2) >= fill) return 2;
         if (tiles(3) >= fill) return 3;
     }
@@ -1388,7 +1409,7 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (tile == 33 || tile == 34 || (tile == 0 && stem_patch_ok(d, k, fast) && getenv("MT4_NO_STEM_PATCH") == nullptr)) {   // the space-to-depth stem
         if (!stem_patch_ok(d, k, fast)) return MT4_EUNSUPPORTED;
-        static const int persistent = getenv("MT4_STEM_PERSISTENT") ? atoi(getenv("MT4_STEM_PERSISTENT")) : 0;
+        const int persistent = MT4_ENV_INT("MT4_STEM_PERSISTENT", 0);
         const int rc = (tile == 34 || (tile == 0 && persistent)) ? launch_stem_patch_persistent(k, s) : launch_stem_patch(k, s);
         if (rc != MT4_EUNSUPPORTED || tile != 0) return rc;
     }
@@ -1402,12 +1423,12 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
         // wave tiles), layer3 0.242 -> 0.244 and layer4 0.232 -> 0.230 (256x256: even); ResNet-50 bench, alternating runs on one box:
         // 67.8 k frames/s generic, 68.5 k mode 2, 69.0 k mode 3).  MT4_PATCH3X3: 0 = generic tiles only, 1 = patch kernel for Cout <= 64 and the
         // two-stage generic 256x128 tile for Cout <= 128, 2 = patch tiles 24 / 26 / 23, 3 = default: 24 / 30 (32 for rows wider than 31) / 23
-        static const int mode = getenv("MT4_PATCH3X3") ? atoi(getenv("MT4_PATCH3X3")) : 3;
+        const int mode = MT4_ENV_INT("MT4_PATCH3X3", 3);
         int pt = 0;
         if (mode == 1) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? 18 : 0;
         else if (mode == 2) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? 26 : 23;
-        else if (mode >= 3) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? (d->W <= 31 ? 30 : 32) : 23;   // (128-row tiles only while the 2W+2 halo stays small:
-                                                                                                    //  W = 56 at 256x448 frames: t30 0.475 ms, t32 0.310, generic 0.325)
+        else if (mode >= 3)   // (128-row tiles only while the 2W+2 halo stays small: W = 56 at 256x448 frames: t30 0.475 ms, t32 0.310, generic 0.325)
+            pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? (d->W <= 31 ? 30 : 32) : 23;
         if (pt >= 21) {
             const int rc = launch_patch_tile(k, pt, s);
             if (rc != MT4_EUNSUPPORTED) return rc;   // (patch too large for LDS: generic tiles)
