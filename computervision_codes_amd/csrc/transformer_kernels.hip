@@ -298,6 +298,126 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
     }
 }
 
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// ---- multi-head attention core on the matrix units, large head dim (Q2L encoder / decoders: 4 heads x 256, 144 keys): bf16, no
+// bias / mask, Nk <= 16*NKT keys.  One workgroup = 64 queries of one (batch, head), a wave owns 16 of them.  As in the window kernel,
+// S^T = K Q^T leaves a lane with ONE query column (softmax = 2 xor-shuffles) and the probabilities are already the B operand of
+// O^T = V^T P^T.  The head dim runs through LDS in chunks of 64: K rows [key][64] for the scores, then V^T [64][key] for the output;
+// the wave's Q fragments (16 queries x HD, pre-scaled) stay in registers.
+template <int NKT, int HD>
+__global__ __launch_bounds__(256) void mha_mfma_kernel(const u16* __restrict__ q, const u16* __restrict__ k, const u16* __restrict__ v,
+                                                       u16* __restrict__ out, int Nq, int Nk, int q_stride, int k_stride, int v_stride,
+                                                       int o_stride, float scale) {
+    constexpr int NKP = NKT * 16;
+    constexpr int NKP2 = ((NKT + 1) / 2) * 32;   // keys padded to whole 32-key MFMA blocks
+    constexpr int K_PITCH = 144;                 // bytes per K row of a chunk (128 used): 16-lane b128 reads conflict-free
+    constexpr int VT_PITCH = (NKP2 + 8) * 2;     // bytes per V^T row
+    constexpr int NCH = HD / 64;
+    static_assert(HD % 64 == 0 && NKP * K_PITCH <= 64 * VT_PITCH + NKP * K_PITCH, "shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                    // [NKP][K_PITCH]
+    char* Vt = smem + NKP * K_PITCH;    // [64][VT_PITCH]
+    const int h = blockIdx.x, b = blockIdx.y, q0 = blockIdx.z * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, qd = lane >> 4;
+    const int query = q0 + wave * 16 + r16;
+    const bool q_ok = query < Nq;
+
+    // Q fragments: k-slot block kk (32 dims) of this lane's query, dims 32kk + 8qd .. +7
+    bf16x8_t qf[HD / 32];
+    {
+        const u16* qp = q + ((long long)b * Nq + (q_ok ? query : 0)) * q_stride + h * HD + qd * 8;
+#pragma unroll
+        for (int kk = 0; kk < HD / 32; ++kk) {
+            uint4 t = q_ok ? *(const uint4*)(qp + kk * 32) : make_uint4(0, 0, 0, 0);
+            uint32_t* u = (uint32_t*)&t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) u[i] = pack_bf16x2(__uint_as_float(u[i] << 16) * scale, __uint_as_float(u[i] & 0xffff0000u) * scale);
+            qf[kk] = __builtin_bit_cast(bf16x8_t, t);
+        }
+    }
+    f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NCH; ++c) {
+        if (c) __syncthreads();
+        for (int e = tid; e < NKP * 8; e += 256) {   // K chunk: rows of 64 dims = 8 pieces of 16 B
+            const int row = e >> 3, pc = e & 7;
+            uint4 kv = make_uint4(0, 0, 0, 0);
+            if (row < Nk) kv = *(const uint4*)(k + ((long long)b * Nk + row) * k_stride + h * HD + c * 64 + pc * 8);
+            *(uint4*)(Ks + row * K_PITCH + pc * 16) = kv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Ks + (kt * 16 + r16) * K_PITCH + kk * 64 + qd * 16));
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[c * 2 + kk], s[kt], 0, 0, 0);
+            }
+    }
+    // softmax over the keys of this lane's query column: lane holds keys 16kt + 4qd .. +3
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (kt * 16 + qd * 4 + e >= Nk) s[kt][e] = -1e30f;
+            mx = fmaxf(mx, s[kt][e]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[kt][e] = __expf(s[kt][e] - mx); sum += s[kt][e]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    uint4 pf[(NKT + 1) / 2];   // probabilities as the B operand: k-slots 8qd..8qd+7 of block kb = keys 32kb + 4qd .. +3 and 32kb + 16 + 4qd .. +3
+#pragma unroll
+    for (int kb = 0; kb < (NKT + 1) / 2; ++kb) {
+        const int k0 = 2 * kb, k1 = 2 * kb + 1;
+        pf[kb].x = pack_bf16x2(s[k0][0], s[k0][1]);
+        pf[kb].y = pack_bf16x2(s[k0][2], s[k0][3]);
+        if (k1 < NKT) { pf[kb].z = pack_bf16x2(s[k1][0], s[k1][1]); pf[kb].w = pack_bf16x2(s[k1][2], s[k1][3]); }
+        else { pf[kb].z = 0; pf[kb].w = 0; }
+    }
+    for (int c = 0; c < NCH; ++c) {
+        __syncthreads();   // previous chunk's (or the K chunk's) readers are done
+        for (int e = tid; e < NKP2 * 8; e += 256) {   // V chunk, transposed: Vt[d][key]
+            const int row = e >> 3, pc = e & 7;
+            uint4 vv = make_uint4(0, 0, 0, 0);
+            if (row < Nk) vv = *(const uint4*)(v + ((long long)b * Nk + row) * v_stride + h * HD + c * 64 + pc * 8);
+            const u16* ve = (const u16*)&vv;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *(u16*)(Vt + (pc * 8 + i) * VT_PITCH + row * 2) = ve[i];
+        }
+        __syncthreads();
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < (NKT + 1) / 2; ++kb)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const char* vr = Vt + (dt * 16 + r16) * VT_PITCH + (kb * 32 + qd * 4) * 2;
+                const uint2 v0 = *(const uint2*)vr;
+                const uint2 v1 = *(const uint2*)(vr + 32);
+                const uint4 vf = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[kb]), o[dt], 0, 0, 0);
+            }
+        if (q_ok) {   // lane (r16 = query, qd): dims 64c + 16dt + 4qd .. +3
+            u16* op = out + ((long long)b * Nq + query) * o_stride + h * HD + c * 64 + qd * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *(uint2*)(op + dt * 16) = make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+        }
+    }
+}
+
 extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* out, const float* bias, const float* mask,
                              int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t hd, int32_t q_stride, int32_t k_stride,
                              int32_t v_stride, int32_t o_stride, int32_t nW, float scale, int32_t dtype, void* stream) {
@@ -311,6 +431,25 @@ extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* 
     const int vec_ok = (hd % 4 == 0) && (k_stride * es) % (4 * es) == 0 && (v_stride * es) % (4 * es) == 0 &&
                        (((uintptr_t)k | (uintptr_t)v) & (4 * es - 1)) == 0;
     hipStream_t s = (hipStream_t)stream;
+    // large head dim, bf16, no bias / mask, keys fit one workgroup's score registers: matrix-unit kernel (MT4_NO_MHA_MFMA=1: VALU kernel)
+    if (dtype == MT4_BF16 && hd == 256 && !bias && !mask && Nk <= 160 && (q_stride % 8) == 0 && (k_stride % 8) == 0 && (v_stride % 8) == 0 &&
+        (o_stride % 4) == 0 && ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0) && (((uintptr_t)out & 7) == 0) && cdiv(Nq, 64) <= 65535) {
+        static const bool off = getenv("MT4_NO_MHA_MFMA") != nullptr;
+        if (!off) {
+            const int nkt = cdiv(Nk, 16);
+            const dim3 grid(H, B, cdiv(Nq, 64)), block(256);
+#define MHA_LAUNCH(NKTV) { constexpr int nkp = NKTV * 16, nkp2 = ((NKTV + 1) / 2) * 32; const size_t lds = (size_t)nkp * 144 + 64 * ((nkp2 + 8) * 2); \
+            hipLaunchKernelGGL((mha_mfma_kernel<NKTV, 256>), grid, block, lds, s, (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, Nq, Nk, \
+                               q_stride, k_stride, v_stride, o_stride, scale); }
+            switch (nkt) {
+                case 1: MHA_LAUNCH(1) break; case 2: MHA_LAUNCH(2) break; case 3: MHA_LAUNCH(3) break; case 4: MHA_LAUNCH(4) break;
+                case 5: MHA_LAUNCH(5) break; case 6: MHA_LAUNCH(6) break; case 7: MHA_LAUNCH(7) break; case 8: MHA_LAUNCH(8) break;
+                case 9: MHA_LAUNCH(9) break; default: MHA_LAUNCH(10) break;
+            }
+#undef MHA_LAUNCH
+            return mt4_check_launch();
+        }
+    }
     // (DPL, LPQ) with DPL*LPQ >= hd, fewest lanes per query first
     static const int cfgs[][2] = {{32, 1}, {24, 2}, {32, 2}, {20, 4}, {28, 4}, {32, 4}, {32, 8},
                                   {4, 8}, {8, 8}, {12, 8}, {16, 8}, {24, 8}};   // 8 lanes per query, few dims per lane

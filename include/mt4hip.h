@@ -152,7 +152,8 @@ int mt4_layernorm(const void* x, const float* gamma, const float* beta, void* y,
  * mask [nW][Nq][Nk] are float32 or NULL.  Replaces WindowAttention's core (swin_transformer.py:120-141, with the
  * relative-position bias gathered to dense form at load time and the -100 shift mask), nn.MultiheadAttention's
  * core in the Q2L transformer (transformer.py:186-189,275-283) and Global_Relational_Block (Temporal_Encoder.py:
- * 80-86).  hd <= 256. */
+ * 80-86).  hd <= 256.  bf16 with hd == 256, no bias / mask and Nk <= 160 runs on the matrix units (probabilities rounded to bf16
+ * before the PV product, like the window kernel). */
 int mt4_attention(const void* q, const void* k, const void* v, void* out, const float* bias, const float* mask, int32_t B,
                   int32_t H, int32_t Nq, int32_t Nk, int32_t hd, int32_t q_stride, int32_t k_stride, int32_t v_stride,
                   int32_t o_stride, int32_t nW, float scale, int32_t dtype, void* stream);

@@ -105,6 +105,28 @@ def test_attention_core(cuda, cfg, dtype):
     assert (out.float().cpu() - ref).abs().max().item() < _tol(dtype, 2e-5, 2e-2)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk", [(3, 4, 144, 144), (2, 4, 100, 144), (5, 4, 6, 144), (2, 2, 15, 49), (1, 4, 70, 160), (2, 1, 10, 7)])
+def test_mha_mfma_head_dim_256(cuda, B, H, Nq, Nk):
+    """the matrix-unit core behind `mt4_attention` for bf16, head dim 256, no bias / mask (Q2L encoder self-attention and decoder
+    cross-attention, `transformer.py:186-189,275-283`): fp32 oracle on the same bf16-rounded q/k/v; ragged query blocks and key tiles"""
+    from computervision_codes_amd import ops
+    hd = 256
+    c = H * hd
+    q = _rand((B * Nq, c), 81, 1.0).to(torch.bfloat16)
+    kv = _rand((B * Nk, 2 * c), 82, 1.0).to(torch.bfloat16)
+    scale = hd ** -0.5
+    qd, kvd = q.to(cuda), kv.to(cuda)
+    out = ops.attention(qd, kvd[:, :c], kvd[:, c:], batch=B, heads=H, nq=Nq, nk=Nk, hd=hd, q_stride=c, k_stride=2 * c, v_stride=2 * c, scale=scale)
+    sp = lambda t, n: t.float().reshape(B, n, H, hd).permute(0, 2, 1, 3)
+    ref = _attn_ref(sp(q, Nq), sp(kv[:, :c], Nk), sp(kv[:, c:], Nk), scale, None, None, 0).permute(0, 2, 1, 3).reshape(B * Nq, c)
+    assert torch.isfinite(out.float()).all()
+    assert (out.float().cpu() - ref).abs().max().item() < 2e-2
+    # sharper scores (a few keys dominate): the probabilities' bf16 rounding shows most here
+    out2 = ops.attention(qd, kvd[:, :c], kvd[:, c:], batch=B, heads=H, nq=Nq, nk=Nk, hd=hd, q_stride=c, k_stride=2 * c, v_stride=2 * c, scale=1.0)
+    ref2 = _attn_ref(sp(q, Nq), sp(kv[:, :c], Nk), sp(kv[:, c:], Nk), 1.0, None, None, 0).permute(0, 2, 1, 3).reshape(B * Nq, c)
+    assert (out2.float().cpu() - ref2).abs().max().item() < 2e-2
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_linear_gelu_rowmap_and_column_slices(cuda, dtype):
     from computervision_codes_amd import ops
