@@ -418,6 +418,121 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const u16* __restrict__ q
     }
 }
 
+// ---- the same core in fp32 on the exact-fp32 matrix instruction (16x16x4): MS-TCT's Global_Relational_Block (`Temporal_Encoder.py:80-86`:
+// 8 heads x 32..108 dims over T <= 256 frames) in the parity mode.  The contraction index of a product may be permuted freely as long as
+// both operands agree, so within a group of 16 dims MFMA j takes dim 4*qd + j from lane group qd: a lane's 4 slots are 4 CONSECUTIVE
+// floats = one 16-byte read (K rows, Q registers); likewise the 4 MFMAs of a 16-key tile take key 4*qd + e, which is what a lane of the
+// score tile already holds.  Head dims run through LDS in chunks of 32 (K rows, then V^T), zero-padded to whole groups.
+template <int NKT>
+__global__ __launch_bounds__(256) void mha_mfma_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                           float* __restrict__ out, int Nq, int Nk, int hd, int q_stride, int k_stride,
+                                                           int v_stride, int o_stride, float scale) {
+    constexpr int NKP = NKT * 16;
+    constexpr int K_PITCH = 36;          // floats per K row of a chunk (32 used): 16 rows x b128 cover the 64 banks once
+    constexpr int VT_PITCH = NKP + 4;    // floats per V^T row: = 4 mod 64 for NKP = 128, 256
+    constexpr int MAXG = 8;              // hd <= 128: at most 8 groups of 16 dims
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ks = (float*)smem;            // [NKP][K_PITCH]; the V^T chunk [32][VT_PITCH] reuses the space
+    float* Vt = (float*)smem;
+    const int h = blockIdx.x, b = blockIdx.y, q0 = blockIdx.z * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, qd = lane >> 4;
+    const int query = q0 + wave * 16 + r16;
+    const bool q_ok = query < Nq;
+    const int nch = (hd + 31) / 32;
+
+    float4 qf[MAXG];
+    {
+        const float* qp = q + ((long long)b * Nq + (q_ok ? query : 0)) * q_stride + h * hd;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            const int d = g * 16 + qd * 4;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q_ok && d < hd) t = *(const float4*)(qp + d);
+            qf[g] = make_float4(t.x * scale, t.y * scale, t.z * scale, t.w * scale);
+        }
+    }
+    f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < MAXG / 2; ++c) {
+        if (c < nch) {   // (uniform)
+            if (c) __syncthreads();
+            for (int e = tid; e < NKP * 8; e += 256) {   // K chunk: rows of 32 dims = 8 pieces of 4 floats
+                const int row = e >> 3, pc = e & 7;
+                const int d = c * 32 + pc * 4;
+                float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < Nk && d < hd) kv = *(const float4*)(k + ((long long)b * Nk + row) * k_stride + h * hd + d);
+                *(float4*)(Ks + row * K_PITCH + pc * 4) = kv;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const float4 kf = *(const float4*)(Ks + (kt * 16 + r16) * K_PITCH + g * 16 + qd * 4);
+                    const float4 qv = qf[c * 2 + g];
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qv.x, s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qv.y, s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qv.z, s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qv.w, s[kt], 0, 0, 0);
+                }
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (kt * 16 + qd * 4 + e >= Nk) s[kt][e] = -1e30f;
+            mx = fmaxf(mx, s[kt][e]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[kt][e] = __expf(s[kt][e] - mx); sum += s[kt][e]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    for (int c = 0; c < nch; ++c) {
+        __syncthreads();
+        for (int e = tid; e < NKP * 8; e += 256) {   // V chunk, transposed: Vt[d][key]
+            const int row = e >> 3, pc = e & 7;
+            const int d = c * 32 + pc * 4;
+            float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < Nk && d < hd) vv = *(const float4*)(v + ((long long)b * Nk + row) * v_stride + h * hd + d);
+            Vt[(pc * 4 + 0) * VT_PITCH + row] = vv.x;
+            Vt[(pc * 4 + 1) * VT_PITCH + row] = vv.y;
+            Vt[(pc * 4 + 2) * VT_PITCH + row] = vv.z;
+            Vt[(pc * 4 + 3) * VT_PITCH + row] = vv.w;
+        }
+        __syncthreads();
+        f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const float4 vf = *(const float4*)(Vt + (dt * 16 + r16) * VT_PITCH + kt * 16 + qd * 4);   // keys 16kt + 4qd .. +3 of dim row r16
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, s[kt][0], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, s[kt][1], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, s[kt][2], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, s[kt][3], o[dt], 0, 0, 0);
+            }
+        if (q_ok) {   // lane (r16 = query, qd): dims 32c + 16dt + 4qd .. +3
+            float* op = out + ((long long)b * Nq + query) * o_stride + h * hd;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int d = c * 32 + dt * 16 + qd * 4;
+                if (d < hd) *(float4*)(op + d) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+            }
+        }
+    }
+}
+
 extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* out, const float* bias, const float* mask,
                              int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t hd, int32_t q_stride, int32_t k_stride,
                              int32_t v_stride, int32_t o_stride, int32_t nW, float scale, int32_t dtype, void* stream) {
@@ -449,6 +564,22 @@ extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* 
 #undef MHA_LAUNCH
             return mt4_check_launch();
         }
+    }
+    // fp32 (parity mode), no bias / mask, <= 256 keys, head dim <= 128: exact-fp32 matrix-unit kernel (MS-TCT's global block)
+    if (dtype == MT4_F32 && hd <= 128 && (hd % 4) == 0 && !bias && !mask && Nk <= 256 && (q_stride % 4) == 0 && (k_stride % 4) == 0 &&
+        (v_stride % 4) == 0 && (o_stride % 4) == 0 && ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0) &&
+        cdiv(Nq, 64) <= 65535 && getenv("MT4_NO_MHA_MFMA") == nullptr) {
+        const dim3 grid(H, B, cdiv(Nq, 64)), block(256);
+        if (Nk <= 128) {
+            const size_t lds = sizeof(float) * (size_t)(128 * 36 > 32 * 132 ? 128 * 36 : 32 * 132);
+            hipLaunchKernelGGL((mha_mfma_f32_kernel<8>), grid, block, lds, s, (const float*)q, (const float*)k, (const float*)v, (float*)out, Nq, Nk, hd,
+                               q_stride, k_stride, v_stride, o_stride, scale);
+        } else {
+            const size_t lds = sizeof(float) * (size_t)(256 * 36 > 32 * 260 ? 256 * 36 : 32 * 260);
+            hipLaunchKernelGGL((mha_mfma_f32_kernel<16>), grid, block, lds, s, (const float*)q, (const float*)k, (const float*)v, (float*)out, Nq, Nk, hd,
+                               q_stride, k_stride, v_stride, o_stride, scale);
+        }
+        return mt4_check_launch();
     }
     // (DPL, LPQ) with DPL*LPQ >= hd, fewest lanes per query first
     static const int cfgs[][2] = {{32, 1}, {24, 2}, {32, 2}, {20, 4}, {28, 4}, {32, 4}, {32, 8},

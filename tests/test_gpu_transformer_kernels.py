@@ -127,6 +127,24 @@ def test_mha_mfma_head_dim_256(cuda, B, H, Nq, Nk):
     assert (out2.float().cpu() - ref2).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,hd", [(1, 8, 256, 256, 32), (1, 8, 256, 256, 48), (1, 8, 256, 256, 72), (1, 8, 256, 256, 108),
+                                           (2, 3, 100, 77, 108), (1, 2, 70, 130, 20), (3, 1, 5, 16, 128), (1, 8, 37, 37, 72)])
+def test_mha_mfma_fp32(cuda, B, H, Nq, Nk, hd):
+    """the exact-fp32 matrix-unit core behind `mt4_attention` (fp32, no bias / mask, <= 256 keys, head dim <= 128: MS-TCT's
+    Global_Relational_Block, `Temporal_Encoder.py:80-86`, incl. the short last chunk of a video) against the fp32 oracle"""
+    from computervision_codes_amd import ops
+    c = H * hd
+    qkv = _rand((B * max(Nq, Nk), 3 * c), 91, 1.5)
+    d = qkv.to(cuda)
+    scale = hd ** -0.5
+    out = ops.attention(d[:B * Nq, :c], d[:B * Nk, c:2 * c], d[:B * Nk, 2 * c:], batch=B, heads=H, nq=Nq, nk=Nk, hd=hd, q_stride=3 * c, k_stride=3 * c,
+                        v_stride=3 * c, scale=scale)
+    sp = lambda t, n: t.reshape(B, n, H, hd).permute(0, 2, 1, 3)
+    ref = _attn_ref(sp(qkv[:B * Nq, :c], Nq), sp(qkv[:B * Nk, c:2 * c], Nk), sp(qkv[:B * Nk, 2 * c:], Nk), scale, None, None, 0)
+    ref = ref.permute(0, 2, 1, 3).reshape(B * Nq, c)
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_linear_gelu_rowmap_and_column_slices(cuda, dtype):
     from computervision_codes_amd import ops
