@@ -93,13 +93,20 @@ struct ConvK {
                             // same-box A/B on the ResNet-50 bench: +2.6 % frames/s).  MT4_NO_NT=1 switches it off
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool FAST, bool OUT_F32>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(const ConvK a) {
+// KS > 1 (FAST only): the workgroup holds KS groups of WAVES_M x WAVES_N waves; group g runs the K-steps g, g+KS, ... of the SAME output
+// tile through its own operand stages and the partial tiles are added in LDS in the fixed order g = 0, 1, ... before the epilogue
+// (deterministic, independent of the batch).  For launches with few tiles and a long K (a TCN layer over one short video: 128 workgroups,
+// 48 K-steps) the K loop -- one barrier and one DMA round trip per step -- is the launch's critical path; this cuts it KS-fold.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool FAST, bool OUT_F32, int KS = 1>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel(const ConvK a) {
     constexpr int ES = (int)sizeof(T);
     constexpr int ROWS = BM + BN;
-    constexpr int NW = WAVES_M * WAVES_N;   // 4 waves, or 8 for the 256-row tiles (1 workgroup per CU, same 2 waves per SIMD)
+    constexpr int NWG = WAVES_M * WAVES_N;  // waves of one group
+    constexpr int NW = NWG * KS;            // 4 waves, or 8 / 16 for the 256-row tiles (1 workgroup per CU)
     constexpr int NTH = NW * 64;
-    constexpr int RPP = NTH / 8;            // operand rows one staging pass of the workgroup covers (8 lanes per 128-B row)
+    constexpr int GTH = NWG * 64;
+    constexpr int RPP = GTH / 8;            // operand rows one staging pass of a group covers (8 lanes per 128-B row)
+    static_assert(KS == 1 || FAST, "K-split groups exist on the LDS-DMA path only");
     constexpr int NLD = ROWS / RPP;
     constexpr int NLD_X = BM / RPP;
     constexpr int NLD_W = BN / RPP;
@@ -112,7 +119,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int grp = KS > 1 ? wave / NWG : 0;         // K-split group of this wave
+    const int wave_l = KS > 1 ? wave % NWG : wave;   // wave within its group
+    const int tid_l = KS > 1 ? tid % GTH : tid;
+    const int wave_m = wave_l / WAVES_N, wave_n = wave_l % WAVES_N;
     const int r16 = lane & 15, q = lane >> 4;
 
     // ---- block -> tile, XCD-contiguous (bijective for any grid size), channel tile fastest: the column tiles of a
@@ -131,16 +141,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
     const int tile_n = bid - tile_m * a.n_tiles;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int ld_row = tid >> 3, ld_chunk = tid & 7;
+    const int ld_row = tid_l >> 3, ld_chunk = tid_l & 7;
     const int st_off = ld_row * 128 + ((ld_chunk ^ (ld_row & 7)) << 4);
 
-    // the accumulators start at the bias of their 4 channels: no bias add in the epilogue
+    // the accumulators start at the bias of their 4 channels: no bias add in the epilogue (K-split: group 0 only)
     f32x4 acc[NT][MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int n = n0 + wave_n * WN + i * 16 + q * 4;
         f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
+        if (a.bias && grp == 0) {
             if ((a.Cout & 3) == 0) {
                 if (n < a.Cout) { const float4 t = *(const float4*)(a.bias + n); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
             } else {
@@ -209,8 +219,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
         const v4u rsw = make_srd(a.w, a.w_bytes);
         constexpr unsigned OOB = 0x80000000u;
         const int gch = ld_chunk ^ (ld_row & 7);
-        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-        const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave_l);
+        const int grp_u = __builtin_amdgcn_readfirstlane(grp);
+        char* const smem_g = smem + grp_u * (STAGES * STAGE_BYTES);   // this group's ring of operand stages
+        const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_g;
         int xoff[NLD_X];
         // tap validity is separable: byte i of hmask/wmask holds, for staged row i, one bit per kh / kw (KH, KW <= 8)
         unsigned hmask = 0, wmask = 0;
@@ -257,9 +269,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
             // is tap*SPT + slice).  Consecutive K-steps then read the same cache lines of x shifted by one pixel / one image row
             // and the re-read comes 1-3 steps later instead of SPT*taps later (+1.2 % frames/s, same-box A/B).
             const int wstep = (f_kh * a.KW + f_kw) * a.SPT + f_cs;
-            if (++f_kw == a.KW) {
-                f_kw = 0;
-                if (++f_kh == a.KH) { f_kh = 0; ++f_cs; }
+#pragma unroll
+            for (int adv = 0; adv < KS; ++adv) {   // this group's next K-step is KS steps on
+                if (++f_kw == a.KW) {
+                    f_kw = 0;
+                    if (++f_kh == a.KH) { f_kh = 0; ++f_cs; }
+                }
             }
             // (keep the K position in SGPRs: without this hipcc carries it in VGPRs and multiplies with v_mul_lo_u32)
             f_cs = __builtin_amdgcn_readfirstlane(f_cs);
@@ -282,20 +297,53 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
         };
         static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 2) * NLD <= 63, "wait_keep covers up to 2 groups in flight");
+        // K-split: this group walks the steps grp, grp + KS, ...; every group runs the same number of iterations (the barrier is the
+        // workgroup's), a group that has run out of steps idles through them
+        int my_steps = nsteps, iters = nsteps;
+        if constexpr (KS > 1) {
+            my_steps = (nsteps - grp_u + KS - 1) / KS;
+            iters = (nsteps + KS - 1) / KS;
+            for (int adv = 0; adv < grp_u; ++adv) {   // start at K-step grp
+                if (++f_kw == a.KW) {
+                    f_kw = 0;
+                    if (++f_kh == a.KH) { f_kh = 0; ++f_cs; }
+                }
+            }
+        }
 #pragma unroll
         for (int s0 = 0; s0 < STAGES - 1; ++s0)
-            if (s0 < nsteps) issue(s0, s0);
-        wait_keep((nsteps < STAGES - 1 ? nsteps : STAGES - 1) - 1);
+            if (s0 < my_steps) issue(s0, s0);
+        wait_keep((my_steps < STAGES - 1 ? my_steps : STAGES - 1) - 1);
         __syncthreads();
         int cur = 0, fill = STAGES - 1;   // stage being computed / stage the next issue refills
-        for (int step = 0; step < nsteps; ++step) {
-            if (step + STAGES - 1 < nsteps) issue(step + STAGES - 1, fill);
-            compute(smem + cur * STAGE_BYTES);
-            const int rem = nsteps - 1 - step;   // K-step groups still outstanding after this one
+        for (int step = 0; step < iters; ++step) {
+            if (step + STAGES - 1 < my_steps) issue(step + STAGES - 1, fill);
+            if (KS == 1 || step < my_steps) compute(smem_g + cur * STAGE_BYTES);
+            const int rem = my_steps - 1 - step;   // K-step groups still outstanding after this one
             wait_keep((rem < STAGES - 1 ? rem : STAGES - 1) - 1);
             __syncthreads();
             cur = cur + 1 == STAGES ? 0 : cur + 1;
             fill = fill + 1 == STAGES ? 0 : fill + 1;
+        }
+        if constexpr (KS > 1) {
+            // partial tiles of groups 1.. -> LDS in accumulator layout; group 0 adds them in order
+            f32x4* red = (f32x4*)smem;
+            if (grp > 0) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) red[(((grp - 1) * NWG + wave_l) * (NT * MT) + i * MT + j) * 64 + lane] = acc[i][j];
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int g = 1; g < KS; ++g)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int j = 0; j < MT; ++j) acc[i][j] += red[(((g - 1) * NWG + wave_l) * (NT * MT) + i * MT + j) * 64 + lane];
+            }
+            __syncthreads();
         }
     } else {
         // ================= register staging (generic geometry: chunk-granular tap decode, e.g. the stem) =================
@@ -415,13 +463,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
                 }
             }
             if (p) __syncthreads();
+            if (KS == 1 || grp == 0) {
 #pragma unroll
-            for (int jj = 0; jj < MTP; ++jj) {
-                const int lrow = wave_m * WMP + jj * 16 + r16;
+                for (int jj = 0; jj < MTP; ++jj) {
+                    const int lrow = wave_m * WMP + jj * 16 + r16;
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const int nl = wave_n * WN + i * 16 + q * 4;
-                    *(f32x4*)(smem + lrow * ROWB + nl * 4) = acc[i][p * MTP + jj];
+                    for (int i = 0; i < NT; ++i) {
+                        const int nl = wave_n * WN + i * 16 + q * 4;
+                        *(f32x4*)(smem + lrow * ROWB + nl * 4) = acc[i][p * MTP + jj];
+                    }
                 }
             }
             __syncthreads();
@@ -482,6 +532,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_conv_kernel(cons
         return;
     }
     // Direct path (ragged Cout, e.g. the 131-wide concatenated heads): per-element guards
+    if (KS > 1 && grp != 0) return;
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         int m = m0 + wave_m * WM + j * 16 + r16;
@@ -1071,10 +1122,11 @@ constexpr TileCfg kTiles[] = {
     {256, 128}, {256, 128}, {256, 256}, {128, 256}, {256, 256}, {256, 128}, {256, 128}, {256, 64},   // 13-20
     {256, 64}, {256, 128}, {256, 256}, {256, 64}, {256, 128}, {256, 128},                            // 21-26: conv3x3_patch_kernel
     {256, 64}, {512, 64}, {128, 64}, {128, 128}, {256, 64}, {256, 128},                              // 27-32: conv3x3_patch_kernel
-    {256, 64}, {256, 64}};                                                                           // 33 / 34: stem patch kernel, persistent form
+    {256, 64}, {256, 64},                                                                            // 33 / 34: stem patch kernel, persistent form
+    {32, 32}, {32, 64}};                                                                             // 35 / 36: generic kernel, 4 K-split groups
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <typename T, int BM, int BN, int WM_, int WN_, int STAGES, bool OUT_F32>
+template <typename T, int BM, int BN, int WM_, int WN_, int STAGES, bool OUT_F32, int KS = 1>
 int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     const int m_tiles = cdiv(k.M, BM);
     ConvK kk = k;
@@ -1095,6 +1147,17 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     constexpr int epi = BM / passes * rowb;
     constexpr int threads = WM_ * WN_ * 64;
     (void)os;
+    if constexpr (KS > 1) {   // K-split groups (LDS-DMA path only): every group has its own ring of stages
+        if (!fast) return MT4_EUNSUPPORTED;
+        constexpr int lds_ks = KS * STAGES * stage > epi ? KS * STAGES * stage : epi;
+        auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, STAGES, true, OUT_F32, KS>;
+        if (lds_ks > 65536) {
+            static bool raised = false;
+            if (!raised) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+        }
+        hipLaunchKernelGGL(fn, dim3(kk.total_tiles), dim3(threads * KS), lds_ks, s, kk);
+        return mt4_check_launch();
+    }
     const int lds = k.nsteps > 1 ? (fast ? STAGES : 2) * stage : (stage > epi ? stage : epi);
     const int grid = kk.total_tiles;  // one tile per workgroup (see PERSIST in the kernel)
     if (fast) {
@@ -1138,6 +1201,8 @@ int launch_dtype(const ConvK& k, int tile, bool fast, hipStream_t s) {
         case 18: return launch_tile<T, 256, 128, 4, 4, 2, OUT_F32>(k, fast, s);
         case 19: return launch_tile<T, 256, 128, 4, 4, 3, OUT_F32>(k, fast, s);
         case 20: return launch_tile<T, 256, 64, 4, 2, 2, OUT_F32>(k, fast, s);
+        case 35: return launch_tile<T, 32, 32, 2, 2, 2, OUT_F32, 4>(k, fast, s);   // K-split x4 (16 waves)
+        case 36: return launch_tile<T, 32, 64, 1, 4, 2, OUT_F32, 4>(k, fast, s);
     }
     return MT4_EINVAL;
 }
@@ -1405,7 +1470,9 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     k.w_bytes = (unsigned)(wb < 0x7fffffffLL ? wb : 0);
     k.SPT = fast ? k.CPT / 8 : 1;
     int tile = d->tile;
-    if (tile < 0 || tile > kNumTiles) return MT4_EINVAL;
+    if (tile < -1 || tile > kNumTiles) return MT4_EINVAL;
+    const bool latency = tile == -1;   // automatic choice, K-split tiles allowed
+    if (latency) tile = 0;
     hipStream_t s = (hipStream_t)stream;
     if (tile == 33 || tile == 34 || (tile == 0 && stem_patch_ok(d, k, fast) && getenv("MT4_NO_STEM_PATCH") == nullptr)) {   // the space-to-depth stem
         if (!stem_patch_ok(d, k, fast)) return MT4_EUNSUPPORTED;
@@ -1413,7 +1480,7 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
         const int rc = (tile == 34 || (tile == 0 && persistent)) ? launch_stem_patch_persistent(k, s) : launch_stem_patch(k, s);
         if (rc != MT4_EUNSUPPORTED || tile != 0) return rc;
     }
-    if (tile >= 21) {   // explicit request for the 3x3 patch kernel
+    if (tile >= 21 && tile <= 32) {   // explicit request for the 3x3 patch kernel
         if (!patch3x3_ok(d, k, fast)) return MT4_EUNSUPPORTED;
         return launch_patch_tile(k, tile, s);
     }
@@ -1436,7 +1503,17 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
             tile = pt;
         }
     }
-    if (tile == 0) tile = auto_tile(k.M, k.Cout, k.nsteps, d->dtype == MT4_F32 ? 4 : 2);
+    if (tile == 0) {
+        tile = auto_tile(k.M, k.Cout, k.nsteps, d->dtype == MT4_F32 ? 4 : 2);
+        // few tiles and a long K: the 4-stage ring of the small tiles (10 / 11), or -- when the caller asked for latency (tile -1) and the
+        // geometry is on the LDS-DMA path -- four K-split groups per workgroup (36 / 35); MT4_KSPLIT=0 keeps the rings
+        // (measured, 4-stage TCN: fp32 T = 256 1.23 -> 1.08 ms, config 1 0.357 -> 0.312; with more than one workgroup per CU -- T = 2000 --
+        //  the 16-wave workgroups lose 27 %, and bf16 (half the K-steps) gains nothing: fp32 launches of at most 256 tiles only)
+        if (latency && fast && d->dtype == MT4_F32 && (tile == 10 || tile == 11) && MT4_ENV_INT("MT4_KSPLIT", 1)) {
+            const int kt = tile == 11 ? 35 : 36;
+            if ((long long)cdiv(k.M, kTiles[kt - 1].bm) * cdiv(k.Cout, kTiles[kt - 1].bn) <= 256) tile = kt;
+        }
+    }
     if (d->dtype == MT4_F32) return launch_dtype<float, true>(k, tile, fast, s);
     if (d->out_dtype == MT4_F32) return launch_dtype<u16, true>(k, tile, fast, s);
     return launch_dtype<u16, false>(k, tile, fast, s);

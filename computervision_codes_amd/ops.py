@@ -1,7 +1,9 @@
 """Thin torch-tensor wrappers over the C-ABI (device memory and streams are torch's: plumbing only)."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import functools
 from typing import Optional, Tuple
 
 import torch
@@ -61,6 +63,32 @@ def conv_out_size(h: int, k: int, stride: int, pad: int, dil: int) -> int:
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
+_LATENCY_TILES = False
+
+
+@contextlib.contextmanager
+def latency_tiles():
+    """Inside this context `tile=0` launches ask for `tile=-1`: automatic choice that may take the K-split tiles (four wave groups per
+    workgroup share one output tile's K loop).  For the temporal heads -- one short video, 40+ dependent launches with few tiles and a
+    long K each -- that cuts the per-launch critical path; the K summation order then differs from the other tiles' (fp32
+    reassociation), so the spatial extractors, whose features are bit-identical whatever batch a frame rides in, do not use it."""
+    global _LATENCY_TILES
+    old, _LATENCY_TILES = _LATENCY_TILES, True
+    try:
+        yield
+    finally:
+        _LATENCY_TILES = old
+
+
+def with_latency_tiles(fn):
+    """decorator form of `latency_tiles` (the temporal heads' forward / train step)"""
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with latency_tiles():
+            return fn(*a, **k)
+    return wrapped
+
+
 def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, kh: int, kw: int,
               stride: Tuple[int, int] = (1, 1), pad: Tuple[int, int] = (0, 0), dil: Tuple[int, int] = (1, 1),
               residual: Optional[torch.Tensor] = None, relu: bool = False, out_dtype: Optional[torch.dtype] = None,
@@ -103,6 +131,8 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     if out_row_map is not None:
         assert out_row_map.dtype == torch.int32 and out_row_map.is_cuda and out_row_map.is_contiguous()
         assert (b * ho * wo) % out_row_map.numel() == 0
+    if tile == 0 and _LATENCY_TILES:
+        tile = -1
     d = ConvDesc(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
                  residual.data_ptr() if residual is not None else None, out.data_ptr(),
                  out_row_map.data_ptr() if out_row_map is not None else None,

@@ -104,6 +104,7 @@ class VideoNas:
         h = ops.dwconv1d_k3(h.view(b, t, -1), *blk["tc"], act="gelu").view(b * t, -1)
         return ops.linear(h, *blk["l2"], residual=x)
 
+    @ops.with_latency_tiles
     def forward_btd(self, x_btd: torch.Tensor):
         """x [B,T,D] (frame-major, the feature-file layout).  Returns like the reference's forward."""
         if self.training:

@@ -109,6 +109,7 @@ class VideoNas:
             x = self._layer(x, f"{prefix}.layers.{i}", 2 ** i)
         return x
 
+    @ops.with_latency_tiles
     def forward(self, x: torch.Tensor, ismask: bool = False):
         """x [B,T,D] float32 on the GPU.  Returns (out_list, out_list_i, out_list_v, out_list_t, f_list, f_list)
         with tensors shaped like the reference's ([B,K,T] logits, [B,C,T] features)."""

@@ -155,6 +155,7 @@ class TencoTrainer:
         pad = dil if c.taps == 3 else 0
         return ops.conv_nhwc(x, w, b, kh=1, kw=c.taps, pad=(0, pad), dil=(1, dil), residual=residual, act=act)
 
+    @ops.with_latency_tiles
     def train_step(self, x: torch.Tensor, labels: Dict[str, torch.Tensor], masks: Optional[dict] = None, apply_update: bool = True,
                    use_graph: bool = False):
         """x [1,T,D] fp32 on the GPU; labels {'': [T,100], '_i': [T,6], '_v': [T,10], '_t': [T,15]} multi-hot.

@@ -110,6 +110,32 @@ def test_conv3x3_patch_kernel(cuda, shape, tile):
     assert torch.equal(ref.view(torch.int16), got.view(torch.int16))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tile", [35, 36])
+def test_conv_ksplit_tiles(cuda, tile, dtype):
+    """tiles 35 / 36: four K-split wave groups per workgroup (each runs every 4th K-step of the same output tile, partial tiles added
+    in LDS in fixed order): TCN-shaped layers -- long K, few pixels -- against F.conv2d; K-step counts that do not divide by 4, a single
+    K-step, ragged T, the 131-wide heads (direct epilogue) and residual + ReLU; deterministic and independent of what else is in the batch"""
+    from computervision_codes_amd import ops
+    _conv_case(cuda, 1, 1, 256, 512, 512, 1, 3, (1, 1), (0, 4), (1, 4), dtype, relu=True, use_res=False, tile=tile, seed=51)     # 48 / 24 K-steps
+    _conv_case(cuda, 1, 1, 77, 512, 512, 1, 1, (1, 1), (0, 0), (1, 1), dtype, relu=False, use_res=True, tile=tile, seed=52)      # ragged T
+    _conv_case(cuda, 2, 1, 100, 448, 131, 1, 1, (1, 1), (0, 0), (1, 1), dtype, relu=False, use_res=False, tile=tile, seed=53)    # 14 / 7 steps, ragged Cout
+    _conv_case(cuda, 1, 1, 40, 64, 96, 1, 3, (1, 1), (0, 1), (1, 1), dtype, relu=True, use_res=True, tile=tile, seed=54)         # 6 / 3 steps
+    _conv_case(cuda, 1, 1, 40, 32 * (4 // (2 if dtype == torch.bfloat16 else 1)), 64, 1, 1, (1, 1), (0, 0), (1, 1), dtype, relu=False,
+               use_res=False, tile=tile, seed=55)                                                                             # one K-step
+    x = _rand((3, 1, 200, 512), 56).to(cuda, dtype)
+    wp = ops.pack_conv_weight(_rand((512, 512, 1, 3), 57, 0.03).to(cuda), None, dtype)
+    bias = _rand((512,), 58, 0.1).to(cuda)
+    kw = dict(kh=1, kw=3, pad=(0, 2), dil=(1, 2), relu=True)
+    a = ops.conv_nhwc(x, wp, bias, tile=tile, **kw)
+    b = ops.conv_nhwc(x, wp, bias, tile=tile, **kw)
+    one = ops.conv_nhwc(x[1:2].contiguous(), wp, bias, tile=tile, **kw)
+    assert torch.equal(a, b) and torch.equal(a[1:2], one)
+    ref = ops.conv_nhwc(x, wp, bias, tile=6, **kw)        # sequential K order: equal up to fp32 reassociation / one bf16 ulp
+    tol = 2e-5 if dtype == torch.float32 else 1.6e-2
+    assert (a.float() - ref.float()).abs().max().item() <= tol * max(1.0, ref.float().abs().max().item())
+
+
 def test_conv_input_larger_than_2gib(cuda):
     """the LDS-DMA path addresses x with 32-bit offsets from a per-tile origin: a 2.3 GB input gives the bytes of its two halves run
     separately (1x1 GEMM rows, 3x3 pad 1, strided 1x1), and takes the same time class as the halves (not the register-staged path)"""
