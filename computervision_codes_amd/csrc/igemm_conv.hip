@@ -1123,7 +1123,7 @@ constexpr TileCfg kTiles[] = {
     {256, 64}, {256, 128}, {256, 256}, {256, 64}, {256, 128}, {256, 128},                            // 21-26: conv3x3_patch_kernel
     {256, 64}, {512, 64}, {128, 64}, {128, 128}, {256, 64}, {256, 128},                              // 27-32: conv3x3_patch_kernel
     {256, 64}, {256, 64},                                                                            // 33 / 34: stem patch kernel, persistent form
-    {32, 32}, {32, 64}};                                                                             // 35 / 36: generic kernel, 4 K-split groups
+    {32, 32}, {32, 64}, {32, 32}, {32, 32}};                                                         // 35-38: generic kernel, K-split groups (4, 4, 8, 4 with 3 stages)
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <typename T, int BM, int BN, int WM_, int WN_, int STAGES, bool OUT_F32, int KS = 1>
@@ -1157,7 +1157,7 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
         }
         hipLaunchKernelGGL(fn, dim3(kk.total_tiles), dim3(threads * KS), lds_ks, s, kk);
         return mt4_check_launch();
-    }
+    } else {
     const int lds = k.nsteps > 1 ? (fast ? STAGES : 2) * stage : (stage > epi ? stage : epi);
     const int grid = kk.total_tiles;  // one tile per workgroup (see PERSIST in the kernel)
     if (fast) {
@@ -1176,6 +1176,7 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
         hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, s, kk);
     }
     return mt4_check_launch();
+    }
 }
 
 template <typename T, bool OUT_F32>
@@ -1203,6 +1204,8 @@ int launch_dtype(const ConvK& k, int tile, bool fast, hipStream_t s) {
         case 20: return launch_tile<T, 256, 64, 4, 2, 2, OUT_F32>(k, fast, s);
         case 35: return launch_tile<T, 32, 32, 2, 2, 2, OUT_F32, 4>(k, fast, s);   // K-split x4 (16 waves)
         case 36: return launch_tile<T, 32, 64, 1, 4, 2, OUT_F32, 4>(k, fast, s);
+        case 37: return launch_tile<T, 32, 32, 1, 2, 2, OUT_F32, 8>(k, fast, s);   // 8 groups of 2 waves
+        case 38: return launch_tile<T, 32, 32, 2, 2, 3, OUT_F32, 4>(k, fast, s);   // 4 groups, 3 stages each
     }
     return MT4_EINVAL;
 }
@@ -1507,10 +1510,12 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
         tile = auto_tile(k.M, k.Cout, k.nsteps, d->dtype == MT4_F32 ? 4 : 2);
         // few tiles and a long K: the 4-stage ring of the small tiles (10 / 11), or -- when the caller asked for latency (tile -1) and the
         // geometry is on the LDS-DMA path -- four K-split groups per workgroup (36 / 35); MT4_KSPLIT=0 keeps the rings
-        // (measured, 4-stage TCN: fp32 T = 256 1.23 -> 1.08 ms, config 1 0.357 -> 0.312; with more than one workgroup per CU -- T = 2000 --
-        //  the 16-wave workgroups lose 27 %, and bf16 (half the K-steps) gains nothing: fp32 launches of at most 256 tiles only)
+        // (measured, 4-stage TCN, fp32, T = 256: 1.23 ms with the rings, 1.07 with four groups, 0.96 with eight; config 1 0.357 -> 0.277;
+        //  with more than one workgroup per CU -- T = 2000 -- the 16-wave workgroups lose 27 %, and bf16 (half the K-steps) gains nothing:
+        //  fp32 launches of at most 256 tiles only)
         if (latency && fast && d->dtype == MT4_F32 && (tile == 10 || tile == 11) && MT4_ENV_INT("MT4_KSPLIT", 1)) {
-            const int kt = tile == 11 ? 35 : 36;
+            const int ksm = MT4_ENV_INT("MT4_KSPLIT", 1);   // 1: eight groups of two waves (tile 37), 2: four groups of four (35), 3: 35's 3-stage form (38)
+            const int kt = tile == 11 ? (ksm == 2 ? 35 : ksm == 3 ? 38 : 37) : 36;
             if ((long long)cdiv(k.M, kTiles[kt - 1].bm) * cdiv(k.Cout, kTiles[kt - 1].bn) <= 256) tile = kt;
         }
     }

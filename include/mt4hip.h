@@ -70,7 +70,7 @@ typedef struct mt4_conv_desc {
                            NOT added but gates the result (y = residual > 0 ? conv : 0; the saved forward activation) */
     int32_t dtype;      /* MT4_F32 / MT4_BF16 : x, w, residual */
     int32_t out_dtype;  /* MT4_F32 / MT4_BF16 : y */
-    int32_t tile;       /* 0 = auto; -1 = auto preferring latency: may take the K-split tiles 35/36 (four wave groups share a tile's K loop;
+    int32_t tile;       /* 0 = auto; -1 = auto preferring latency: may take the K-split tiles 35-38 (groups of waves share a tile's K loop;
                            the K summation order then differs from the other tiles' by fp32 reassociation -- the temporal heads use it);
                            else a tile id 1..mt4_conv_tile_count() (for tuning/tests).  Ids 21-32 (3x3 patch kernel) and 33-34
                            (space-to-depth stem kernels) cover one geometry each: MT4_EUNSUPPORTED for any other */

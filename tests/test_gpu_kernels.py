@@ -111,7 +111,7 @@ def test_conv3x3_patch_kernel(cuda, shape, tile):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", [35, 36])
+@pytest.mark.parametrize("tile", [35, 36, 37, 38])
 def test_conv_ksplit_tiles(cuda, tile, dtype):
     """tiles 35 / 36: four K-split wave groups per workgroup (each runs every 4th K-step of the same output tile, partial tiles added
     in LDS in fixed order): TCN-shaped layers -- long K, few pixels -- against F.conv2d; K-step counts that do not divide by 4, a single
