@@ -1511,7 +1511,7 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
         // few tiles and a long K: the 4-stage ring of the small tiles (10 / 11), or -- when the caller asked for latency (tile -1) and the
         // geometry is on the LDS-DMA path -- four K-split groups per workgroup (36 / 35); MT4_KSPLIT=0 keeps the rings
         // (measured, 4-stage TCN, fp32, T = 256: 1.23 ms with the rings, 1.07 with four groups, 0.96 with eight; config 1 0.357 -> 0.277;
-        //  with more than one workgroup per CU -- T = 2000 -- the 16-wave workgroups lose 27 %, and bf16 (half the K-steps) gains nothing:
+        //  with more than one workgroup per CU -- T = 2000 -- the 16-wave workgroups lose 27 %, and bf16 (half the K-steps; 0.640 -> 0.630 ms with eight groups: the 84 dependent launches are the floor) gains nothing:
         //  fp32 launches of at most 256 tiles only)
         if (latency && fast && d->dtype == MT4_F32 && (tile == 10 || tile == 11) && MT4_ENV_INT("MT4_KSPLIT", 1)) {
             const int ksm = MT4_ENV_INT("MT4_KSPLIT", 1);   // 1: eight groups of two waves (tile 37), 2: four groups of four (35), 3: 35's 3-stage form (38)
