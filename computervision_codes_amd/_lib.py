@@ -37,6 +37,15 @@ class ConvDesc(C.Structure):
     ]
 
 
+class TcnDesc(C.Structure):
+    """mirror of `mt4_tcn_desc` (include/mt4hip.h)"""
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
+        ("B", C.c_int32), ("T", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("taps", C.c_int32), ("dilation", C.c_int32), ("relu", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32),
+    ]
+
+
 _vp, _i32 = C.c_void_p, C.c_int32
 _FLOAT3 = C.c_float * 3
 
@@ -83,6 +92,10 @@ SIGNATURES = {
     "mt4_distill_kl_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _i32, _vp]),
     "mt4_mse_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, _vp]),
     "mt4_kd_mix_bwd_f32": (C.c_int, [_vp] * 9 + [_i32, _i32, _vp]),
+    "mt4_tcn_conv": (C.c_int, [C.POINTER(TcnDesc), _vp]),
+    "mt4_tcn_dilated_residual_layer": (C.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
+    "mt4_tcn_stage": (C.c_int, [_vp] * 5 + [C.POINTER(_vp)] * 4 + [_i32] * 5 + [_vp]),
+    "mt4_fpn_topdown": (C.c_int, [_vp, _vp, _i32, C.c_int64, _i32, _vp]),
 }
 
 

@@ -143,6 +143,84 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     return out
 
 
+def tcn_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, taps: int, dilation: int = 1,
+             residual: Optional[torch.Tensor] = None, relu: bool = False, out_dtype: Optional[torch.dtype] = None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Temporal-head latency path (`mt4_tcn_conv`): x [B,T,Cin] frame-major rows, w packed by `pack_conv_weight` for a 1 x taps kernel;
+    y = act(conv1d(x, w, dilation, padding = dilation*(taps-1)/2) + bias [+ residual]) -> [B,T,Cout]"""
+    _need_cuda(x, w_packed, bias, residual, out)
+    assert x.dim() == 3 and x.is_contiguous()
+    b, t, cin = x.shape
+    cout = w_packed.shape[0]
+    od = out_dtype or x.dtype
+    assert w_packed.dtype == x.dtype and w_packed.shape[1] == packed_k(cin, 1, taps, x.dtype)
+    if out is None:
+        out = torch.empty((b, t, cout), dtype=od, device=x.device)
+    else:
+        assert out.is_contiguous() and out.numel() == b * t * cout and out.dtype == od
+    if residual is not None:
+        assert residual.dtype == x.dtype and residual.is_contiguous() and residual.numel() == b * t * cout
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == cout
+    d = _lib.TcnDesc(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                     residual.data_ptr() if residual is not None else None, out.data_ptr(), b, t, cin, cout, taps, dilation,
+                     1 if relu else 0, dt_code(x.dtype), dt_code(od))
+    check(lib.mt4_tcn_conv(C.byref(d), _stream()), "mt4_tcn_conv")
+    return out
+
+
+def tcn_supported(cin: int, dtype: torch.dtype) -> bool:
+    """geometry contract of the latency path: whole 128-byte K-steps per tap"""
+    return (cin * (2 if dtype == torch.bfloat16 else 4)) % 128 == 0
+
+
+class TcnStage:
+    """pointer tables of one stage's layer stack for `mt4_tcn_stage` (built once per model; keeps the tensors alive)"""
+
+    def __init__(self, w_dilated, b_dilated, w_1x1, b_1x1):
+        self.n = len(w_dilated)
+        self._keep = (list(w_dilated), list(b_dilated), list(w_1x1), list(b_1x1))
+        arr = lambda ts: (C.c_void_p * self.n)(*[t.data_ptr() for t in ts])
+        self.wd, self.bd, self.w1, self.b1 = arr(w_dilated), arr(b_dilated), arr(w_1x1), arr(b_1x1)
+        self.dtype = w_dilated[0].dtype if self.n else torch.float32
+
+
+def tcn_stage(stage: TcnStage, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """run the stage's DilatedResidualLayers on x [B,T,C]; x is left untouched, the result goes to `out` (or a new tensor)"""
+    _need_cuda(x, out)
+    assert x.dim() == 3 and x.is_contiguous() and x.dtype == stage.dtype and stage.n >= 1
+    b, t, c = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.is_contiguous() and out.shape == x.shape and out.dtype == x.dtype
+    scratch = torch.empty((3,) + tuple(x.shape), dtype=x.dtype, device=x.device)   # h, buf_a, buf_b
+    check(lib.mt4_tcn_stage(x.data_ptr(), scratch[1].data_ptr(), scratch[2].data_ptr(), scratch[0].data_ptr(), out.data_ptr(), stage.wd,
+                            stage.bd, stage.w1, stage.b1, stage.n, b, t, c, dt_code(x.dtype), _stream()), "mt4_tcn_stage")
+    return out
+
+
+def tcn_layer(x: torch.Tensor, w_dilated: torch.Tensor, b_dilated: torch.Tensor, w_1x1: torch.Tensor, b_1x1: torch.Tensor,
+              dilation: int) -> torch.Tensor:
+    """one DilatedResidualLayer (`mt4_tcn_dilated_residual_layer`): x [B,T,C] -> x + conv_1x1(relu(conv_dilated(x)))"""
+    _need_cuda(x, w_dilated, b_dilated, w_1x1, b_1x1)
+    assert x.dim() == 3 and x.is_contiguous()
+    b, t, c = x.shape
+    h, y = torch.empty_like(x), torch.empty_like(x)
+    check(lib.mt4_tcn_dilated_residual_layer(x.data_ptr(), w_dilated.data_ptr(), b_dilated.data_ptr(), w_1x1.data_ptr(), b_1x1.data_ptr(),
+                                             h.data_ptr(), y.data_ptr(), b, t, c, dilation, dt_code(x.dtype), _stream()),
+          "mt4_tcn_dilated_residual_layer")
+    return y
+
+
+def fpn_topdown(lat: torch.Tensor, levels: torch.Tensor) -> None:
+    """levels[l] = lat[l] + levels[l+1], l = nlev-2 .. 0, in place (`mt4_fpn_topdown`)"""
+    _need_cuda(lat, levels)
+    nlev = levels.shape[0]
+    n = levels[0].numel()
+    assert lat.is_contiguous() and levels.is_contiguous() and lat.dtype == levels.dtype and lat.shape[0] == nlev - 1 and lat[0].numel() == n
+    check(lib.mt4_fpn_topdown(lat.data_ptr(), levels.data_ptr(), nlev, n, dt_code(levels.dtype), _stream()), "mt4_fpn_topdown")
+
+
 def stem_pad_dims(h: int, w: int) -> Tuple[int, int]:
     return h + 6, (w + 6 + 1) & ~1
 

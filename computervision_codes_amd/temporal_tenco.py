@@ -6,9 +6,11 @@ feature files and of the module's own input [1,T,D]) -- the reference's permute 
 (`network.py:42`) is folded into addressing, and the [1,K,T] logits it returns are permuted VIEWS
 of our [T][K] buffers (same shape and values, different strides).
 
-One DilatedResidualLayer (`network.py:186-198`) = two launches of the implicit-GEMM kernel:
-dilated k3 conv + bias + ReLU, then 1x1 conv + bias + residual.  The four 1x1 heads
-(`network.py:21-24`) are concatenated into one [131][C] GEMM per FPN level.
+One DilatedResidualLayer (`network.py:186-198`) = two dependent launches: dilated k3 conv + bias + ReLU, then 1x1 conv + bias +
+residual.  Short videos (B*T <= TCN_PATH_MAX_ROWS) run the latency path (`mt4_tcn_stage` / `mt4_tcn_conv`, csrc/tcn_kernels.hip: comb
+tiles, one workgroup per 32 frames x 16 channels, no barrier in the K loop); long ones the implicit-GEMM kernel with its large tiles.
+The four 1x1 heads (`network.py:21-24`) are concatenated into one [131][C] GEMM; on the latency path the three FPN laterals run as
+one launch over the stacked stage outputs and the heads as one launch over the four levels.
 """
 from __future__ import annotations
 
@@ -19,6 +21,10 @@ import torch
 from . import ops
 from .shapes import tenco_shapes
 
+# rows (B*T) up to which a forward takes the latency path: above it the 128 x 128 tiles of the implicit-GEMM kernel move fewer operand
+# bytes per FLOP than 32 x 16 (measured crossover)
+TCN_PATH_MAX_ROWS = 640
+
 
 class VideoNas:
     """Drop-in for `Temporal_tenco.network.VideoNas` (inference path; eval semantics).
@@ -28,10 +34,12 @@ class VideoNas:
     """
 
     def __init__(self, args, num_layers_PG, num_layers_R, num_R, num_f_maps, dim, num_classes, num_i=6, num_v=10,
-                 num_t=15, device: str = "cuda", dtype: torch.dtype = torch.float32):
+                 num_t=15, device: str = "cuda", dtype: torch.dtype = torch.float32, path: str = "auto"):
         """dtype float32: the parity mode (exact-fp32 MFMA chain); bfloat16: throughput mode (bf16 weights / activations, fp32
-        accumulate and epilogue, fp32 logits)"""
+        accumulate and epilogue, fp32 logits).  path: "auto" (by B*T), "tcn" (latency path), "igemm" (implicit-GEMM kernel)"""
         self.dtype = dtype
+        assert path in ("auto", "tcn", "igemm")
+        self.path = path
         if getattr(args, "output", False) or getattr(args, "hier", False):
             raise NotImplementedError("--output / --hier are never set by the shipped scripts (Scripts/*.sh)")
         self.args = args
@@ -93,6 +101,10 @@ class VideoNas:
             p["heads.w"] = ops.pack_conv_weight(w.unsqueeze(2), None, self.dtype)
             p["heads.b"] = b.contiguous()
         self._p = p
+        self._stages = {prefix: ops.TcnStage([p[f"{prefix}.layers.{i}.conv_dilated.w"] for i in range(n)],
+                                             [p[f"{prefix}.layers.{i}.conv_dilated.b"] for i in range(n)],
+                                             [p[f"{prefix}.layers.{i}.conv_1x1.w"] for i in range(n)],
+                                             [p[f"{prefix}.layers.{i}.conv_1x1.b"] for i in range(n)]) for prefix, n in stages}
 
     # ------------------------------------------------------------------ forward
     def _c1(self, x, name, residual=None, relu=False):
@@ -109,6 +121,55 @@ class VideoNas:
             x = self._layer(x, f"{prefix}.layers.{i}", 2 ** i)
         return x
 
+    def _use_tcn_path(self, rows: int) -> bool:
+        ok = ops.tcn_supported(self.C, self.dtype) and ops.tcn_supported(self.D, self.dtype)
+        if self.path == "tcn":
+            if not ok:
+                raise ValueError("latency path needs channel counts that are whole 128-byte K-steps")
+            return True
+        return self.path == "auto" and ok and rows <= TCN_PATH_MAX_ROWS
+
+    def _forward_tcn(self, x: torch.Tensor):
+        """latency path: x [B,T,D] of self.dtype -> the reference's return structure"""
+        b, t, _ = x.shape
+        p = self._p
+        as_ref = lambda y: y.permute(0, 2, 1)                     # [B,T,K] -> [B,K,T] view
+        f0 = ops.tcn_conv(x, p["PG.conv_1x1.w"], p["PG.conv_1x1.b"], taps=1)
+        out_list: List[torch.Tensor] = []
+        out_i: List[torch.Tensor] = []
+        out_v: List[torch.Tensor] = []
+        out_t: List[torch.Tensor] = []
+        if not self.use_fpn:
+            f = ops.tcn_stage(self._stages["PG"], f0)
+            out_list.append(as_ref(ops.tcn_conv(f, p["PG.conv_out.w"], p["PG.conv_out.b"], taps=1, out_dtype=torch.float32)))
+            f_list = [f]
+            for r in range(self.num_R):
+                f = ops.tcn_stage(self._stages[f"Rs.{r}"], f)
+                f_list.append(f)
+        else:
+            # the stage outputs c1..c3, p4 live in one [4,B,T,C] buffer: the three laterals (all `latlayer1`, network.py:103-105) are ONE
+            # launch over the rows of c1..c3, and the heads one launch over the four levels
+            nlev = self.num_R + 1
+            cs = torch.empty((nlev, b, t, self.C), dtype=self.dtype, device=x.device)
+            ops.tcn_stage(self._stages["PG"], f0, out=cs[0])
+            for r in range(self.num_R):
+                ops.tcn_stage(self._stages[f"Rs.{r}"], cs[r], out=cs[r + 1])
+            if nlev > 1:
+                lat = ops.tcn_conv(cs[:nlev - 1].view(1, (nlev - 1) * b * t, self.C), p["fpn.latlayer1.w"], p["fpn.latlayer1.b"], taps=1)
+                ops.fpn_topdown(lat.view(nlev - 1, b * t * self.C), cs.view(nlev, b * t * self.C))   # p_l = lat(c_l) + p_{l+1}
+            y = ops.tcn_conv(cs.view(1, nlev * b * t, self.C), p["heads.w"], p["heads.b"], taps=1,
+                             out_dtype=torch.float32).view(nlev, b, t, -1)
+            k0, k1, k2, k3 = self.head_sizes
+            f_list = [cs[l] for l in range(nlev)]
+            for l in range(nlev):
+                yl = as_ref(y[l])
+                out_list.append(yl[:, :k0])
+                out_i.append(yl[:, k0:k0 + k1])
+                out_v.append(yl[:, k0 + k1:k0 + k1 + k2])
+                out_t.append(yl[:, k0 + k1 + k2:])
+        f_ref = [as_ref(ff) for ff in f_list]
+        return out_list, out_i, out_v, out_t, f_ref, f_ref
+
     @ops.with_latency_tiles
     def forward(self, x: torch.Tensor, ismask: bool = False):
         """x [B,T,D] float32 on the GPU.  Returns (out_list, out_list_i, out_list_v, out_list_t, f_list, f_list)
@@ -119,6 +180,8 @@ class VideoNas:
             raise RuntimeError("load_state_dict first")
         assert x.dim() == 3 and x.shape[2] == self.D and x.dtype == torch.float32
         b, t, _ = x.shape
+        if self._use_tcn_path(b * t):
+            return self._forward_tcn(x.contiguous().to(self.dtype))
         x4 = x.contiguous().to(self.dtype).view(b, 1, t, self.D)
         f = self._stage(self._c1(x4, "PG.conv_1x1"), "PG", self.num_layers_PG)
         f_list = [f]

@@ -254,6 +254,48 @@ int mt4_mse_f32(const float* a, const float* b, float* da, float* loss, int64_t 
 int mt4_kd_mix_bwd_f32(const float* s, const float* tea_i, const float* tea_v, const float* tea_t, const float* g_i, const float* g_v,
                        const float* g_t, float* ds, float* dtau, int32_t B, int32_t C, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Temporal head, latency path: Conv1d (k = 1 or 3, any dilation, stride 1, padding = dilation*(k-1)/2) over frame-major rows,
+ * fused epilogue   y = act( conv(x, w) + bias [+ residual] )
+ * for ONE short video (or a few): replaces `DilatedResidualLayer` (Temporal_tenco/network.py:186-198: conv_dilated -> ReLU ->
+ * conv_1x1 -> +x, Dropout inactive in eval) and the 1x1 projections / heads around it (network.py:21-24,96,113,129).
+ * Same arithmetic contract as mt4_conv_nhwc (fp32 = exact-fp32 MFMA chain, bf16 = fp32 accumulate); the K sum is split over the
+ * 8 waves of a workgroup by 128-byte channel slice and the partial tiles are added in a fixed order, so results are deterministic
+ * and independent of how many videos ride along, but differ from mt4_conv_nhwc's by fp32 reassociation.
+ *   x        [B*T][Cin]   dtype        w  [Cout][taps*Cin] packed by mt4_pack_conv_weight(Cout, Cin, 1, taps, dtype)
+ *   bias     [Cout] float32 or NULL    residual [B*T][Cout] dtype or NULL     y [B*T][Cout] out_dtype
+ * Contract: Cin*esize % 128 == 0 (MT4_EUNSUPPORTED otherwise: use mt4_conv_nhwc), pointers 16-byte aligned, B*T*Cin*esize < 2 GiB.
+ * One workgroup per 32 frames x 16 channels: meant for B*T up to a few hundred frames (above that mt4_conv_nhwc's large tiles
+ * move fewer operand bytes per FLOP). */
+typedef struct mt4_tcn_desc {
+    const void* x;
+    const void* w;
+    const float* bias;
+    const void* residual;
+    void* y;
+    int32_t B, T, Cin, Cout;
+    int32_t taps;      /* 1 or 3 */
+    int32_t dilation;  /* >= 1 (ignored for taps == 1) */
+    int32_t relu;      /* 0 / 1 */
+    int32_t dtype;     /* MT4_F32 / MT4_BF16: x, w, residual */
+    int32_t out_dtype; /* MT4_F32 / MT4_BF16: y */
+} mt4_tcn_desc;
+int mt4_tcn_conv(const mt4_tcn_desc* d, void* stream);
+/* One DilatedResidualLayer: y = x + conv_1x1(relu(conv_dilated(x))) (network.py:193-198); h [B*T][C] is scratch for the hidden
+ * activation; C*esize % 128 == 0.  Two dependent launches of the kernel above. */
+int mt4_tcn_dilated_residual_layer(const void* x, const void* w_dilated, const float* b_dilated, const void* w_1x1, const float* b_1x1,
+                                   void* h, void* y, int32_t B, int32_t T, int32_t C, int32_t dilation, int32_t dtype, void* stream);
+/* A stage's layer stack (BaseCausalTCN.layers / Refinement.layers, network.py:116-118,130-131,147-148,157-158): n_layers >= 1
+ * DilatedResidualLayers with dilation 2^i.  Layer 0 reads x (never written); the layers in between ping-pong between the scratch
+ * buffers buf_a / buf_b (needed for n_layers > 1 / > 2); the last layer writes y.  All activations [B*T][C]; the four arrays hold
+ * n_layers DEVICE pointers each and live in HOST memory. */
+int mt4_tcn_stage(const void* x, void* buf_a, void* buf_b, void* h, void* y, const void* const* w_dilated, const float* const* b_dilated,
+                  const void* const* w_1x1, const float* const* b_1x1, int32_t n_layers, int32_t B, int32_t T, int32_t C,
+                  int32_t dtype, void* stream);
+/* FPN top-down pathway at equal lengths (network.py:93-106; `F.interpolate(x, size=W, mode='linear')` to the same length is the
+ * identity): levels[l] = lat[l] + levels[l+1] for l = nlev-2 .. 0, in place.  lat [nlev-1][n], levels [nlev][n] of dtype, n % 4 == 0. */
+int mt4_fpn_topdown(const void* lat, void* levels, int32_t nlev, int64_t n, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
