@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""MI355X entry point for `MT4MTLKD/Spatial_transformer/run.py` (same flags, paths and files; see computervision_codes_amd/drivers.py):
+-t trains the Swin + Query2Label teacher, -e without -t runs the evaluation / extraction pass of test.py."""
+import os
+import sys
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
+from computervision_codes_amd.drivers import spatial_transformer_run  # noqa: E402
+
+if __name__ == "__main__":
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    spatial_transformer_run(sys.argv[1:])

@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU; every stream gets --batch frames of a step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-temporal", action="store_true")
+    ap.add_argument("--no-ddp-train", action="store_true", help="N > 1: skip the data-parallel training sub-record")
     ap.add_argument("--per-layer", default="", help="write a per-conv-layer timing table (json) to this path")
     return ap.parse_args()
 
@@ -313,11 +314,131 @@ def spatial_train_bench(dev):
     return out
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: start the N ranks ourselves, as a CHILD
+    `torch.distributed.run` (one process per GPU, RCCL), BEFORE anything here has touched the GPU, and exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def plumbing_only(a, world, rank):
+    """MT4_BENCH_PLUMBING=1 (CPU tests of the N-rank protocol, no kernels): rendezvous over gloo, the barrier-bracketed timed region with
+    a sleep for a step, MAX over ranks, one JSON line from rank 0 -- everything of the N > 1 path except the GPU work."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    for _ in range(a.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.002 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "plumbing_only": True}))
+
+
+def ddp_train_bench(dev, dist, world, rank):
+    """Data-parallel training rate of the two student trainers (BASELINE configs[3]/[4]; reference loops `Spatial_cnn/run.py:145-224`,
+    `Temporal_tenco/run.py:181-235`): every rank steps on its own batch / video, gradients meet in the flat buffer's all-reduce (RCCL).
+    Per case: whole-job rate, ms per step (MAX over ranks), the all-reduce of the full gradient payload timed alone, the step with the
+    exchange switched off, and from those the share of the exchange that hides behind the backward."""
+    from computervision_codes_amd import shapes, synth
+    from computervision_codes_amd.spatial_cnn_train import SpatialCnnTrainer
+    from computervision_codes_amd.tenco_train import TencoTrainer
+
+    def sync_max(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(fn, iters):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return sync_max((time.perf_counter() - t0) / iters * 1e3)
+
+    def allreduce_alone(flat):
+        if dist is None:
+            return 0.0
+        buf = torch.zeros_like(flat)
+        return timed(lambda: dist.all_reduce(buf), 5)
+
+    out = {}
+    for net, B in (("resnet50", 8), ("resnet50", 64)):
+        H, W = 256, 448
+        tr = SpatialCnnTrainer(net, lr=0.01, device=str(dev)).load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes(net), seed=5))
+        frames = synth.synthetic_frames(B, H, W, seed=1 + rank).to(dev)
+        z = torch.cat([torch.from_numpy((synth.uniform01(5 + rank, i, B * k) < 0.15).reshape(B, k).astype(np.float32)) for i, k in
+                       enumerate((6, 10, 15, 100))], 1).to(dev)
+        tp = [synth.synthetic_features(B, k, seed=11 + i)[0].to(dev) for i, k in enumerate((6, 10, 15))]
+        tf = [synth.synthetic_features(B, 1536, seed=21 + i)[0].to(dev) for i in range(3)]
+        iters = 10 if B == 8 else 4
+        ms = timed(lambda: tr.train_step(frames, z, tp, tf), iters)                       # eager: bucketed all-reduce behind the backward
+        tr.exchange = False
+        ms_local = timed(lambda: tr.train_step(frames, z, tp, tf), iters)
+        tr.exchange = True
+        ar = allreduce_alone(tr.G)
+        exposed = max(0.0, ms - ms_local)
+        out[f"spatial_{net}_b{B}"] = dict(frames_per_s=round(world * B / ms * 1e3, 1), ms_per_step=round(ms, 3), ms_per_step_no_exchange=round(ms_local, 3),
+                                          allreduce_alone_ms=round(ar, 3), grad_MB=round(tr.G.numel() * 4 / 1e6, 1),
+                                          overlap_fraction=round(1.0 - min(1.0, exposed / ar), 3) if ar > 0 else None,
+                                          frames_per_rank=B, dtype="f32", mode="eager, bucketed all-reduce issued behind the backward")
+        del tr
+    T = 1000
+    tr = TencoTrainer(lr=0.01, device=str(dev)).load_state_dict(synth.fill_from_shapes(shapes.tenco_shapes(), seed=47))
+    xt = synth.synthetic_features(T, 512, seed=47 + rank).to(dev)
+    zl = tr.prepare_labels({s: torch.from_numpy((synth.uniform01(3 + rank, i, T * k) < 0.1).reshape(T, k).astype(np.int64))
+                            for i, (s, k) in enumerate((("", 100), ("_i", 6), ("_v", 10), ("_t", 15)))})
+    ms = timed(lambda: tr.train_step(xt, zl, use_graph=True), 10)
+    tr.exchange = False
+    ms_local = timed(lambda: tr.train_step(xt, zl, use_graph=True), 10)
+    tr.exchange = True
+    ar = allreduce_alone(tr.G)
+    exposed = max(0.0, ms - ms_local)
+    out[f"tenco4_T{T}"] = dict(videos_per_s=round(world / ms * 1e3, 2), ms_per_step=round(ms, 3), ms_per_step_no_exchange=round(ms_local, 3),
+                               allreduce_alone_ms=round(ar, 3), grad_MB=round(tr.G.numel() * 4 / 1e6, 1),
+                               overlap_fraction=round(1.0 - min(1.0, exposed / ar), 3) if ar > 0 else None,
+                               mode="hipGraph replay of forward+backward, one flat all-reduce")
+    return out
+
+
+METRIC = "frames/sec spatial-extract + per-video TCN latency, Cholec80, 1/2/4/8 GPU"
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MT4_BENCH_PLUMBING") == "1":
+        return plumbing_only(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     backend = os.environ.get("MT4_BENCH_BACKEND", "nccl")    # "gloo": rehearsal of the N>1 path with several ranks on ONE GPU
@@ -407,7 +528,7 @@ def main():
             os.makedirs(os.path.dirname(os.path.abspath(a.per_layer)), exist_ok=True)
             json.dump(rows, open(a.per_layer, "w"), indent=1)
         res = {
-            "metric": "frames/sec spatial-extract + per-video TCN latency, Cholec80, 1/2/4/8 GPU",
+            "metric": METRIC,
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
@@ -428,6 +549,13 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_spatial(a.network, a.height, a.width, 1234)
             res["gpu_over_cpu"] = round(fps / res["cpu_baseline"]["value"], 1)
+    if world > 1 and not a.no_ddp_train:
+        try:
+            rec = ddp_train_bench(dev, dist, world, rank)  # every rank takes part (the exchange is collective)
+        except Exception as e:                             # the headline line must survive a failure of the sub-record
+            rec = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            res["ddp_train"] = rec
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1132,10 +1132,9 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     ConvK kk = k;
     kk.n_tiles = cdiv(k.Cout, BN);
     kk.total_tiles = m_tiles * kk.n_tiles;
-    kk.nt_epi = getenv("MT4_NO_NT") == nullptr ? 1 : 0;
+    kk.nt_epi = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
     {   // outputs that fit the 256 MB Infinity Cache stay cacheable for the next layer (+0.8 % over always-nt; MT4_NT_MIN_MB overrides)
-        const char* e = getenv("MT4_NT_MIN_MB");
-        const long long min_mb = e ? atoi(e) : 200;
+        const long long min_mb = MT4_ENV_INT("MT4_NT_MIN_MB", 200);
         if ((long long)k.M * k.Cout * 2 < min_mb * 1000000LL) kk.nt_epi = 0;
     }
     // LDS: two operand stages, or ONE when the whole K fits a single step (then only the epilogue staging may need
@@ -1152,8 +1151,7 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
         constexpr int lds_ks = KS * STAGES * stage > epi ? KS * STAGES * stage : epi;
         auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, STAGES, true, OUT_F32, KS>;
         if (lds_ks > 65536) {
-            static bool raised = false;
-            if (!raised) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+            MT4_RAISE_LDS(fn);
         }
         hipLaunchKernelGGL(fn, dim3(kk.total_tiles), dim3(threads * KS), lds_ks, s, kk);
         return mt4_check_launch();
@@ -1163,15 +1161,13 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     if (fast) {
         auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, STAGES, true, OUT_F32>;
         if (lds > 65536) {
-            static bool raised = false;   // per instantiation: allow > 64 KiB of dynamic LDS once
-            if (!raised) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+            MT4_RAISE_LDS(fn);
         }
         hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, s, kk);
     } else {
         auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, 2, false, OUT_F32>;
         if (lds > 65536) {
-            static bool raised = false;
-            if (!raised) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+            MT4_RAISE_LDS(fn);
         }
         hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, s, kk);
     }
@@ -1224,10 +1220,9 @@ int launch_patch3x3(const ConvK& k, hipStream_t s) {
     ConvK kk = k;
     kk.n_tiles = cdiv(k.Cout, BN);
     kk.total_tiles = cdiv(k.M, BM) * kk.n_tiles;
-    kk.nt_epi = getenv("MT4_NO_NT") == nullptr ? 1 : 0;
+    kk.nt_epi = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
     {
-        const char* e = getenv("MT4_NT_MIN_MB");
-        const long long min_mb = e ? atoi(e) : 200;
+        const long long min_mb = MT4_ENV_INT("MT4_NT_MIN_MB", 200);
         if ((long long)k.M * k.Cout * 2 < min_mb * 1000000LL) kk.nt_epi = 0;
     }
     constexpr int threads = WM_ * WN_ * 64;
@@ -1241,8 +1236,7 @@ int launch_patch3x3(const ConvK& k, hipStream_t s) {
     if (lds > 160 * 1024 || (k.SPT > 1 && cdiv(pra, rpp) > 11 - WS)) return MT4_EUNSUPPORTED;   // (next-slice patch pieces ride along with taps 0..)
     auto fn = conv3x3_patch_kernel<BM, BN, WM_, WN_, WS>;
     if (lds > 65536) {
-        static bool raised = false;
-        if (!raised) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+        MT4_RAISE_LDS(fn);
     }
     hipLaunchKernelGGL(fn, dim3(kk.total_tiles), dim3(threads), lds, s, kk, pra, npatch);
     return mt4_check_launch();
@@ -1279,10 +1273,9 @@ int launch_stem_patch(const ConvK& k, hipStream_t s) {
     ConvK kk = k;
     kk.n_tiles = 1;
     kk.total_tiles = cdiv(k.M, BM);
-    kk.nt_epi = getenv("MT4_NO_NT") == nullptr ? 1 : 0;
+    kk.nt_epi = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
     {
-        const char* e = getenv("MT4_NT_MIN_MB");
-        const long long min_mb = e ? atoi(e) : 200;
+        const long long min_mb = MT4_ENV_INT("MT4_NT_MIN_MB", 200);
         if ((long long)k.M * k.Cout * 2 < min_mb * 1000000LL) kk.nt_epi = 0;
     }
     // frame pixels a tile of 256 consecutive output pixels of ONE image can span: its own run, 3 extra pixels per output row it crosses,
@@ -1298,8 +1291,7 @@ int launch_stem_patch(const ConvK& k, hipStream_t s) {
     if (lds > 160 * 1024) return MT4_EUNSUPPORTED;
     auto fn = stem_patch_kernel<BM, 4, 2>;
     if (lds > 65536) {
-        static bool raised = false;
-        if (!raised) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+        MT4_RAISE_LDS(fn);
     }
     hipLaunchKernelGGL(fn, dim3(kk.total_tiles), dim3(512), lds, s, kk, pra);
     return mt4_check_launch();
@@ -1310,10 +1302,9 @@ int launch_stem_patch_persistent(const ConvK& k, hipStream_t s) {
     ConvK kk = k;
     kk.n_tiles = cdiv(k.HoWo, BM);
     kk.total_tiles = k.B * kk.n_tiles;
-    kk.nt_epi = getenv("MT4_NO_NT") == nullptr ? 1 : 0;
+    kk.nt_epi = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
     {
-        const char* e = getenv("MT4_NT_MIN_MB");
-        const long long min_mb = e ? atoi(e) : 200;
+        const long long min_mb = MT4_ENV_INT("MT4_NT_MIN_MB", 200);
         if ((long long)k.M * k.Cout * 2 < min_mb * 1000000LL) kk.nt_epi = 0;
     }
     const int span = BM + 3 * (cdiv(BM, k.Wo) + 1) + (k.KH - 1) * k.W + 4;
@@ -1333,15 +1324,12 @@ int launch_stem_patch_persistent(const ConvK& k, hipStream_t s) {
     if (grid > kk.total_tiles) grid = kk.total_tiles;
     auto fn = stem_patch_persistent_kernel<BM, 4, 2>;
     if (lds > 65536) {
-        static bool raised = false;
-        if (!raised) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+        MT4_RAISE_LDS(fn);
     }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, kk, pbuf);
     return mt4_check_launch();
 }
 
-// tuning override: integer value of an environment variable, read once per call site
-#define MT4_ENV_INT(name, dflt) ([]() { static const int v = getenv(name) ? atoi(getenv(name)) : (dflt); return v; }())
 
 int auto_tile(int M, int N, int nsteps, int es) {
     // Measured on MI355X over the ResNet-50 layer set (tools/tune_conv.py, profiles/r01_tile_tuning.txt):
@@ -1391,7 +1379,7 @@ int auto_tile(int M, int N, int nsteps, int es) {
     }
     // few workgroups, long K (a TCN layer over one short video): nothing else hides the per-step DMA latency, so take
     // the 4-stage ring of the same tile (slower than 2 stages whenever the chip is full: it halves workgroups per CU)
-    if (getenv("MT4_NO_DEEP_RING") == nullptr && nsteps >= 8) {
+    if (!MT4_ENV_SET("MT4_NO_DEEP_RING") && nsteps >= 8) {
         if (best == 5) return 10;
         if (best == 6) return 11;
         if (best == 3) return 9;
@@ -1477,7 +1465,7 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     const bool latency = tile == -1;   // automatic choice, K-split tiles allowed
     if (latency) tile = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (tile == 33 || tile == 34 || (tile == 0 && stem_patch_ok(d, k, fast) && getenv("MT4_NO_STEM_PATCH") == nullptr)) {   // the space-to-depth stem
+    if (tile == 33 || tile == 34 || (tile == 0 && stem_patch_ok(d, k, fast) && !MT4_ENV_SET("MT4_NO_STEM_PATCH"))) {   // the space-to-depth stem
         if (!stem_patch_ok(d, k, fast)) return MT4_EUNSUPPORTED;
         const int persistent = MT4_ENV_INT("MT4_STEM_PERSISTENT", 0);
         const int rc = (tile == 34 || (tile == 0 && persistent)) ? launch_stem_patch_persistent(k, s) : launch_stem_patch(k, s);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mt4hip.h"
 
@@ -57,3 +58,20 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// allow > 64 KiB of dynamic LDS for kernel `fn` on the CURRENT device: once per device and call site (the attribute is per device; a
+// process-wide flag would leave the second GPU of a process at the 64 KiB default)
+#define MT4_RAISE_LDS(fn)                                                                                                   \
+    do {                                                                                                                    \
+        static bool raised_[64] = {};                                                                                       \
+        int dev_ = 0;                                                                                                       \
+        (void)hipGetDevice(&dev_);                                                                                          \
+        if (dev_ < 0 || dev_ >= 64 || !raised_[dev_]) {                                                                     \
+            (void)hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
+            if (dev_ >= 0 && dev_ < 64) raised_[dev_] = true;                                                               \
+        }                                                                                                                   \
+    } while (0)
+
+// integer value of an environment variable, read ONCE per process and call site (tuning switches must not cost a getenv per launch)
+#define MT4_ENV_INT(name, dflt) ([]() { static const int v = getenv(name) ? atoi(getenv(name)) : (dflt); return v; }())
+#define MT4_ENV_SET(name) ([]() { static const bool v = getenv(name) != nullptr; return v; }())

@@ -316,15 +316,7 @@ int launch_tcn(const TcnK& k, hipStream_t s) {
     const int lds = kTcnWaves * kTcnRing * k.np * 1024 + kTcnWaves * 2 * 64 * 16;
     if (lds > 160 * 1024) return MT4_EUNSUPPORTED;
     auto fn = tcn_conv_kernel<T, TAPS, OUT_F32>;
-    if (lds > 65536) {   // allow > 64 KiB of dynamic LDS: once per device and instantiation
-        static bool raised[64] = {};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev < 0 || dev >= 64 || !raised[dev]) {
-            (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (dev >= 0 && dev < 64) raised[dev] = true;
-        }
-    }
+    if (lds > 65536) MT4_RAISE_LDS(fn);
     hipLaunchKernelGGL(fn, dim3(8, k.TT, k.B * k.nnx), dim3(kTcnWaves * 64), lds, s, k);
     return mt4_check_launch();
 }

@@ -568,7 +568,7 @@ extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* 
     // fp32 (parity mode), no bias / mask, <= 256 keys, head dim <= 128: exact-fp32 matrix-unit kernel (MS-TCT's global block)
     if (dtype == MT4_F32 && hd <= 128 && (hd % 4) == 0 && !bias && !mask && Nk <= 256 && (q_stride % 4) == 0 && (k_stride % 4) == 0 &&
         (v_stride % 4) == 0 && (o_stride % 4) == 0 && ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0) &&
-        cdiv(Nq, 64) <= 65535 && getenv("MT4_NO_MHA_MFMA") == nullptr) {
+        cdiv(Nq, 64) <= 65535 && !MT4_ENV_SET("MT4_NO_MHA_MFMA")) {
         const dim3 grid(H, B, cdiv(Nq, 64)), block(256);
         if (Nk <= 128) {
             const size_t lds = sizeof(float) * (size_t)(128 * 36 > 32 * 132 ? 128 * 36 : 32 * 132);

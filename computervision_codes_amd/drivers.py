@@ -6,6 +6,7 @@ torch.distributed is initialised (torchrun), whole videos are sharded over ranks
 from __future__ import annotations
 
 import argparse
+import sys
 import os
 import pickle
 import time
@@ -42,6 +43,12 @@ def _dist():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def _barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
 
 
 def _log(path: str, msg: str):
@@ -256,6 +263,17 @@ def tenco_eval(argv=None) -> Dict[str, float]:
         _tenco_train(F)
         if not F.test:
             return {}
+    if _dist()[0] != 0:      # under torchrun the evaluation, its log lines and the mAP pickle belong to rank 0 alone
+        _barrier()
+        return {}
+    try:
+        return _tenco_eval_rank0(F)
+    finally:
+        _barrier()
+
+
+def _tenco_eval_rank0(F) -> Dict[str, float]:
+    from .temporal_tenco import VideoNas
     modelname = f"{F.model}_l8_cholect{F.dataset_variant}_k{F.kfold}_batchnorm_lowres"   # `run.py:137-142`
     model_dir = f"./__checkpoint__/run_{F.version}"
     logfile = os.path.join(model_dir, modelname + ".log")
@@ -323,12 +341,16 @@ def _tenco_train(F):
         for s in range(steps):
             v = order[(s * world + rank) % len(order)]
             x = xs[v]
-            masks = tr.draw_masks(x.shape[1], gen) if F.mask else None
+            masks = tr.draw_masks(x.shape[1], gen)                 # Dropout2d + per-layer Dropout are always on in train mode
+            if not F.mask:                                         # (`network.py:123-127,194-196`); --mask gates the 75 % input mask only
+                masks["input_mask"] = None                         # (`network.py:43-48`)
             loss, _ = tr.train_step(x, zs[v], masks=masks)
             tot += loss
         if rank == 0:
             _log(logfile, f"Traning | lr: {tr.lr:.6f} | epoch {epoch} | loss {tot / steps:.4f} | {time.time() - t0:.2f} secs")
-            torch.save(tr.state_dict(), init)
+            torch.save(tr.state_dict(), init + ".tmp")
+            os.replace(init + ".tmp", init)                        # readers never see a half-written checkpoint
+    _barrier()                                                     # the last checkpoint is on disk before any rank goes on to -e
 
 
 # ------------------------------------------------------------------------------------------------ Spatial_transformer/test.py
@@ -340,8 +362,10 @@ def spatial_transformer_test(argv=None) -> Dict[str, np.ndarray]:
     p.add_argument("--img_size", type=int, default=384)
     p.add_argument("--hidden_dim", type=int, default=1536)
     F, _ = p.parse_known_args(argv)
-    version = F.version + ("_" + F.loss_type if F.loss_type != "all" else "")          # `test.py:94-95`
-    ckpt = F.test_ckpt or f"./__checkpoint__/run_{version}/rendezvous_l{F.dataset_variant}_cholect{F.kfold}.pth"
+    # only the CHECKPOINT directory carries the task suffix (`test.py:93-95`); the feature file goes to run_<version as given>
+    # (`test.py:364-372`: `version1`), which is where Temporal_mstct and the student's dataloader look for it
+    ckpt_version = F.version + ("_" + F.loss_type if F.loss_type != "all" else "")
+    ckpt = F.test_ckpt or f"./__checkpoint__/run_{ckpt_version}/rendezvous_l{F.dataset_variant}_cholect{F.kfold}.pth"
     model = build_q2l(F, dtype=torch.float32 if F.dtype == "fp32" else torch.bfloat16).eval()
     model.load_state_dict(torch.load(ckpt, map_location="cpu"), strict=True)
     rank, world = _dist()
@@ -358,7 +382,7 @@ def spatial_transformer_test(argv=None) -> Dict[str, np.ndarray]:
         feats_local[featfile.video_key(v, "transformer")] = torch.vstack(chunks).numpy()
     merged = extract.gather_feats(feats_local)
     if rank == 0:
-        featfile.write_feats(featfile.feats_path("..", version, F.kfold, F.loss_type), merged)
+        featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type), merged)
     return merged
 
 
@@ -371,13 +395,15 @@ def mstct_test(argv=None):
     p.add_argument("--final_embedding_dim", type=int, default=512)
     F, _ = p.parse_known_args(argv)
     F.in_feat_dim = F.input_dim
-    model_dir = f"./__checkpoint__/run_{F.version}"
+    # checkpoint directory: run_<version>_<task> for a single-task teacher (`test.py:88-90,131,326`); the feature / prediction files it
+    # writes go to run_<version as given> (`test.py:342-366`) and its input comes from run_<version1> (`dataloader_test.py:220`)
+    model_dir = f"./__checkpoint__/run_{F.version}" + ("_" + F.loss_type if F.loss_type != "all" else "")
     modelname = f"{F.model}_l8_cholect{F.dataset_variant}_k{F.kfold}_batchnorm_lowres"
     ckpt = F.test_ckpt or os.path.join(model_dir, modelname + "latest.pth")              # no underscore (`run.py:268`)
     model = VideoNas(F, [256, 384, 576, 864], 2, 8, 8, F.input_dim, F.final_embedding_dim,
                      dtype=torch.float32 if F.dtype == "fp32" else torch.bfloat16).eval()
     model.load_state_dict(torch.load(ckpt, map_location="cpu"))
-    feats = featfile.read_feats(featfile.feats_path("..", F.version1 + ("_" + F.loss_type if F.loss_type != "all" else ""), F.kfold, F.loss_type))
+    feats = featfile.read_feats(featfile.feats_path("..", F.version1, F.kfold, F.loss_type))
     out_feats, out_preds = {}, {}
     gi = {"i": 0, "v": 1, "t": 2, "ivt": 3}[F.loss_type]
     for key, f in feats.items():
@@ -391,3 +417,42 @@ def mstct_test(argv=None):
     featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type, "feats"), out_feats)
     featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type, "pred"), out_preds)
     return out_feats, out_preds
+
+
+# ------------------------------------------------------------------------------------------------ teacher run.py entry points
+class StageNotBuilt(SystemExit):
+    """a stage of the recipe whose training loop is not part of this build: exit code 3 and a message naming the reference lines"""
+
+    def __init__(self, msg: str):
+        print(msg, file=sys.stderr)
+        super().__init__(3)
+
+
+def _wants_train(argv) -> bool:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    return "-t" in argv or "--train" in argv
+
+
+def spatial_transformer_run(argv=None):
+    """`Spatial_transformer/run.py`: -e alone = the extraction / evaluation pass (`spatial_transformer_test`); -t (teacher training,
+    `run.py:150-229`: window-attention / LayerNorm / GELU backward, DropPath, dropout 0.1) is not built."""
+    if _wants_train(argv):
+        raise StageNotBuilt("Spatial_transformer/run.py -t: training of the Swin + Query2Label teacher (reference Spatial_transformer/run.py:150-229) "
+                            "is not built on MI355X yet.  Put a trained teacher checkpoint under ./__checkpoint__/run_<version>[_<task>]/ and "
+                            "re-run with SKIP_TEACHER_TRAIN=1 (Scripts/train_fold1.sh), or run test.py -e directly.")
+    return spatial_transformer_test(argv)
+
+
+def mstct_run(argv=None):
+    """`Temporal_mstct/run.py`: -t trains the MS-TCT teacher on random 256-frame windows (`run.py:147-235`), -e evaluates / extracts."""
+    if _wants_train(argv):
+        try:
+            from . import mstct_train
+        except ImportError:
+            raise StageNotBuilt("Temporal_mstct/run.py -t: training of the MS-TCT teacher (reference Temporal_mstct/run.py:147-235) is not built on "
+                                "MI355X yet.  Put a trained checkpoint under ./__checkpoint__/run_<version>[_<task>]/ and re-run with "
+                                "SKIP_TEACHER_TRAIN=1 (Scripts/train_fold1.sh), or run test.py -e directly.")
+        mstct_train.train_driver(sys.argv[1:] if argv is None else argv)
+        if "-e" not in (sys.argv[1:] if argv is None else argv):
+            return None
+    return mstct_test(argv)

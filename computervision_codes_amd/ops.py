@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import contextlib
+import contextvars
 import ctypes as C
 import functools
 from typing import Optional, Tuple
@@ -63,7 +64,7 @@ def conv_out_size(h: int, k: int, stride: int, pad: int, dil: int) -> int:
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-_LATENCY_TILES = False
+_LATENCY_TILES = contextvars.ContextVar("mt4_latency_tiles", default=False)   # per thread / task: forwards may run from several threads
 
 
 @contextlib.contextmanager
@@ -72,12 +73,11 @@ def latency_tiles():
     workgroup share one output tile's K loop).  For the temporal heads -- one short video, 40+ dependent launches with few tiles and a
     long K each -- that cuts the per-launch critical path; the K summation order then differs from the other tiles' (fp32
     reassociation), so the spatial extractors, whose features are bit-identical whatever batch a frame rides in, do not use it."""
-    global _LATENCY_TILES
-    old, _LATENCY_TILES = _LATENCY_TILES, True
+    token = _LATENCY_TILES.set(True)
     try:
         yield
     finally:
-        _LATENCY_TILES = old
+        _LATENCY_TILES.reset(token)
 
 
 def with_latency_tiles(fn):
@@ -131,7 +131,7 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     if out_row_map is not None:
         assert out_row_map.dtype == torch.int32 and out_row_map.is_cuda and out_row_map.is_contiguous()
         assert (b * ho * wo) % out_row_map.numel() == 0
-    if tile == 0 and _LATENCY_TILES:
+    if tile == 0 and _LATENCY_TILES.get():
         tile = -1
     d = ConvDesc(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
                  residual.data_ptr() if residual is not None else None, out.data_ptr(),

@@ -403,7 +403,7 @@ class SpatialCnnTrainer:
     def _reduce_bucket(self, name: str):
         """DDP overlap: the bucket's all-reduce is enqueued behind the kernels that wrote it and runs while the backward
         of the earlier layers continues; `apply_update` waits for all of them.  Not inside a hipGraph capture."""
-        if not self.overlap or self._capturing or self._ddp_world() == 1:
+        if not self.overlap or self._capturing or not getattr(self, "exchange", True) or self._ddp_world() == 1:
             return
         import torch.distributed as dist
         a, b = self._ranges[name]
@@ -425,7 +425,9 @@ class SpatialCnnTrainer:
                 h.wait()
             self._pending = []
             scale = 1.0 / self._ddp_world()
-        else:
+        elif getattr(self, "exchange", True):
             scale = allreduce_sum_flat(self.G, self.pg)
+        else:
+            scale = 1.0                                     # exchange=False: rank-local step (bench: the step without its exchange)
         ops.sgd_step(self.P, self.G, self.lr, self.wd, scale)
         self._refresh_transposed()

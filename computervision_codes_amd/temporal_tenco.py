@@ -7,7 +7,7 @@ feature files and of the module's own input [1,T,D]) -- the reference's permute 
 of our [T][K] buffers (same shape and values, different strides).
 
 One DilatedResidualLayer (`network.py:186-198`) = two dependent launches: dilated k3 conv + bias + ReLU, then 1x1 conv + bias +
-residual.  Short videos (B*T <= TCN_PATH_MAX_ROWS) run the latency path (`mt4_tcn_stage` / `mt4_tcn_conv`, csrc/tcn_kernels.hip: comb
+residual.  Short videos (B*T <= TCN_PATH_MAX_ROWS[dtype]) run the latency path (`mt4_tcn_stage` / `mt4_tcn_conv`, csrc/tcn_kernels.hip: comb
 tiles, one workgroup per 32 frames x 16 channels, no barrier in the K loop); long ones the implicit-GEMM kernel with its large tiles.
 The four 1x1 heads (`network.py:21-24`) are concatenated into one [131][C] GEMM; on the latency path the three FPN laterals run as
 one launch over the stacked stage outputs and the heads as one launch over the four levels.
@@ -22,8 +22,9 @@ from . import ops
 from .shapes import tenco_shapes
 
 # rows (B*T) up to which a forward takes the latency path: above it the 128 x 128 tiles of the implicit-GEMM kernel move fewer operand
-# bytes per FLOP than 32 x 16 (measured crossover)
-TCN_PATH_MAX_ROWS = 640
+# bytes per FLOP than 32 x 16.  Measured crossover, 4-stage head, hipGraph replay, ms (latency path | implicit GEMM):
+#   fp32  T=512 0.89 | 0.96   T=768 1.34 | 1.53   T=1024 1.60 | 1.54        bf16  T=512 0.57 | 0.64   T=768 0.85 | 0.72
+TCN_PATH_MAX_ROWS = {torch.float32: 896, torch.bfloat16: 640}
 
 
 class VideoNas:
@@ -127,7 +128,7 @@ class VideoNas:
             if not ok:
                 raise ValueError("latency path needs channel counts that are whole 128-byte K-steps")
             return True
-        return self.path == "auto" and ok and rows <= TCN_PATH_MAX_ROWS
+        return self.path == "auto" and ok and rows <= TCN_PATH_MAX_ROWS[self.dtype]
 
     def _forward_tcn(self, x: torch.Tensor):
         """latency path: x [B,T,D] of self.dtype -> the reference's return structure"""

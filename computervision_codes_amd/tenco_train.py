@@ -281,7 +281,7 @@ class TencoTrainer:
 
     def apply_update(self):
         """DDP exchange (one all-reduce of the flat gradient buffer, mean over ranks) + SGD + refresh of the transposed copies"""
-        scale = allreduce_sum_flat(self.G, self.pg)
+        scale = allreduce_sum_flat(self.G, self.pg) if getattr(self, "exchange", True) else 1.0   # exchange=False: rank-local step (bench only)
         ops.sgd_step(self.P, self.G, self.lr, self.wd, scale)
         self._refresh_transposed()
 

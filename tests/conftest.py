@@ -1,3 +1,4 @@
+import ast
 import os
 import sys
 
@@ -17,7 +18,7 @@ def pytest_configure(config):
 
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
-    cfg = eval(str(z["cfg"]))  # repr(dict) written by oracle/gen_golden.py
+    cfg = ast.literal_eval(str(z["cfg"]))  # repr(dict) of plain literals written by oracle/gen_golden.py
     return z, cfg
 
 

@@ -207,9 +207,11 @@ def test_q2l_fp32_vs_reference_golden(cuda, name):
     assert _maxerr(out2[gi][1], z["logits"]) < 1e-3
 
 
-def test_q2l_loss_type_all_with_kd_vs_reference_golden(cuda):
-    """four decoders over the shared transformer + the always-on KD mixing (`Spatial_transformer/network.py:98-124`)"""
-    z, cfg = load_golden("q2l_swinT_224_all")
+@pytest.mark.parametrize("name", ["q2l_swinT_224_all", "q2l_swinB_384_all"])
+def test_q2l_loss_type_all_with_kd_vs_reference_golden(cuda, name):
+    """four decoders over the shared transformer + the always-on KD mixing (`Spatial_transformer/network.py:98-124`); the Swin-B/384 case
+    is BASELINE configs[2] as a composite (Swin-B + the K = 100 triplet head beside the three component heads)"""
+    z, cfg = load_golden(name)
     m = _q2l_model(cfg, torch.float32)
     frames = synth.synthetic_frames(cfg["B"], cfg["img"], cfg["img"], seed=cfg["seed"])
     tf = [synth.synthetic_features(cfg["B"], 512, seed=cfg["seed"] + k)[0].to(cuda) for k in (1, 2, 3)]
@@ -217,6 +219,8 @@ def test_q2l_loss_type_all_with_kd_vs_reference_golden(cuda):
     for got, key in ((yi, "logit_i"), (yv, "logit_v"), (yt, "logit_t"), (yivt, "logit_ivt"), (feat, "feat"), (kd_i, "kd_i"), (kd_v, "kd_v"),
                      (kd_t, "kd_t")):
         assert tuple(got.shape) == z[key].shape and _maxerr(got, z[key]) < 1e-3, (key, _maxerr(got, z[key]))
+    for got, key in ((yi, "logit_i"), (yv, "logit_v"), (yt, "logit_t"), (yivt, "logit_ivt")):
+        assert torch.equal(got.float().cpu().argmax(1), torch.from_numpy(z[key]).argmax(1)) and _same_topk(got, z[key], 5), key
     with pytest.raises(TypeError):
         m(frames.to(cuda))
 

@@ -127,13 +127,16 @@ def test_tenco_train_oracle_matches_reference_step():
             _close(flat[:: max(1, flat.numel() // 2048)], z[key], tol=1e-4)
 
 
-def test_spatial_cnn_train_oracle_matches_reference_step():
+@pytest.mark.parametrize("name", ["cnn_train_resnet18", "cnn_train_resnet50_tiefree"])
+def test_spatial_cnn_train_oracle_matches_reference_step(name):
     """one Spatial_cnn step (`run.py:145-224`, train-mode BatchNorm + KD branch + hard/soft/KD losses + SGD) vs the fixture captured from
     the reference VideoNas + torch autograd + torch.optim.SGD"""
     from oracle import spatial_cnn_train as o_ct
-    z, cfg = load_golden("cnn_train_resnet18")
+    z, cfg = load_golden(name)
     table = shapes.spatial_cnn_shapes(cfg["network"])
     sd = o_ct.damp_residual_gamma(synth.fill_from_shapes(table, seed=cfg["seed"]), cfg["network"], cfg.get("damp", 1.0))
+    if cfg.get("tie_free"):
+        sd = o_ct.tie_free_bn(sd, cfg["network"])
     img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["H"], cfg["W"], seed=cfg["seed"]))
     labels = [torch.from_numpy((synth.uniform01(cfg["seed"], 700 + i, cfg["B"] * k) < 0.15).reshape(cfg["B"], k).astype(np.int64))
               for i, k in enumerate((6, 10, 15, 100))]
@@ -142,13 +145,17 @@ def test_spatial_cnn_train_oracle_matches_reference_step():
     new, terms, g = o_ct.train_step(sd, img, labels, tpred, tfeat, cfg["network"], cfg["lr"], 1e-5, cfg["rates"], 4.0)
     for key in ("loss", "hard", "soft", "kd"):
         assert abs(terms[key] - float(z[key])) < 2e-5 * max(1.0, abs(float(z[key]))), key
+    floor = max(1e-5, 1e-6 * float(z["grad_norms"].max()))    # (a gradient that is mathematically zero is rounding noise in any run)
     for k, ref in zip([k for k, _ in table], z["grad_norms"]):
         if ref >= 0:
-            assert abs(float(g[k].norm()) - ref) <= 1e-4 * max(ref, 1e-5), (k, float(g[k].norm()), ref)
+            assert abs(float(g[k].norm()) - ref) <= 1e-4 * max(ref, floor), (k, float(g[k].norm()), ref)
         else:
             assert k not in g or g[k] is None
     for key in z.files:
         if key.startswith("delta::"):
             k = key[len("delta::"):]
             flat = (new[k].float() - sd[k].float()).flatten()
-            _close(flat[:: max(1, flat.numel() // 2048)], z[key], tol=2e-4)
+            ref = torch.from_numpy(z[key])
+            ulp = 2.0 ** -22 * sd[k].float().abs().max().item()      # new - old is quantised by the parameter's own ulp
+            err = (flat[:: max(1, flat.numel() // 2048)] - ref).abs().max().item()
+            assert err <= 2e-4 * ref.abs().max().item() + ulp, (k, err, ref.abs().max().item())
