@@ -293,6 +293,38 @@ def student_resnet18_bench(dev, streams):
     return out
 
 
+def e2e_script_bench(dev):
+    """Script-level extraction rate: exactly the per-video loop `drivers.spatial_cnn_test` runs (`extract.extract_video_device`: the
+    video's frames in passes of --device_batch = 512 through the extractor, features + logits kept on the device, ONE pinned D2H per
+    video) on a synthetic 2000-frame video of 256x448 uint8 frames that is already on the device -- PNG decode and the host-side resize
+    input are excluded and stated; the D2H of features / logits and the per-video synchronisation are included.  Student network
+    of the shipped scripts (ResNet-18, `Scripts/test_fold1.sh`) and the bench's ResNet-50."""
+    from computervision_codes_amd import extract, shapes, synth
+    from computervision_codes_amd.spatial_cnn import VideoNas
+    out = {}
+    n = 2000
+    frames = device_frames(n, 256, 448, 321, dev)
+    for net in ("resnet18", "resnet50"):
+        args = types.SimpleNamespace(network=net, loss_type="all", student_dim=shapes.resnet_feat_dim(net), teacher_dim=1536, train=False)
+        for dt in (torch.bfloat16, torch.float32):
+            m = VideoNas(args=args, dtype=dt, device=str(dev)).eval().load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes(net), seed=3))
+            run = lambda: extract.extract_video_device(m, n, lambda s, e: frames[s:e], 512)
+            run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                feat, lgs = run()
+            dt_s = (time.perf_counter() - t0) / reps
+            assert feat.shape == (n, shapes.resnet_feat_dim(net)) and lgs[3].shape == (n, 100)
+            out[f"{net}_{'bf16' if dt == torch.bfloat16 else 'f32'}_256x448"] = dict(
+                frames_per_s=round(n / dt_s, 1), ms_per_video=round(dt_s * 1e3, 2), frames_per_video=n, device_batch=512,
+                includes="preprocess + trunk + heads + D2H of features and logits (pinned, once per video) + sync",
+                excludes="PNG decode and H2D of the frames (host side)")
+            del m
+    return out
+
+
 def spatial_train_bench(dev):
     """BASELINE configs[4] on one GPU: the student distillation step (`Spatial_cnn/run.py -t`, fp32, batch 8 of 256x448 frames as in
     Scripts/train_fold1.sh) -- forward, hard+soft+KD losses, backward, SGD; hipGraph replay of forward+backward."""
@@ -545,6 +577,7 @@ def main():
                 res["student_resnet18"] = student_resnet18_bench(dev, a.streams)
             res["swin_q2l"] = swin_bench(dev)
             res["spatial_train"] = spatial_train_bench(dev)
+            res["e2e_script"] = e2e_script_bench(dev)
             res["parity_mode_f32"] = parity_mode_bench(dev, a.network, a.height, a.width)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_spatial(a.network, a.height, a.width, 1234)

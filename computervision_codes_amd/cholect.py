@@ -74,18 +74,26 @@ def load_frames_u8(data_dir: str, video: str, frame_ids, height: int = 256, widt
     return out
 
 
-def load_frames_device(data_dir: str, video: str, frame_ids, height: int = 256, width: int = 448, device="cuda"):
+def load_frames_device(data_dir: str, video: str, frame_ids, height: int = 256, width: int = 448, device="cuda", workers: int = 0):
     """Same bytes as `load_frames_u8`, as a uint8 [N,H,W,3] tensor on the GPU: the PNGs are decoded on the host at their native size
     and `Resize((height,width))` runs on the device (`ops.resize_bilinear_u8`, byte-identical to Pillow's bilinear resize).  Frames
-    of one native size go through one launch pair; a video mixing sizes falls back to one group per size."""
+    of one native size go through one launch pair; a video mixing sizes falls back to one group per size.  workers > 1: the PNGs
+    are decoded by that many threads (Pillow releases the GIL while it inflates; the reference's loader has 3 worker processes,
+    `Spatial_cnn/test.py:240-241`)."""
     import torch
     from PIL import Image
 
     from . import ops
-    raw = []
-    for fid in frame_ids:
+
+    def decode(fid):
         with Image.open(os.path.join(data_dir, "data", video, "{}.png".format(str(int(fid)).zfill(6)))) as im:
-            raw.append(np.asarray(im.convert("RGB")))
+            return np.asarray(im.convert("RGB"))
+    if workers > 1 and len(frame_ids) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            raw = list(ex.map(decode, frame_ids))
+    else:
+        raw = [decode(fid) for fid in frame_ids]
     out = torch.empty((len(raw), height, width, 3), dtype=torch.uint8, device=device)
     groups: Dict[tuple, List[int]] = {}
     for i, a in enumerate(raw):

@@ -36,6 +36,8 @@ def _common(p: argparse.ArgumentParser):
     p.add_argument("--gpu", type=str, default="0")
     p.add_argument("--seed", type=int, default=47)
     p.add_argument("--dtype", type=str, default="fp32", choices=["fp32", "bf16"])
+    p.add_argument("--device_batch", type=int, default=512, help="frames per extraction pass on the GPU (results do not depend on it)")
+    p.add_argument("--decode_workers", type=int, default=8, help="host threads decoding PNGs")
 
 
 def _dist():
@@ -88,17 +90,14 @@ def spatial_cnn_test(argv=None) -> Dict[str, np.ndarray]:
     for vi in mine:
         v = videos[vi]
         lab = labels[v]
-        chunks = []
-        for s in range(0, len(lab["ivt"]), F.batch):           # file order, no shuffle, drop_last False
-            ids = lab["ivt"][s:s + F.batch, 0]
-            fr = cholect.load_frames_device(F.data_dir, v, ids, F.image_height, F.image_width)   # decode on the host, Resize on the GPU
-            (_, li), (_, lv), (_, lt), (feat, livt) = model.extract_u8(fr)
-            chunks.append(feat.float().cpu())
-            for key, lg in (("i", li), ("v", lv), ("t", lt), ("ivt", livt)):
-                m[key].update(lab[key][s:s + F.batch, 1:], _sigmoid(lg))
-        for r in m.values():
-            r.video_end()
-        feats_local[featfile.video_key(v)] = torch.vstack(chunks).numpy()
+        ids_all = lab["ivt"][:, 0]                             # file order, no shuffle, drop_last False (`test.py:227-242`)
+        load = lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.image_height, F.image_width,   # decode on the
+                                                       workers=F.decode_workers)                                # host, Resize on the GPU
+        feat, lgs = extract.extract_video_device(model, len(ids_all), load, F.device_batch)
+        for key, lg in zip(("i", "v", "t", "ivt"), lgs):
+            m[key].update(lab[key][:, 1:], torch.sigmoid(torch.from_numpy(lg)).numpy())   # `test.py:162-169`
+            m[key].video_end()
+        feats_local[featfile.video_key(v)] = np.array(feat)    # (own copy: the pinned staging buffer is released)
     merged = extract.gather_feats(feats_local)
     all_feats = {featfile.video_key(v): merged[featfile.video_key(v)] for v in videos}
     if rank == 0:
@@ -178,7 +177,8 @@ def spatial_cnn_train(argv=None) -> Dict[str, float]:
     logfile = os.path.join(model_dir, modelname + ".log")
     ckpt, latest = os.path.join(model_dir, modelname + ".pth"), os.path.join(model_dir, modelname + "_latest.pth")
     val_interval = F.epochs - 1 if F.val_interval == -1 else F.val_interval
-    tr = SpatialCnnTrainer(F.network, lr=F.initial_learning_rates[2], weight_decay=F.weight_decay, rates=F.rates, temp=float(F.temp))
+    tr = SpatialCnnTrainer(F.network, lr=F.initial_learning_rates[2], weight_decay=F.weight_decay, rates=F.rates, temp=float(F.temp),
+                           teacher_dim=F.teacher_dim)
     table = shapes.spatial_cnn_shapes(F.network, F.student_dim, F.teacher_dim)
     sd = synth.fill_from_shapes(table, seed=F.seed)          # no torch.nn init here: deterministic synthetic start
     for src in (F.pretrain_dir, latest):                     # `load_model` (:272-278): keys present in the model, strict=False

@@ -36,6 +36,29 @@ def extract_video(frames: torch.Tensor, forward: Callable[[torch.Tensor], torch.
     return torch.vstack(out).numpy() if out else np.zeros((0, 0), np.float32)
 
 
+def extract_video_device(model, n_frames: int, load_chunk: Callable[[int, int], torch.Tensor], device_batch: int = 512, streams: int = 1):
+    """One video through the spatial extractor the MI355X way (`Spatial_cnn/test.py:143-177` restated): frames [s, e) arrive as uint8
+    device tensors from `load_chunk(s, e)` in file order, `device_batch` of them per pass (a frame's result does not depend on the batch
+    it rides in -- bit-exact, tests/test_gpu_models.py -- so the reference's `--batch` need not bound the launch size); features and
+    the four heads' logits stay on the device until the video ends, then cross to the host ONCE through pinned memory.
+    Returns (feat [N,D] float32 ndarray, logits (i, v, t, ivt) float32 ndarrays)."""
+    feats, logits = [], [[], [], [], []]
+    for s in range(0, n_frames, device_batch):
+        fr = load_chunk(s, min(n_frames, s + device_batch))
+        (_, li), (_, lv), (_, lt), (feat, livt) = model.extract_u8(fr, streams=streams)
+        feats.append(feat)
+        for acc, lg in zip(logits, (li, lv, lt, livt)):
+            acc.append(lg)
+    if not feats:
+        return np.zeros((0, 0), np.float32), tuple(np.zeros((0, 0), np.float32) for _ in range(4))
+    dev_out = [torch.cat(feats).float()] + [torch.cat(l).float() for l in logits]
+    host = [torch.empty(t.shape, dtype=torch.float32, pin_memory=True) for t in dev_out]
+    for h, d in zip(host, dev_out):
+        h.copy_(d, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return host[0].numpy(), tuple(h.numpy() for h in host[1:])
+
+
 def gather_feats(local: Mapping[str, np.ndarray], group=None) -> Dict[str, np.ndarray]:
     """Merge per-rank {video -> [N,D]} dicts on every rank (host-side object gather; no-op for 1 rank)."""
     import torch.distributed as dist

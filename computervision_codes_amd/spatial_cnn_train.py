@@ -22,7 +22,7 @@ from .tenco_train import allreduce_sum_flat
 
 _DEPTHS = {"resnet18": (2, 2, 2, 2), "resnet50": (3, 4, 6, 3)}
 _HEADS = (("i", 6), ("v", 10), ("t", 15), ("ivt", 100))
-NH, NHP, TD = 131, 132, 1536
+NH, NHP = 131, 132
 # `Spatial_cnn/run.py:306-311`
 TOOL_W = [0.93487068, 0.94234964, 0.93487068, 1.18448115, 1.02368339, 0.97974447]
 VERB_W = [0.60002400, 0.60002400, 0.60002400, 0.61682467, 0.67082683, 0.80163207, 0.70562823, 2.11208448, 2.69230769, 0.60062402]
@@ -39,14 +39,15 @@ class _Unit:
 
 class SpatialCnnTrainer:
     def __init__(self, network: str = "resnet50", lr: float = 0.01, weight_decay: float = 1e-5, rates: Sequence[float] = (1.0, 1.0, 1.0),
-                 temp: float = 4.0, device: str = "cuda", process_group=None, overlap: bool = True):
+                 temp: float = 4.0, device: str = "cuda", process_group=None, overlap: bool = True, teacher_dim: int = 1536):
         self.network, self.lr, self.wd, self.rates, self.temp = network, lr, weight_decay, tuple(rates), float(temp)
         self.overlap = overlap            # DDP: all-reduce each gradient bucket as soon as the backward has written it (eager steps)
         self._pending: list = []
         self._capturing = False
         self.dev, self.pg = torch.device(device), process_group
         self.C = resnet_feat_dim(network)
-        self._table = spatial_cnn_shapes(network)
+        self.TD = int(teacher_dim)          # `--teacher_dim` (`Spatial_cnn/run.py:82`): width of the teachers' frame features
+        self._table = spatial_cnn_shapes(network, self.C, self.TD)
         self.units: Dict[str, _Unit] = {}
         self.nbt: Dict[str, int] = {}
         self._extra: Dict[str, torch.Tensor] = {}
@@ -76,6 +77,7 @@ class SpatialCnnTrainer:
         assert all(k in sd for k, _ in self._table), "state dict incomplete"
         dev, C = self.dev, self.C
         specs = self._unit_specs()
+        TD = self.TD
         lin = [("heads", NHP, C), ("wi", TD, C), ("wv", TD, C), ("wt", TD, C), ("mi", C, TD), ("mv", C, TD), ("mt", C, TD)]
         r4 = lambda n: (n + 3) // 4 * 4
         total = sum(co * ops.packed_k(ci, k, k, F32) + 2 * r4(co) for _, _, ci, co, k, _, _ in specs)

@@ -138,6 +138,37 @@ def test_spatial_cnn_bf16_mode(cuda, name):
     assert _maxerr(feat, z["feat"]) < 5e-2 * float(np.abs(z["feat"]).max())
 
 
+def _agreement(a, ref):
+    a, ref = a.float().cpu(), torch.as_tensor(np.asarray(ref)).float()
+    k = min(5, a.shape[1])
+    argmax = float((a.argmax(1) == ref.argmax(1)).float().mean())
+    top5 = float((a.topk(k, 1).indices.sort(1).values == ref.topk(k, 1).indices.sort(1).values).all(1).float().mean())
+    return argmax, top5
+
+
+def test_bf16_argmax_top5_agreement(cuda):
+    """The discrete readouts in the mode the headline number is quoted in.  bf16 extraction against the REFERENCE goldens: per-head argmax
+    and top-5 index sets identical on every golden frame (measured 100 % on all four fixtures, tools/argmax_probe.py); and at
+    bench.py's full step size, 1336 distinct frames, bf16 against the fp32 parity mode: measured 100 % / 100 % on every head (median
+    top-1 margin of the triplet head 1.86 against a bf16 logit error <= 0.08); asserted floor 99 % argmax, 98 % top-5 sets."""
+    for name in ("cnn_resnet50_224", "cnn_resnet18_224", "cnn_resnet50_256x448", "cnn_resnet50_small"):
+        z, cfg = load_golden(name)
+        out = _cnn_model(cfg, torch.bfloat16).extract_u8(synth.synthetic_frames(cfg["B"], cfg["H"], cfg["W"], seed=cfg["seed"]).to(cuda))
+        for gi, key in enumerate(("logit_i", "logit_v", "logit_t", "logit_ivt")):
+            assert _agreement(out[gi][1], z[key]) == (1.0, 1.0), (name, key, _agreement(out[gi][1], z[key]))
+    n = 1336
+    _, cfg = load_golden("cnn_resnet50_224")
+    base = synth.synthetic_frames(64, 224, 224, seed=11).to(cuda)
+    idx = torch.arange(n, device=cuda)
+    frames = (base[idx % 64] ^ ((idx // 64 * 37) % 256).to(torch.uint8)[:, None, None, None]).contiguous()
+    o16 = _cnn_model(cfg, torch.bfloat16).extract_u8(frames)
+    m32 = _cnn_model(cfg, torch.float32)
+    for gi in range(4):
+        l32 = torch.cat([m32.extract_u8(frames[s:s + 167].contiguous())[gi][1] for s in range(0, n, 167)])
+        am, t5 = _agreement(o16[gi][1], l32.cpu().numpy())
+        assert am >= 0.99 and t5 >= 0.98, (gi, am, t5)
+
+
 def test_spatial_cnn_batch_independence(cuda):
     """frames are independent units (the multi-GPU sharding premise): a frame's output does not depend on
     its batch neighbours or its position in the batch -- bit-exact."""
