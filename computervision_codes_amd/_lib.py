@@ -96,6 +96,14 @@ SIGNATURES = {
     "mt4_tcn_dilated_residual_layer": (C.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
     "mt4_tcn_stage": (C.c_int, [_vp] * 5 + [C.POINTER(_vp)] * 4 + [_i32] * 5 + [_vp]),
     "mt4_fpn_topdown": (C.c_int, [_vp, _vp, _i32, C.c_int64, _i32, _vp]),
+    "mt4_bgemm_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                C.c_float, _i32, _vp]),
+    "mt4_softmax_rows_f32": (C.c_int, [_vp, C.c_int64, _i32, C.c_float, _vp]),
+    "mt4_softmax_bwd_rows_f32": (C.c_int, [_vp, _vp, C.c_int64, _i32, C.c_float, _vp]),
+    "mt4_layernorm_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, C.c_float, _i32, _vp]),
+    "mt4_gelu_bwd_f32": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "mt4_dwconv1d_k3_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "mt4_axpby_f32": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_float, _vp]),
 }
 
 

@@ -1,0 +1,380 @@
+// Backward-pass pieces of the transformer-shaped temporal teacher (MS-TCT, `Temporal_mstct/MSTCT/Temporal_Encoder.py`, trained by
+// `Temporal_mstct/run.py:147-235` through torch autograd): what autograd derives for nn.LayerNorm, the softmax attention of
+// Global_Relational_Block (:76-88), nn.GELU and the depthwise Conv1d of Local_Relational_Block (:34-43).  fp32 throughout (the parity
+// mode of the trainers); GEMM-shaped work runs on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
+#include "mt4_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ strided batched GEMM
+// C[b1][b0] (M x N) = alpha * A[b1][b0] (M x K) . B[b1][b0] (K x N) (+ C when beta != 0); every operand is addressed by element strides,
+// so transposes and head slices of packed projection buffers ([B*T][heads*hd]) need no copies.  64 x 64 tile per workgroup of four
+// waves (2 x 2, wave tile 32 x 32 = 2 x 2 MFMA tiles), K-steps of 16 staged through LDS k-major (As[k][m], Bs[k][n]): the fragment of
+// lane (r16, q) is one word of row k0 + q, so the 16 lanes of a quad read 16 consecutive words.
+struct BgemmK {
+    const float* A; const float* B; float* C;
+    int M, N, K, nb0;
+    long long a_b0, a_b1, a_m, a_k;
+    long long b_b0, b_b1, b_k, b_n;
+    long long c_b0, c_b1, c_m, c_n;
+    float alpha; int beta;
+};
+
+__global__ __launch_bounds__(256) void bgemm_f32_kernel(const BgemmK p) {
+    constexpr int BT = 64, KS = 16, LD = BT + 16;   // +16 words: the two quads of a 32-lane ds_read_b32 group land on disjoint banks
+    __shared__ float As[2][KS][LD];
+    __shared__ float Bs[2][KS][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int b = blockIdx.z;
+    const int b1 = b / p.nb0, b0 = b - b1 * p.nb0;
+    const float* A = p.A + b0 * p.a_b0 + b1 * p.a_b1;
+    const float* B = p.B + b0 * p.b_b0 + b1 * p.b_b1;
+    float* C = p.C + b0 * p.c_b0 + b1 * p.c_b1;
+    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+    // staging map: 1024 elements per operand and K-step, 4 per thread.  k-fast when the operand is contiguous along k (16 lanes read
+    // one 64-byte run), else m-fast / n-fast (64 lanes read one 256-byte run when that stride is 1)
+    const bool a_kfast = p.a_k == 1, b_kfast = p.b_k == 1;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            const int ka = a_kfast ? (e & 15) : (e >> 6), ma = a_kfast ? (e >> 4) : (e & 63);
+            const int kb = b_kfast ? (e & 15) : (e >> 6), nb = b_kfast ? (e >> 4) : (e & 63);
+            ra[i] = (m0 + ma < p.M && k0 + ka < p.K) ? A[(long long)(m0 + ma) * p.a_m + (long long)(k0 + ka) * p.a_k] : 0.f;
+            rb[i] = (n0 + nb < p.N && k0 + kb < p.K) ? B[(long long)(k0 + kb) * p.b_k + (long long)(n0 + nb) * p.b_n] : 0.f;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            const int ka = a_kfast ? (e & 15) : (e >> 6), ma = a_kfast ? (e >> 4) : (e & 63);
+            const int kb = b_kfast ? (e & 15) : (e >> 6), nb = b_kfast ? (e >> 4) : (e & 63);
+            As[buf][ka][ma] = ra[i];
+            Bs[buf][kb][nb] = rb[i];
+        }
+    };
+    const int nk = (p.K + KS - 1) / KS;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int s = 0; s < nk; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nk) fetch((s + 1) * KS);          // next K-step's global loads fly during the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < KS; kk += 4) {
+            float fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = As[buf][kk + q][wm + i * 16 + r16];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = Bs[buf][kk + q][wn + j * 16 + r16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nk) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // accumulator lane (r16, q) holds rows m = 4q + e, column n = r16 of its 16 x 16 tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + j * 16 + r16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm + i * 16 + q * 4 + e;
+                if (m < p.M && n < p.N) {
+                    float* c = C + (long long)m * p.c_m + (long long)n * p.c_n;
+                    const float v = p.alpha * acc[i][j][e];
+                    *c = p.beta ? *c + v : v;
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ softmax rows, forward and backward
+// P = softmax(scale * S) in place; one wave per row, cols <= 64 * 16
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S, long long rows, int cols, float scale) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* s = S + row * cols;
+    float v[16];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < cols ? s[c] * scale : -3.0e38f;
+        mx = fmaxf(mx, v[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        v[i] = (lane + 64 * i) < cols ? __expf(v[i] - mx) : 0.f;
+        sum += v[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        if (c < cols) s[c] = v[i] * inv;
+    }
+}
+
+// dS = scale * P .* (dP - rowsum(P .* dP)), written over dP
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dP, long long rows, int cols,
+                                                                float scale) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = P + row * cols;
+    float* d = dP + row * cols;
+    float pv[16], dv[16];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        pv[i] = c < cols ? p[c] : 0.f;
+        dv[i] = c < cols ? d[c] : 0.f;
+        dot += pv[i] * dv[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        if (c < cols) d[c] = scale * pv[i] * (dv[i] - dot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// y = (x - mean) * rstd * gamma + beta over the last dimension (nn.LayerNorm, eps inside the sqrt, biased variance).
+//   g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dgamma += sum_rows dy * xhat;  dbeta += sum_rows dy
+// One wave per row at a time (C <= 64 * 16), statistics recomputed from x; a wave keeps its dgamma / dbeta partial sums in registers
+// over all its rows and adds them to the (caller-zeroed or accumulating) gradient buffers once, with float atomics.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             long long M, int C, float eps, int add_dx) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * 4;
+    float gm[16], pg[16], pb[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        gm[i] = c < C ? gamma[c] : 0.f;
+        pg[i] = pb[i] = 0.f;
+    }
+    const float invC = 1.0f / (float)C;
+    for (long long row = wave; row < M; row += nwaves) {
+        const float* xr = x + row * C;
+        const float* dr = dy + row * C;
+        float xv[16], dv[16];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = lane + 64 * i;
+            xv[i] = c < C ? xr[c] : 0.f;
+            dv[i] = c < C ? dr[c] : 0.f;
+            s += xv[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * invC;
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float d = (lane + 64 * i) < C ? xv[i] - mean : 0.f;
+            var += d * d;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+        const float rstd = rsqrtf(var * invC + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float xh = (xv[i] - mean) * rstd;
+            const float g = dv[i] * gm[i];
+            xv[i] = xh;                 // keep xhat
+            sg += g;
+            sgx += g * xh;
+            pg[i] += dv[i] * xh;
+            pb[i] += dv[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sg += __shfl_xor(sg, o); sgx += __shfl_xor(sgx, o); }
+        sg *= invC;
+        sgx *= invC;
+        float* dxr = dx + row * C;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) {
+                const float v = rstd * (dv[i] * gm[i] - sg - xv[i] * sgx);
+                dxr[c] = add_dx ? dxr[c] + v : v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) {
+            atomicAdd(dgamma + c, pg[i]);
+            atomicAdd(dbeta + c, pb[i]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GELU backward (erf form)
+// dx = dy * (Phi(x) + x phi(x)),  Phi by the same Abramowitz-Stegun erf as the forward (gelu_erf), phi(x) = exp(-x^2/2) / sqrt(2 pi)
+__global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long long n) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 d4 = *(const float4*)(dy + i);
+    const float4 x4 = *(const float4*)(x + i);
+    const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float v = xx[e];
+        const float ax = fabsf(v) * 0.70710678118654752440f;
+        const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+        float pl = fmaf(1.061405429f, t, -1.453152027f);
+        pl = fmaf(pl, t, 1.421413741f);
+        pl = fmaf(pl, t, -0.284496736f);
+        pl = fmaf(pl, t, 0.254829592f);
+        const float ex = __expf(-ax * ax);                       // exp(-x^2/2)
+        const float erfa = 1.0f - pl * t * ex;
+        const float Phi = 0.5f * (1.0f + copysignf(erfa, v));
+        o[e] = dd[e] * (Phi + v * 0.3989422804014327f * ex);
+    }
+    *(float4*)(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise Conv1d k = 3 backward
+// y[t][c] = b[c] + sum_k w[c][k] x[t + k - 1][c] per sequence of T frames (zero padding).
+//   dx[t][c] = w[c][0] dy[t+1][c] + w[c][1] dy[t][c] + w[c][2] dy[t-1][c]
+//   dw[c][k] += sum_t dy[t][c] x[t + k - 1][c];   db[c] += sum_t dy[t][c]
+// One thread per channel over a slab of rows of one sequence (coalesced across channels); partial sums -> float atomics.
+__global__ void dwconv1d_k3_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
+                                       float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int T, int C, int slab) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int seq = blockIdx.z, t0 = blockIdx.y * slab;
+    const int t1 = min(T, t0 + slab);
+    const long long base = (long long)seq * T * C + c;
+    const float w0 = w[c * 3 + 0], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ab = 0.f;
+    float dprev = t0 > 0 ? dy[base + (long long)(t0 - 1) * C] : 0.f;
+    float dcur = dy[base + (long long)t0 * C];
+    float xprev = t0 > 0 ? x[base + (long long)(t0 - 1) * C] : 0.f;
+    float xcur = x[base + (long long)t0 * C];
+    for (int t = t0; t < t1; ++t) {
+        const float dnext = t + 1 < T ? dy[base + (long long)(t + 1) * C] : 0.f;
+        const float xnext = t + 1 < T ? x[base + (long long)(t + 1) * C] : 0.f;
+        dx[base + (long long)t * C] = w0 * dnext + w1 * dcur + w2 * dprev;
+        a0 += dcur * xprev;
+        a1 += dcur * xcur;
+        a2 += dcur * xnext;
+        ab += dcur;
+        dprev = dcur; dcur = dnext;
+        xprev = xcur; xcur = xnext;
+    }
+    atomicAdd(dw + c * 3 + 0, a0);
+    atomicAdd(dw + c * 3 + 1, a1);
+    atomicAdd(dw + c * 3 + 2, a2);
+    atomicAdd(db + c, ab);
+}
+
+// y = a * x + b * y   (gradient fan-in, summed mixer weights)
+__global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float a, float b) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 xv = *(const float4*)(x + i);
+    float4 yv = b != 0.f ? *(const float4*)(y + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    yv.x = a * xv.x + b * yv.x; yv.y = a * xv.y + b * yv.y; yv.z = a * xv.z + b * yv.z; yv.w = a * xv.w + b * yv.w;
+    *(float4*)(y + i) = yv;
+}
+
+}  // namespace
+
+extern "C" int mt4_bgemm_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t nb0, int32_t nb1,
+                             const int64_t a_strides[4], const int64_t b_strides[4], const int64_t c_strides[4], float alpha, int32_t accumulate,
+                             void* stream) {
+    mt4_clear_error();
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || nb0 <= 0 || nb1 <= 0 || !a_strides || !b_strides || !c_strides) return MT4_EINVAL;
+    if ((long long)nb0 * nb1 > 65535) return MT4_EUNSUPPORTED;
+    BgemmK p{A, B, C, M, N, K, nb0, a_strides[0], a_strides[1], a_strides[2], a_strides[3], b_strides[0], b_strides[1], b_strides[2], b_strides[3],
+             c_strides[0], c_strides[1], c_strides[2], c_strides[3], alpha, accumulate ? 1 : 0};
+    hipLaunchKernelGGL(bgemm_f32_kernel, dim3(cdiv(N, 64), cdiv(M, 64), nb0 * nb1), dim3(256), 0, (hipStream_t)stream, p);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_softmax_rows_f32(float* S, int64_t rows, int32_t cols, float scale, void* stream) {
+    mt4_clear_error();
+    if (!S || rows <= 0 || cols <= 0) return MT4_EINVAL;
+    if (cols > 1024) return MT4_EUNSUPPORTED;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, (long long)rows, cols, scale);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_softmax_bwd_rows_f32(const float* P, float* dP, int64_t rows, int32_t cols, float scale, void* stream) {
+    mt4_clear_error();
+    if (!P || !dP || rows <= 0 || cols <= 0) return MT4_EINVAL;
+    if (cols > 1024) return MT4_EUNSUPPORTED;
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, dP, (long long)rows, cols, scale);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta, int64_t M,
+                                     int32_t C, float eps, int32_t accumulate_dx, void* stream) {
+    mt4_clear_error();
+    if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || M <= 0 || C <= 0) return MT4_EINVAL;
+    if (C > 1024) return MT4_EUNSUPPORTED;
+    long long blocks = (M + 31) / 32;                       // a wave takes ~8 rows: few atomics, enough waves
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, dx, dgamma, dbeta, (long long)M, C,
+                       eps, accumulate_dx ? 1 : 0);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_gelu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, void* stream) {
+    mt4_clear_error();
+    if (!dy || !x || !dx || n <= 0 || (n & 3)) return MT4_EINVAL;
+    if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 15) return MT4_EALIGN;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, (long long)n);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_dwconv1d_k3_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int32_t B, int32_t T,
+                                       int32_t C, void* stream) {
+    mt4_clear_error();
+    if (!dy || !x || !w || !dx || !dw || !db || B <= 0 || T <= 0 || C <= 0) return MT4_EINVAL;
+    if (B > 65535) return MT4_EUNSUPPORTED;
+    const int slab = 32;
+    hipLaunchKernelGGL(dwconv1d_k3_bwd_kernel, dim3(cdiv(C, 256), cdiv(T, slab), B), dim3(256), 0, (hipStream_t)stream, dy, x, w, dx, dw, db, T, C, slab);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_axpby_f32(const float* x, float* y, int64_t n, float a, float b, void* stream) {
+    mt4_clear_error();
+    if (!x || !y || n <= 0 || (n & 3)) return MT4_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return MT4_EALIGN;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n, a, b);
+    return mt4_check_launch();
+}

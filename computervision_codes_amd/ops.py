@@ -665,3 +665,74 @@ def kd_mix_bwd(s, teas, gs):
     check(lib.mt4_kd_mix_bwd_f32(s.data_ptr(), teas[0].data_ptr(), teas[1].data_ptr(), teas[2].data_ptr(), gs[0].data_ptr(), gs[1].data_ptr(),
                                  gs[2].data_ptr(), ds.data_ptr(), dtau.data_ptr(), b, c, _stream()), "mt4_kd_mix_bwd_f32")
     return ds, dtau
+
+
+# ----------------------------------------------------------------------------------------- MS-TCT training pieces (fp32)
+def bgemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, m: int, n: int, k: int, nb0: int, nb1: int, a_strides, b_strides, c_strides,
+          alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
+    """strided batched GEMM `mt4_bgemm_f32`: C[b1][b0] = alpha * A.B (+C); strides {b0, b1, rows, cols} in elements; a / b / c are the tensors
+    whose data_ptr is the origin (storage offsets of views are honoured)"""
+    _need_cuda(a, b, c)
+    assert a.dtype == b.dtype == c.dtype == torch.float32
+    i64x4 = C.c_int64 * 4
+    check(lib.mt4_bgemm_f32(a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, nb0, nb1, i64x4(*a_strides), i64x4(*b_strides), i64x4(*c_strides),
+                            alpha, 1 if accumulate else 0, _stream()), "mt4_bgemm_f32")
+    return c
+
+
+def softmax_rows_(s: torch.Tensor, scale: float) -> torch.Tensor:
+    """in place: rows of the last dimension -> softmax(scale * row)"""
+    _need_cuda(s)
+    assert s.dtype == torch.float32 and s.is_contiguous()
+    check(lib.mt4_softmax_rows_f32(s.data_ptr(), s.numel() // s.shape[-1], s.shape[-1], scale, _stream()), "mt4_softmax_rows_f32")
+    return s
+
+
+def softmax_bwd_rows_(p: torch.Tensor, dp: torch.Tensor, scale: float) -> torch.Tensor:
+    """dp <- scale * p .* (dp - rowsum(p .* dp))"""
+    _need_cuda(p, dp)
+    assert p.dtype == dp.dtype == torch.float32 and p.is_contiguous() and dp.is_contiguous() and p.shape == dp.shape
+    check(lib.mt4_softmax_bwd_rows_f32(p.data_ptr(), dp.data_ptr(), p.numel() // p.shape[-1], p.shape[-1], scale, _stream()),
+          "mt4_softmax_bwd_rows_f32")
+    return dp
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
+                  dx: Optional[torch.Tensor] = None, accumulate_dx: bool = False, eps: float = 1e-5) -> torch.Tensor:
+    """dgamma / dbeta are ADDED to; dx is written (or added to with accumulate_dx)"""
+    _need_cuda(dy, x, gamma, dgamma, dbeta, dx)
+    m, c = x.shape
+    assert dy.is_contiguous() and x.is_contiguous() and dy.shape == x.shape and dy.dtype == x.dtype == torch.float32
+    if dx is None:
+        assert not accumulate_dx
+        dx = torch.empty_like(x)
+    check(lib.mt4_layernorm_bwd_f32(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), m, c, eps,
+                                    1 if accumulate_dx else 0, _stream()), "mt4_layernorm_bwd_f32")
+    return dx
+
+
+def gelu_bwd(dy: torch.Tensor, x_pre: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_cuda(dy, x_pre, out)
+    assert dy.is_contiguous() and x_pre.is_contiguous() and dy.numel() == x_pre.numel() and dy.dtype == torch.float32
+    dx = torch.empty_like(dy) if out is None else out
+    check(lib.mt4_gelu_bwd_f32(dy.data_ptr(), x_pre.data_ptr(), dx.data_ptr(), dy.numel(), _stream()), "mt4_gelu_bwd_f32")
+    return dx
+
+
+def dwconv1d_k3_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, dw: torch.Tensor, db: torch.Tensor) -> torch.Tensor:
+    """dy, x [B,T,C]; w [C,3]; dw [C,3] / db [C] are ADDED to; returns dx"""
+    _need_cuda(dy, x, w, dw, db)
+    b, t, c = x.shape
+    assert dy.is_contiguous() and x.is_contiguous() and dy.shape == x.shape and w.is_contiguous() and dw.is_contiguous()
+    dx = torch.empty_like(x)
+    check(lib.mt4_dwconv1d_k3_bwd_f32(dy.data_ptr(), x.data_ptr(), w.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), b, t, c, _stream()),
+          "mt4_dwconv1d_k3_bwd_f32")
+    return dx
+
+
+def axpby_(x: torch.Tensor, y: torch.Tensor, a: float = 1.0, b: float = 1.0) -> torch.Tensor:
+    """y <- a * x + b * y"""
+    _need_cuda(x, y)
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel() and x.dtype == y.dtype == torch.float32
+    check(lib.mt4_axpby_f32(x.data_ptr(), y.data_ptr(), x.numel(), a, b, _stream()), "mt4_axpby_f32")
+    return y

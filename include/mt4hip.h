@@ -296,6 +296,33 @@ int mt4_tcn_stage(const void* x, void* buf_a, void* buf_b, void* h, void* y, con
  * identity): levels[l] = lat[l] + levels[l+1] for l = nlev-2 .. 0, in place.  lat [nlev-1][n], levels [nlev][n] of dtype, n % 4 == 0. */
 int mt4_fpn_topdown(const void* lat, void* levels, int32_t nlev, int64_t n, int32_t dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward pieces of the transformer-shaped temporal teacher MS-TCT (what torch autograd derives inside
+ * Temporal_mstct/run.py:147-235 for Temporal_mstct/MSTCT/Temporal_Encoder.py).  float32.
+ */
+/* Strided batched GEMM: C[b1][b0] (M x N) = alpha * A[b1][b0] (M x K) . B[b1][b0] (K x N)  (+ C when accumulate).
+ * *_strides = element strides {batch-inner b0, batch-outer b1, rows, cols}: for A {b0, b1, m, k}, for B {b0, b1, k, n}, for C {b0, b1, m, n}.
+ * Transposes and head slices of a packed projection buffer ([B*T][heads*hd]: b0 = head -> hd, b1 = sequence -> T*C) are strides, not
+ * copies: q.k^T, P.v and the four products of the attention backward (Temporal_Encoder.py:76-88) all go through it.  nb0*nb1 <= 65535. */
+int mt4_bgemm_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t nb0, int32_t nb1,
+                  const int64_t a_strides[4], const int64_t b_strides[4], const int64_t c_strides[4], float alpha, int32_t accumulate,
+                  void* stream);
+/* P = softmax(scale * S) over the last dimension, in place (Temporal_Encoder.py:82-83); cols <= 1024 */
+int mt4_softmax_rows_f32(float* S, int64_t rows, int32_t cols, float scale, void* stream);
+/* dS = scale * P .* (dP - rowsum(P .* dP)), written over dP */
+int mt4_softmax_bwd_rows_f32(const float* P, float* dP, int64_t rows, int32_t cols, float scale, void* stream);
+/* nn.LayerNorm backward: dx (written, or added to when accumulate_dx), dgamma / dbeta ADDED to (float atomics; zero or pre-fill them).
+ * Statistics are recomputed from x.  C <= 1024. */
+int mt4_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta, int64_t M, int32_t C,
+                          float eps, int32_t accumulate_dx, void* stream);
+/* nn.GELU (erf form) backward: dx = dy * gelu'(x) with x the pre-activation; n % 4 == 0 */
+int mt4_gelu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+/* backward of mt4_dwconv1d_k3 (depthwise Conv1d k3 pad 1, Temporal_Encoder.py:12,38): dx written, dw [C][3] / db [C] ADDED to */
+int mt4_dwconv1d_k3_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int32_t B, int32_t T, int32_t C,
+                            void* stream);
+/* y = a * x + b * y (b == 0: y is not read); n % 4 == 0 */
+int mt4_axpby_f32(const float* x, float* y, int64_t n, float a, float b, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -491,7 +491,81 @@ def gen_cnn_train(name):
         torch.set_grad_enabled(False)
 
 
+# ------------------------------------------------------------------------------------------ MS-TCT train step
+MSTCT_TRAIN_CASES = {
+    "mstct_train_tiny": dict(D=64, inter=(32, 48, 64, 96), final=32, T=40, B=3, loss_type="v", seed=701, lr=0.1),
+    "mstct_train_full": dict(D=512, inter=(256, 384, 576, 864), final=512, T=256, B=2, loss_type="ivt", seed=702, lr=0.1),
+}
+
+
+def mstct_train_inputs(cfg):
+    x = torch.cat([synth.synthetic_features(cfg["T"], cfg["D"], seed=cfg["seed"] + b) for b in range(cfg["B"])], 0).permute(0, 2, 1).contiguous()
+    k = {"i": 6, "v": 10, "t": 15, "ivt": 100}[cfg["loss_type"]]
+    y = torch.from_numpy((synth.uniform01(cfg["seed"], 800, cfg["B"] * cfg["T"] * k) < 0.15).reshape(cfg["B"], cfg["T"], k).astype(np.int64))
+    return x, y
+
+
+def gen_mstct_train(name):
+    """The reference `VideoNas` in train() mode with its two nn.Dropout modules set to p = 0 (their draw comes from torch's global RNG;
+    the dropout pieces are pinned oracle-vs-HIP with explicit masks), the loss loop of `run.py:159-192` and torch.optim.SGD for one step."""
+    from oracle import mstct_train as o_mt
+    cfg = MSTCT_TRAIN_CASES[name]
+    torch.set_grad_enabled(True)
+    try:
+        m = _ref_mstct(cfg)
+        m.train()
+        m.dropout.p = 0.0
+        getattr(m, "classifier_" + cfg["loss_type"]).dropout.p = 0.0
+        table = shapes.mstct_shapes(cfg["D"], cfg["inter"], 2, 8, cfg["final"], cfg["loss_type"])
+        sd = synth.fill_from_shapes(table, seed=cfg["seed"])
+        m.load_state_dict(sd, strict=True)
+        x, y = mstct_train_inputs(cfg)
+        lt = cfg["loss_type"]
+        pw = o_mt.POS_W[lt]
+        fn = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(pw)) if pw is not None else torch.nn.BCEWithLogitsLoss()
+        opt = torch.optim.SGD(m.parameters(), lr=cfg["lr"], weight_decay=1e-5)
+        out = m(x)
+        logits = out[{"i": 0, "v": 1, "t": 2, "ivt": 3}[lt]][0]
+        loss = sum(fn(logits[i], y[i].float()) for i in range(len(x))) / len(x)        # `run.py:159-187`
+        for p_ in m.parameters():
+            p_.grad = None
+        loss.backward()
+        grads = {k: (p_.grad.clone() if p_.grad is not None else None) for k, p_ in m.named_parameters()}
+        opt.step()
+        new_ref = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        new_o, loss_o, g_o = o_mt.train_step(sd, x, y, lt, cfg["lr"], 1e-5)
+        assert abs(loss_o - float(loss)) < 2e-5 * max(1, abs(float(loss))), (loss_o, float(loss))
+        worst = 0.0
+        for k in new_ref:
+            e = _rel(new_o[k].float(), new_ref[k].float())
+            worst = max(worst, e)
+            assert e < 2e-4, (name, k, e)
+        keys = [k for k, _ in table]
+        assert all(grads[k] is not None for k in keys)
+        _, _, g64 = o_mt.train_step_f64(sd, x, y, lt, cfg["lr"], 1e-5)
+        outd = {"cfg": np.array(repr(cfg)), "loss": np.array(float(loss)),
+                "grad_norms": np.array([float(grads[k].norm()) for k in keys], dtype=np.float64),
+                "grad_cond": np.array([float((grads[k].double() - g64[k]).abs().max() / max(float(g64[k].abs().max()), 1e-30)) for k in keys],
+                                      dtype=np.float64)}
+        samp = ["TemporalEncoder.Temporal_Merging_Block1.proj.weight", "TemporalEncoder.Temporal_Merging_Block1.norm.weight",
+                "TemporalEncoder.block1.0.norm1.bias", "TemporalEncoder.block1.0.Global_Relational_Block.q.weight",
+                "TemporalEncoder.block1.1.Global_Relational_Block.kv.weight", "TemporalEncoder.block2.0.Global_Relational_Block.proj.bias",
+                "TemporalEncoder.block3.1.Local_Relational_Block.linear1.weight", "TemporalEncoder.block3.1.Local_Relational_Block.TC.weight",
+                "TemporalEncoder.block4.0.Local_Relational_Block.TC.bias", "TemporalEncoder.block4.1.Local_Relational_Block.linear2.weight",
+                "TemporalEncoder.norm4.weight", "Temporal_Mixer.linear_f2.proj.weight", "Temporal_Mixer.linear1.weight", "Temporal_Mixer.linear9.bias",
+                f"classifier_{lt}.linear_fuse.weight", f"classifier_{lt}.linear_pred.bias"]
+        for k in samp:
+            flat = (new_ref[k].float() - sd[k].float()).flatten()
+            outd["delta::" + k] = flat[:: max(1, flat.numel() // 2048)].numpy()
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **outd)
+        print(name, "ok: loss", float(loss), "worst oracle-vs-ref rel", worst, "grad_cond median", float(np.median(outd["grad_cond"])),
+              "max", float(outd["grad_cond"].max()))
+    finally:
+        torch.set_grad_enabled(False)
+
+
 GENERATORS = {}
+GENERATORS.update({k: gen_mstct_train for k in MSTCT_TRAIN_CASES})
 GENERATORS.update({k: gen_tenco for k in TENCO_CASES})
 GENERATORS.update({k: gen_cnn for k in CNN_CASES})
 GENERATORS.update({k: gen_q2l for k in Q2L_CASES})

@@ -60,3 +60,25 @@ def test_tenco_two_rank_step_equals_mean_gradient_step(cuda, tmp_path):
     want = trs[0].state_dict()
     for k in want:
         assert (got[k].float() - want[k].float()).abs().max().item() <= 2e-6 * max(1.0, want[k].float().abs().max().item()), k
+
+
+def test_mstct_two_rank_step_equals_mean_gradient_step(cuda, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "helpers"))
+    from ddp_mstct_worker import trainer, windows
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29534", os.path.join(ROOT, "tests", "helpers", "ddp_mstct_worker.py"), str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    got = torch.load(tmp_path / "ddp_mstct.pth", map_location="cpu")
+    trs = []
+    for rank in (0, 1):
+        tr = trainer()
+        x, y = windows(rank)
+        tr.train_step(x.to(cuda), y, apply_update=False)
+        trs.append(tr)
+    trs[0].G.add_(trs[1].G).mul_(0.5)
+    trs[0].apply_update()
+    want = trs[0].state_dict()
+    for k in want:
+        assert (got[k].float() - want[k].float()).abs().max().item() <= 2e-6 * max(1.0, want[k].float().abs().max().item()), k

@@ -159,3 +159,26 @@ def test_spatial_cnn_train_oracle_matches_reference_step(name):
             ulp = 2.0 ** -22 * sd[k].float().abs().max().item()      # new - old is quantised by the parameter's own ulp
             err = (flat[:: max(1, flat.numel() // 2048)] - ref).abs().max().item()
             assert err <= 2e-4 * ref.abs().max().item() + ulp, (k, err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["mstct_train_tiny"])
+def test_mstct_train_oracle_matches_reference_step(name):
+    """one Temporal_mstct step (`run.py:147-235`, dropout off) vs the fixture captured from the reference VideoNas + torch autograd + SGD"""
+    from oracle import mstct_train as o_mt
+    z, cfg = load_golden(name)
+    table = shapes.mstct_shapes(cfg["D"], cfg["inter"], 2, 8, cfg["final"], cfg["loss_type"])
+    sd = synth.fill_from_shapes(table, seed=cfg["seed"])
+    x = torch.cat([synth.synthetic_features(cfg["T"], cfg["D"], seed=cfg["seed"] + b) for b in range(cfg["B"])], 0).permute(0, 2, 1).contiguous()
+    k = {"i": 6, "v": 10, "t": 15, "ivt": 100}[cfg["loss_type"]]
+    y = torch.from_numpy((synth.uniform01(cfg["seed"], 800, cfg["B"] * cfg["T"] * k) < 0.15).reshape(cfg["B"], cfg["T"], k).astype(np.int64))
+    new, loss, g = o_mt.train_step(sd, x, y, cfg["loss_type"], cfg["lr"], 1e-5)
+    assert abs(loss - float(z["loss"])) < 2e-5 * max(1.0, abs(float(z["loss"])))
+    for kname, ref in zip([k_ for k_, _ in table], z["grad_norms"]):
+        assert abs(float(g[kname].norm()) - ref) <= 1e-4 * max(ref, 1e-6 * float(z["grad_norms"].max())), kname
+    for key in z.files:
+        if key.startswith("delta::"):
+            kname = key[len("delta::"):]
+            flat = (new[kname] - sd[kname]).flatten()
+            ref = torch.from_numpy(z[key])
+            ulp = 2.0 ** -22 * sd[kname].abs().max().item()
+            assert (flat[:: max(1, flat.numel() // 2048)] - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + ulp, kname
