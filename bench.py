@@ -226,7 +226,7 @@ def mstct_train_bench(dev):
         synth.fill_from_shapes(shapes.mstct_shapes(D, (256, 384, 576, 864), 2, 8, 512, "i"), seed=47))
     x = torch.randn(B, T, D, device=dev)
     z = (torch.rand(B * T, 6, device=dev) < 0.15).float()
-    masks = tr.draw_masks(B, T, torch.Generator().manual_seed(1))
+    masks = tr.draw_masks_device(B, T, 1, 0)
     ms = _time_call(lambda: tr.train_step_btd(x, z, masks=masks), iters=5)
     ms_g = _time_call(lambda: tr.train_step_btd(x, z, masks=masks, use_graph=True), iters=5)
     gflop = 3 * 31.2 * B     # ~3x the forward: 31.4 GFLOP per window at D = 2048, 31.2 at D = 1536 (D enters the first conv only)

@@ -101,8 +101,10 @@ SIGNATURES = {
     "mt4_softmax_rows_f32": (C.c_int, [_vp, C.c_int64, _i32, C.c_float, _vp]),
     "mt4_softmax_bwd_rows_f32": (C.c_int, [_vp, _vp, C.c_int64, _i32, C.c_float, _vp]),
     "mt4_layernorm_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, C.c_float, _i32, _vp]),
+    "mt4_gelu_f32": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "mt4_gelu_bwd_f32": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "mt4_dwconv1d_k3_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "mt4_dropout_mask_f32": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_float, _vp]),
     "mt4_axpby_f32": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_float, _vp]),
 }
 

@@ -265,6 +265,14 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __res
     *(float4*)(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// nn.GELU forward on a saved pre-activation (the training step keeps both): the same gelu_erf as the fused epilogues
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 v = *(const float4*)(x + i);
+    *(float4*)(y + i) = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+}
+
 // ------------------------------------------------------------------------------------------------ depthwise Conv1d k = 3 backward
 // y[t][c] = b[c] + sum_k w[c][k] x[t + k - 1][c] per sequence of T frames (zero padding).
 //   dx[t][c] = w[c][0] dy[t+1][c] + w[c][1] dy[t][c] + w[c][2] dy[t-1][c]
@@ -310,7 +318,38 @@ __global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y,
     *(float4*)(y + i) = yv;
 }
 
+// nn.Dropout(p) mask from a counter generator: element i = splitmix64(base + i), base = splitmix64(seed * 0x100000001B3 + stream) -- the
+// same function as computervision_codes_amd/synth.py:uniform01, so the host can reproduce a draw bit for bit.
+// out[i] = u_i >= p ? 1 / (1 - p) : 0
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__global__ void dropout_mask_kernel(float* __restrict__ out, long long n, unsigned long long base, float p, float keep_scale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double u = (double)(splitmix64(base + (unsigned long long)i) >> 11) * (1.0 / 9007199254740992.0);
+    out[i] = u >= (double)p ? keep_scale : 0.f;
+}
+
 }  // namespace
+
+extern "C" int mt4_dropout_mask_f32(float* out, int64_t n, int64_t seed, int64_t stream_id, float p, void* stream) {
+    mt4_clear_error();
+    if (!out || n <= 0 || p < 0.f || p >= 1.f) return MT4_EINVAL;
+    unsigned long long x = (unsigned long long)seed * 0x100000001B3ULL + (unsigned long long)stream_id;
+    x += 0x9E3779B97F4A7C15ULL;                     // (splitmix64 on the host: same arithmetic as the device function)
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    const unsigned long long base = z ^ (z >> 31);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long long)n, base, p,
+                       1.0f / (1.0f - p));
+    return mt4_check_launch();
+}
 
 extern "C" int mt4_bgemm_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t nb0, int32_t nb1,
                              const int64_t a_strides[4], const int64_t b_strides[4], const int64_t c_strides[4], float alpha, int32_t accumulate,
@@ -358,6 +397,14 @@ extern "C" int mt4_gelu_bwd_f32(const float* dy, const float* x, float* dx, int6
     if (!dy || !x || !dx || n <= 0 || (n & 3)) return MT4_EINVAL;
     if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 15) return MT4_EALIGN;
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, (long long)n);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_gelu_f32(const float* x, float* y, int64_t n, void* stream) {
+    mt4_clear_error();
+    if (!x || !y || n <= 0 || (n & 3)) return MT4_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return MT4_EALIGN;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n);
     return mt4_check_launch();
 }
 

@@ -338,27 +338,37 @@ extern "C" int mt4_avgpool_bwd_f32(const float* dfeat, float* dx, int32_t B, int
 // ------------------------------------------------------------------------------------------------ losses
 // BCEWithLogitsLoss(pos_weight) (run.py:322-324): l = (1-z) y + (1 + (pw-1) z) (log1p(exp(-|y|)) + max(-y, 0));
 // dy = ((1-z) - lw + lw sigmoid(y)) * col_scale.  pos_weight NULL = 1.
-__global__ void bce_pw_kernel(const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ pw,
-                              const float* __restrict__ col_scale, float* __restrict__ dy, float* __restrict__ col_loss, int M, int N, int ld_y,
-                              int ld_dy) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const float p = pw ? pw[n] : 1.f, sc = col_scale[n];
+// 256 threads = 64 columns x 4 row groups over a slab of 64 rows; the column sums of a slab meet in LDS and leave as ONE atomic per
+// column (a step of the MS-TCT teacher has M = 31 x 256 rows: a thread per column looping over all rows took 4 ms there).
+__global__ __launch_bounds__(256) void bce_pw_kernel(const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ pw,
+                                                     const float* __restrict__ col_scale, float* __restrict__ dy, float* __restrict__ col_loss, int M,
+                                                     int N, int ld_y, int ld_dy) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    const int m0 = blockIdx.y * 64, m1 = min(M, m0 + 64);
     float ls = 0.f;
-    for (int m = 0; m < M; ++m) {
-        const float yv = y[(long long)m * ld_y + n], zv = z[(long long)m * N + n];
-        const float lw = 1.f + (p - 1.f) * zv;
-        ls += (1.f - zv) * yv + lw * (log1pf(expf(-fabsf(yv))) + fmaxf(-yv, 0.f));
-        dy[(long long)m * ld_dy + n] = ((1.f - zv) - lw + lw / (1.f + expf(-yv))) * sc;
+    if (n < N) {
+        const float p = pw ? pw[n] : 1.f, sc = col_scale[n];
+        for (int m = m0 + rg; m < m1; m += 4) {
+            const float yv = y[(long long)m * ld_y + n], zv = z[(long long)m * N + n];
+            const float lw = 1.f + (p - 1.f) * zv;
+            ls += (1.f - zv) * yv + lw * (log1pf(expf(-fabsf(yv))) + fmaxf(-yv, 0.f));
+            dy[(long long)m * ld_dy + n] = ((1.f - zv) - lw + lw / (1.f + expf(-yv))) * sc;
+        }
     }
-    atomicAdd(col_loss + n, ls);
+    part[rg][c] = ls;
+    __syncthreads();
+    if (rg == 0 && n < N) atomicAdd(col_loss + n, (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]));
 }
 
 extern "C" int mt4_bce_logits_pw_f32(const float* y, const float* z, const float* pos_weight, const float* col_scale, float* dy, float* col_loss,
                                      int32_t M, int32_t N, int32_t ld_y, int32_t ld_dy, void* stream) {
     mt4_clear_error();
     if (!y || !z || !col_scale || !dy || !col_loss || M <= 0 || N <= 0 || ld_y < N || ld_dy < N) return MT4_EINVAL;
-    hipLaunchKernelGGL(bce_pw_kernel, dim3(cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, y, z, pos_weight, col_scale, dy, col_loss, M, N, ld_y, ld_dy);
+    if (cdiv(M, 64) > 65535) return MT4_EUNSUPPORTED;
+    hipLaunchKernelGGL(bce_pw_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, y, z, pos_weight, col_scale, dy, col_loss, M, N,
+                       ld_y, ld_dy);
     return mt4_check_launch();
 }
 

@@ -191,6 +191,12 @@ class MstctTrainer:
         return {"input": (torch.rand(b, self.D, t, generator=g) >= 0.5).float() * 2.0,
                 "feat": (torch.rand(b, self.E, t, generator=g) >= 0.5).float() * 2.0}
 
+    def draw_masks_device(self, b: int, t: int, seed: int, step: int) -> dict:
+        """the same two draws made on the device, already in row layout ([B*T,D] / [B*T,E]): what the training driver uses (a host draw of
+        31 x 1536 x 256 values and its upload cost more than the step).  Element i of stream 2*step (+1) of `synth.uniform01(seed, .)`."""
+        return {"input_rows": ops.dropout_mask((b * t, self.D), seed, 2 * step, 0.5, self.dev),
+                "feat_rows": ops.dropout_mask((b * t, self.E), seed, 2 * step + 1, 0.5, self.dev)}
+
     # ------------------------------------------------------------------ building blocks
     def _fwd(self, x2d, c: _Lin, residual=None, act=None, out=None):
         return ops.linear(x2d, c.w, c.b, residual=residual, act=act, out=out)
@@ -263,7 +269,7 @@ class MstctTrainer:
                 n2 = self._ln(x_mid, q_ + ".norm2")
                 h1 = self._fwd(n2, L[l_ + ".linear1"])
                 h2 = ops.dwconv1d_k3(h1.view(b, t, -1), self.vecs[l_ + ".TC.weight"].p, self.vecs[l_ + ".TC.bias"].p, act="none").view(M, -1)
-                h3 = ops.dwconv1d_k3(h1.view(b, t, -1), self.vecs[l_ + ".TC.weight"].p, self.vecs[l_ + ".TC.bias"].p, act="gelu").view(M, -1)
+                h3 = ops.gelu(h2)
                 y_out = self._fwd(h3, L[l_ + ".linear2"], residual=x_mid)
                 st["blocks"].append(dict(x_in=y, n1=n1, q=q, kv=kv, P=P, o=o, x_mid=x_mid, n2=n2, h1=h1, h2=h2, h3=h3))
                 y = y_out
@@ -384,8 +390,9 @@ class MstctTrainer:
         z = labels if (labels.dim() == 2 and labels.is_cuda) else self.prepare_labels(labels)
         assert tuple(z.shape) == (b * t, self.K)
         rows = lambda m: m.permute(0, 2, 1).reshape(b * t, -1).contiguous().to(self.dev)     # [B,C,T] -> rows
-        mi = rows(masks["input"]) if masks and masks.get("input") is not None else None
-        mf = rows(masks["feat"]) if masks and masks.get("feat") is not None else None
+        masks = masks or {}
+        mi = masks["input_rows"] if "input_rows" in masks else rows(masks["input"]) if masks.get("input") is not None else None
+        mf = masks["feat_rows"] if "feat_rows" in masks else rows(masks["feat"]) if masks.get("feat") is not None else None
         if use_graph:
             key = (b, t, mi is not None, mf is not None)
             g = self._graphs.get(key)
@@ -474,7 +481,6 @@ def train_driver(argv=None):
     if short:
         raise ValueError(f"videos shorter than the {F.num_clips}-frame training window: {short[:3]} (the reference's sampler fails on them too)")
     order_rng, win_rng = random.Random(F.seed), random.Random(F.seed * 7919 + 1)
-    gen = torch.Generator().manual_seed(F.seed + rank)
     for epoch in range(F.epochs):
         tr.lr = lr_at_epoch(epoch, F.initial_learning_rates[2], F.power, F.warmups[2], F.decay_rate)
         starts = draw_windows(lengths, win_rng, F.num_clips)                                       # same draw on every rank
@@ -487,7 +493,7 @@ def train_driver(argv=None):
             vids = batches[(s * world + rank) % len(batches)]
             x = torch.stack([xs[v][starts[v]:starts[v] + F.num_clips] for v in vids])             # [B,T,D] frame-major
             z = torch.cat([zs[v][starts[v]:starts[v] + F.num_clips] for v in vids])               # [B*T,K]
-            tot += tr.train_step_btd(x, z, masks=tr.draw_masks(len(vids), F.num_clips, gen))
+            tot += tr.train_step_btd(x, z, masks=tr.draw_masks_device(len(vids), F.num_clips, F.seed + rank, epoch * steps + s))
         if rank == 0:
             _log(logfile, f"Traning | lr: {tr.lr:.6f} | epoch {epoch} | loss {tot / steps:.4f} | {time.time() - t0:.2f} secs")
             os.makedirs(model_dir, exist_ok=True)

@@ -711,6 +711,14 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dgamma
     return dx
 
 
+def gelu(x: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    y = torch.empty_like(x)
+    check(lib.mt4_gelu_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "mt4_gelu_f32")
+    return y
+
+
 def gelu_bwd(dy: torch.Tensor, x_pre: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _need_cuda(dy, x_pre, out)
     assert dy.is_contiguous() and x_pre.is_contiguous() and dy.numel() == x_pre.numel() and dy.dtype == torch.float32
@@ -736,3 +744,11 @@ def axpby_(x: torch.Tensor, y: torch.Tensor, a: float = 1.0, b: float = 1.0) -> 
     assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel() and x.dtype == y.dtype == torch.float32
     check(lib.mt4_axpby_f32(x.data_ptr(), y.data_ptr(), x.numel(), a, b, _stream()), "mt4_axpby_f32")
     return y
+
+
+def dropout_mask(shape, seed: int, stream_id: int, p: float = 0.5, device="cuda") -> torch.Tensor:
+    """keep mask of nn.Dropout(p) drawn on the device from the counter generator of `synth.uniform01(seed, stream_id, n)`: 1/(1-p) where
+    u >= p, else 0 (`mt4_dropout_mask_f32`)"""
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(lib.mt4_dropout_mask_f32(out.data_ptr(), out.numel(), seed, stream_id, p, _stream()), "mt4_dropout_mask_f32")
+    return out

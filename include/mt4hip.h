@@ -315,11 +315,18 @@ int mt4_softmax_bwd_rows_f32(const float* P, float* dP, int64_t rows, int32_t co
  * Statistics are recomputed from x.  C <= 1024. */
 int mt4_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta, int64_t M, int32_t C,
                           float eps, int32_t accumulate_dx, void* stream);
+/* nn.GELU (erf form) forward on a float32 buffer, y = gelu(x); n % 4 == 0 (the fused epilogues of mt4_conv_nhwc / mt4_dwconv1d_k3 apply the
+ * same function; a training step that keeps the pre-activation calls this instead) */
+int mt4_gelu_f32(const float* x, float* y, int64_t n, void* stream);
 /* nn.GELU (erf form) backward: dx = dy * gelu'(x) with x the pre-activation; n % 4 == 0 */
 int mt4_gelu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, void* stream);
 /* backward of mt4_dwconv1d_k3 (depthwise Conv1d k3 pad 1, Temporal_Encoder.py:12,38): dx written, dw [C][3] / db [C] ADDED to */
 int mt4_dwconv1d_k3_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int32_t B, int32_t T, int32_t C,
                             void* stream);
+/* nn.Dropout(p) keep mask (network.py:58,76,108,113 draw theirs from torch's RNG): out[i] = u_i >= p ? 1/(1-p) : 0 with the counter
+ * generator of computervision_codes_amd/synth.py (u_i = splitmix64(splitmix64(seed * 0x100000001B3 + stream_id) + i) >> 11 / 2^53), so a
+ * draw is reproducible on the host */
+int mt4_dropout_mask_f32(float* out, int64_t n, int64_t seed, int64_t stream_id, float p, void* stream);
 /* y = a * x + b * y (b == 0: y is not read); n % 4 == 0 */
 int mt4_axpby_f32(const float* x, float* y, int64_t n, float a, float b, void* stream);
 

@@ -64,6 +64,7 @@ def test_softmax_layernorm_gelu_dwconv_backward_vs_autograd(cuda):
         base = _rand((M, C), 17).to(cuda)
         acc = ops.layernorm_bwd(dy.to(cuda), x.to(cuda), g.to(cuda), dg, db, dx=base.clone(), accumulate_dx=True)
         assert (acc - base - dx).abs().max() < 1e-5
+    assert (ops.gelu(_rand((16, 20), 30, 4.0).to(cuda)).cpu() - F.gelu(_rand((16, 20), 30, 4.0))).abs().max() < 2e-6
     # GELU backward
     x, dy = _rand((64, 50), 18, 4.0), _rand((64, 50), 19)
     xt = x.clone().requires_grad_()
@@ -79,6 +80,10 @@ def test_softmax_layernorm_gelu_dwconv_backward_vs_autograd(cuda):
     dx = ops.dwconv1d_k3_bwd(dy.to(cuda), x.to(cuda), w.to(cuda), dw, db)
     assert (dx.cpu() - xt.grad).abs().max() < 1e-5
     assert (dw.cpu() - wt.grad).abs().max() < 2e-5 * wt.grad.abs().max() and (db.cpu() - bt.grad).abs().max() < 2e-5 * bt.grad.abs().max()
+    # device dropout draw == the host counter generator
+    mk = ops.dropout_mask((7, 33), 123, 5, 0.5, cuda)
+    want = torch.from_numpy(((synth.uniform01(123, 5, 7 * 33) >= 0.5) * 2.0).astype(np.float32).reshape(7, 33))
+    assert torch.equal(mk.cpu(), want)
     # axpby
     a, b_ = _rand((1000,), 24).to(cuda), _rand((1000,), 25).to(cuda)
     r = 0.5 * a - 2.0 * b_
