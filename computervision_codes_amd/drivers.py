@@ -168,8 +168,9 @@ def spatial_cnn_train(argv=None) -> Dict[str, float]:
     p.add_argument("--val_interval", type=int, default=1)
     p.add_argument("--pretrain_dir", type=str, default="")
     F, _ = p.parse_known_args(argv)
-    if F.loss_type != "all":
-        raise NotImplementedError("the student recipe trains with --loss_type all (Scripts/train_fold1.sh:24)")
+    if F.loss_type not in ("all", "i", "v", "t"):
+        raise ValueError("--loss_type all | i | v | t (`Spatial_cnn/run.py:165-192`)")
+    single = F.loss_type != "all"
     rank, world = _dist()
     kfold = F.kfold if "crossval" in F.dataset_variant else 0
     modelname = f"{F.model}_l{F.dataset_variant}_cholect{kfold}"
@@ -178,8 +179,8 @@ def spatial_cnn_train(argv=None) -> Dict[str, float]:
     ckpt, latest = os.path.join(model_dir, modelname + ".pth"), os.path.join(model_dir, modelname + "_latest.pth")
     val_interval = F.epochs - 1 if F.val_interval == -1 else F.val_interval
     tr = SpatialCnnTrainer(F.network, lr=F.initial_learning_rates[2], weight_decay=F.weight_decay, rates=F.rates, temp=float(F.temp),
-                           teacher_dim=F.teacher_dim)
-    table = shapes.spatial_cnn_shapes(F.network, F.student_dim, F.teacher_dim)
+                           teacher_dim=F.teacher_dim, loss_type=F.loss_type)
+    table = shapes.spatial_cnn_shapes(F.network, F.student_dim, F.teacher_dim, F.loss_type)
     sd = synth.fill_from_shapes(table, seed=F.seed)          # no torch.nn init here: deterministic synthetic start
     for src in (F.pretrain_dir, latest):                     # `load_model` (:272-278): keys present in the model, strict=False
         if src and os.path.exists(src):
@@ -188,8 +189,9 @@ def spatial_cnn_train(argv=None) -> Dict[str, float]:
     train_videos, val_videos, _ = cholect.split_videos(F.dataset_variant, kfold)
     labels = {v: cholect.load_labels(F.data_dir, v) for v in train_videos + val_videos}
     tdir = lambda ver, task, kind: featfile.feats_path("..", ver, kfold, task, kind)
-    tpred = {t: featfile.read_feats(tdir(F.teacher_pred_version, t, "pred")) for t in "ivt"}
-    tfeat = {t: featfile.read_feats(tdir(F.teacher_feat_version, t, "feats")) for t in "ivt"}
+    # the teacher files feed the distillation losses only (`dataloader.py:216-238` loads them regardless; a single-task run never uses them)
+    tpred = {} if single else {t: featfile.read_feats(tdir(F.teacher_pred_version, t, "pred")) for t in "ivt"}
+    tfeat = {} if single else {t: featfile.read_feats(tdir(F.teacher_feat_version, t, "feats")) for t in "ivt"}
     samples = [(v, i) for v in train_videos for i in range(len(labels[v]["ivt"]))]
     order_rng, aug_rng = random.Random(F.seed), random.Random(F.seed * 1000003 + rank)
     eval_args = argparse.Namespace(**vars(F))
@@ -209,8 +211,8 @@ def spatial_cnn_train(argv=None) -> Dict[str, float]:
                                                           F.augmentation_list) for v, i in batch])
             lab = [torch.from_numpy(np.stack([labels[v][k][i, 1:] for v, i in batch])) for k in ("i", "v", "t", "ivt")]
             key = lambda v: featfile.video_key(v)
-            tp = [torch.from_numpy(np.stack([tpred[t][key(v)][i] for v, i in batch]).astype(np.float32)) for t in "ivt"]
-            tf = [torch.from_numpy(np.stack([tfeat[t][key(v)][i] for v, i in batch]).astype(np.float32)) for t in "ivt"]
+            tp = [] if single else [torch.from_numpy(np.stack([tpred[t][key(v)][i] for v, i in batch]).astype(np.float32)) for t in "ivt"]
+            tf = [] if single else [torch.from_numpy(np.stack([tfeat[t][key(v)][i] for v, i in batch]).astype(np.float32)) for t in "ivt"]
             terms = tr.train_step(torch.from_numpy(frames).cuda(), lab, tp, tf)
             tot += terms["loss"]
         last = {"loss": tot / steps, "lr": tr.lr}
@@ -221,12 +223,13 @@ def spatial_cnn_train(argv=None) -> Dict[str, float]:
             torch.save(state, latest)
             model = VideoNas(args=eval_args, dtype=torch.float32).eval()
             model.load_state_dict(state)
-            m = Recognition(100)
+            vt = F.loss_type if single else "ivt"               # the head the validation mAP is taken on (`run.py:416-451`)
+            m = Recognition({"i": 6, "v": 10, "t": 15, "ivt": 100}[vt])
             for v in val_videos:
-                lv = labels[v]["ivt"]
+                lv = labels[v][vt]
                 for s0 in range(0, len(lv), F.batch):
                     fr = cholect.load_frames_device(F.data_dir, v, lv[s0:s0 + F.batch, 0], F.image_height, F.image_width)
-                    m.update(lv[s0:s0 + F.batch, 1:], _sigmoid(model.extract_u8(fr)[3][1]))
+                    m.update(lv[s0:s0 + F.batch, 1:], _sigmoid(model.extract_u8(fr)["ivt".index(vt) if single else 3][1]))
                 m.video_end()
             score = float(m.compute_video_AP()["mAP"]) if val_videos else 0.0
             last["val_mAP_ivt"] = score

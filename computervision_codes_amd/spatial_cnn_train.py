@@ -21,14 +21,14 @@ from .shapes import resnet_feat_dim, spatial_cnn_shapes
 from .tenco_train import allreduce_sum_flat
 
 _DEPTHS = {"resnet18": (2, 2, 2, 2), "resnet50": (3, 4, 6, 3)}
-_HEADS = (("i", 6), ("v", 10), ("t", 15), ("ivt", 100))
-NH, NHP = 131, 132
+_ALL_HEADS = (("i", 6), ("v", 10), ("t", 15), ("ivt", 100))
 # `Spatial_cnn/run.py:306-311`
 TOOL_W = [0.93487068, 0.94234964, 0.93487068, 1.18448115, 1.02368339, 0.97974447]
 VERB_W = [0.60002400, 0.60002400, 0.60002400, 0.61682467, 0.67082683, 0.80163207, 0.70562823, 2.11208448, 2.69230769, 0.60062402]
 TARGET_W = [0.49752894, 0.52041527, 0.49752894, 0.51394739, 2.71899565, 1.75577963, 0.58509403, 1.25228034, 0.49752894, 2.42993134,
             0.49802647, 0.87266576, 1.36074165, 0.50150917, 0.49802647]
 F32 = torch.float32
+_POS_W = {"i": TOOL_W, "v": VERB_W, "t": TARGET_W, "ivt": [1.0] * 100}
 
 
 class _Unit:
@@ -39,7 +39,16 @@ class _Unit:
 
 class SpatialCnnTrainer:
     def __init__(self, network: str = "resnet50", lr: float = 0.01, weight_decay: float = 1e-5, rates: Sequence[float] = (1.0, 1.0, 1.0),
-                 temp: float = 4.0, device: str = "cuda", process_group=None, overlap: bool = True, teacher_dim: int = 1536):
+                 temp: float = 4.0, device: str = "cuda", process_group=None, overlap: bool = True, teacher_dim: int = 1536,
+                 loss_type: str = "all"):
+        """loss_type 'all': the distillation recipe (four heads, KD branch, hard + soft + feature losses: `run.py:180-192`);
+        'i' | 'v' | 't': a single-task student -- only that classifier exists (`network.py:34-41`) and the loss is its BCE alone
+        (`run.py:165-179`)"""
+        assert loss_type in ("all", "i", "v", "t")
+        self.loss_type = loss_type
+        self.heads = _ALL_HEADS if loss_type == "all" else tuple(h for h in _ALL_HEADS if h[0] == loss_type)
+        self.NH = sum(k for _, k in self.heads)
+        self.NHP = (self.NH + 3) // 4 * 4
         self.network, self.lr, self.wd, self.rates, self.temp = network, lr, weight_decay, tuple(rates), float(temp)
         self.overlap = overlap            # DDP: all-reduce each gradient bucket as soon as the backward has written it (eager steps)
         self._pending: list = []
@@ -47,7 +56,7 @@ class SpatialCnnTrainer:
         self.dev, self.pg = torch.device(device), process_group
         self.C = resnet_feat_dim(network)
         self.TD = int(teacher_dim)          # `--teacher_dim` (`Spatial_cnn/run.py:82`): width of the teachers' frame features
-        self._table = spatial_cnn_shapes(network, self.C, self.TD)
+        self._table = spatial_cnn_shapes(network, self.C, self.TD, loss_type)
         self.units: Dict[str, _Unit] = {}
         self.nbt: Dict[str, int] = {}
         self._extra: Dict[str, torch.Tensor] = {}
@@ -78,7 +87,10 @@ class SpatialCnnTrainer:
         dev, C = self.dev, self.C
         specs = self._unit_specs()
         TD = self.TD
-        lin = [("heads", NHP, C), ("wi", TD, C), ("wv", TD, C), ("wt", TD, C), ("mi", C, TD), ("mv", C, TD), ("mt", C, TD)]
+        NH, NHP, _HEADS = self.NH, self.NHP, self.heads
+        lin = [("heads", NHP, C)]
+        if self.loss_type == "all":
+            lin += [("wi", TD, C), ("wv", TD, C), ("wt", TD, C), ("mi", C, TD), ("mv", C, TD), ("mt", C, TD)]
         r4 = lambda n: (n + 3) // 4 * 4
         total = sum(co * ops.packed_k(ci, k, k, F32) + 2 * r4(co) for _, _, ci, co, k, _, _ in specs)
         total += sum(co * ops.packed_k(ci, 1, 1, F32) + r4(co) for _, co, ci in lin)
@@ -141,7 +153,7 @@ class SpatialCnnTrainer:
         self._col_scales: Dict[int, torch.Tensor] = {}
         self._graphs: Dict[tuple, object] = {}
         self._extra = {k: sd[k].detach().clone() for k, _ in self._table if k not in trained}   # the trunk's unused 1000-way fc
-        self.pos_weight = torch.tensor(TOOL_W + VERB_W + TARGET_W + [1.0] * 100, dtype=F32, device=dev)
+        self.pos_weight = torch.tensor(sum((_POS_W[t] for t, _ in self.heads), []), dtype=F32, device=dev)
         self._refresh_transposed()
         return self
 
@@ -186,7 +198,7 @@ class SpatialCnnTrainer:
             ww, bb = w[:, :ci].clone().cpu(), b.clone().cpu()
             if name == "heads":
                 o = 0
-                for t, k in _HEADS:
+                for t, k in self.heads:
                     out[f"classifier_{t}.fc.weight"], out[f"classifier_{t}.fc.bias"] = ww[o:o + k].clone(), bb[o:o + k].clone()
                     o += k
             else:
@@ -204,7 +216,7 @@ class SpatialCnnTrainer:
             gg, gbb = gw[:, :ci].clone().cpu(), gb.clone().cpu()
             if name == "heads":
                 o = 0
-                for t, k in _HEADS:
+                for t, k in self.heads:
                     out[f"classifier_{t}.fc.weight"], out[f"classifier_{t}.fc.bias"] = gg[o:o + k].clone(), gbb[o:o + k].clone()
                     o += k
             else:
@@ -278,11 +290,13 @@ class SpatialCnnTrainer:
         Returns the dict of loss terms.  use_graph: replay a hipGraph of the whole forward+backward captured for this input shape
         (~900 launches become one; running statistics and gradients are updated by the replay exactly as by the eager step)."""
         dev = self.dev
+        if not torch.is_tensor(labels) and self.loss_type != "all":       # (y_i, y_v, y_t, y_ivt) as the loader yields them: keep the task's
+            labels = [labels["ivt".index(self.loss_type)]] if len(labels) == 4 else labels
         z = labels if torch.is_tensor(labels) else torch.cat([l.to(dev, F32) for l in labels], 1).contiguous()
         tp = [t.to(dev, F32).contiguous() for t in teacher_pred]
         tf = [t.to(dev, F32).contiguous() for t in teacher_feat]
         B = frames.shape[0]
-        assert frames.is_cuda and tuple(z.shape) == (B, NH)
+        assert frames.is_cuda and tuple(z.shape) == (B, self.NH)
         if use_graph:
             key = (tuple(frames.shape), frames.dtype)
             g = self._graphs.get(key)
@@ -306,12 +320,12 @@ class SpatialCnnTrainer:
         cl, sk = col_loss.cpu(), torch.cat([soft, kdl]).cpu()
         terms, o = {}, 0
         hard = 0.0
-        for t, k in _HEADS:
+        for t, k in self.heads:
             terms["hard_" + t] = float(cl[o:o + k].sum() / (B * k))
             hard += terms["hard_" + t]
             o += k
         terms.update(hard=hard, soft=float(sk[0]) / 3.0, kd=float(sk[1]) / 3.0)
-        terms["loss"] = r0 * terms["hard"] + r1 * terms["soft"] + r2 * terms["kd"]
+        terms["loss"] = (r0 * terms["hard"] + r1 * terms["soft"] + r2 * terms["kd"]) if self.loss_type == "all" else hard   # `run.py:165-192`
         if apply_update:
             self.apply_update()
         return terms
@@ -352,10 +366,8 @@ class SpatialCnnTrainer:
         Bh, Hh, Wh, _ = x.shape
         feat = ops.global_avgpool(x)                                               # [B, C]
         # ---- heads, KD branch
-        logits = self._linear_fwd("heads", feat)                                   # [B, 132]
-        teas = [self._linear_fwd(m, t) for m, t in zip(("mi", "mv", "mt"), tf)]
-        mixed = ops.kd_mix(feat, *teas)
-        cams = [self._linear_fwd(wn, mx) for wn, mx in zip(("wi", "wv", "wt"), mixed)]
+        NH, NHP, kd_on = self.NH, self.NHP, self.loss_type == "all"
+        logits = self._linear_fwd("heads", feat)                                   # [B, 132] (single task: its K rounded up to 4)
         # ---- losses and their gradients
         r0, r1, r2 = self.rates
         col_scale = self._col_scale(B)
@@ -363,20 +375,25 @@ class SpatialCnnTrainer:
         dlog = torch.zeros((B, NHP), device=dev)
         ops.bce_logits_pw(logits[:, :NH], z, self.pos_weight, col_scale, dlog, col_loss)
         soft = torch.zeros(1, device=dev)
-        o = 0
-        for (t, k), tpn in zip(_HEADS[:3], tp):
-            ops.distill_kl(logits[:, o:o + k], tpn, dlog[:, o:o + k], soft, self.temp, r1 / 3.0, accumulate=True)
-            o += k
         kdl = torch.zeros(1, device=dev)
-        dcams = [ops.mse(c, t, kdl, r2 / 3.0) for c, t in zip(cams, tf)]
+        if kd_on:
+            teas = [self._linear_fwd(m, t) for m, t in zip(("mi", "mv", "mt"), tf)]
+            mixed = ops.kd_mix(feat, *teas)
+            cams = [self._linear_fwd(wn, mx) for wn, mx in zip(("wi", "wv", "wt"), mixed)]
+            o = 0
+            for (t, k), tpn in zip(self.heads[:3], tp):
+                ops.distill_kl(logits[:, o:o + k], tpn, dlog[:, o:o + k], soft, self.temp, r1 / 3.0, accumulate=True)
+                o += k
+            dcams = [ops.mse(c, t, kdl, r2 / 3.0) for c, t in zip(cams, tf)]
         # ---- backward: heads + KD branch -> dfeat
         dfeat = self._linear_bwd("heads", dlog, feat)
-        gs = [self._linear_bwd(wn, dc, mx) for wn, dc, mx in zip(("wi", "wv", "wt"), dcams, mixed)]
-        ds_kd, dtau = ops.kd_mix_bwd(feat, teas, gs)
-        dfeat = ops.mul_add(dfeat, torch.ones_like(dfeat), ds_kd)
-        for n, (m, t) in enumerate(zip(("mi", "mv", "mt"), tf)):
-            dte = dtau[:, n:n + 1].expand(B, C).contiguous()                        # d(tea_n)[b][:] = dtau[b][n]
-            self._linear_bwd(m, dte, t, need_dx=False)
+        if kd_on:
+            gs = [self._linear_bwd(wn, dc, mx) for wn, dc, mx in zip(("wi", "wv", "wt"), dcams, mixed)]
+            ds_kd, dtau = ops.kd_mix_bwd(feat, teas, gs)
+            dfeat = ops.mul_add(dfeat, torch.ones_like(dfeat), ds_kd)
+            for n, (m, t) in enumerate(zip(("mi", "mv", "mt"), tf)):
+                dte = dtau[:, n:n + 1].expand(B, C).contiguous()                    # d(tea_n)[b][:] = dtau[b][n]
+                self._linear_bwd(m, dte, t, need_dx=False)
         self._reduce_bucket("heads")
         # ---- backward through the trunk
         dx = ops.avgpool_bwd(dfeat, Bh, Hh * Wh, C).view(Bh, Hh, Wh, C)
@@ -414,7 +431,8 @@ class SpatialCnnTrainer:
 
     def _col_scale(self, B: int) -> torch.Tensor:
         if B not in self._col_scales:
-            self._col_scales[B] = torch.cat([torch.full((k,), self.rates[0] / (B * k)) for _, k in _HEADS]).to(self.dev)
+            r0 = self.rates[0] if self.loss_type == "all" else 1.0       # a single-task loss carries no rate (`run.py:165-179`)
+            self._col_scales[B] = torch.cat([torch.full((k,), r0 / (B * k)) for _, k in self.heads]).to(self.dev)
         return self._col_scales[B]
 
     def relu_outputs(self) -> Dict[str, torch.Tensor]:

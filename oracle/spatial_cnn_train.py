@@ -102,14 +102,26 @@ def distill_kl(y_s, y_t, temp):
 
 
 def train_step(sd: SD, img, labels, teacher_pred, teacher_feat, network="resnet50", lr=0.1, weight_decay=1e-5, rates=(1.0, 1.0, 1.0), temp=4.0,
-               acts: Optional[dict] = None):
+               acts: Optional[dict] = None, loss_type: str = "all"):
     """labels (y_i,y_v,y_t,y_ivt) multi-hot; teacher_pred 3 x raw logits [B,K]; teacher_feat 3 x [B,1536].
+    loss_type 'i' | 'v' | 't': the single-task student (`run.py:165-179`: loss = that head's BCE; sd holds only that classifier).
     Returns (new_sd incl. running stats, loss terms dict, grads dict)."""
     names = list(sd)
     is_param = lambda k: not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items() if is_param(k)}
     buf = {k: v.clone() for k, v in sd.items() if not is_param(k)}
     s = trunk_train(p, buf, img, network, "basemodel.basemodel.", acts)
+    if loss_type != "all":
+        t = loss_type
+        y = labels["ivt".index(t)].to(s.dtype)
+        pw = {"i": TOOL_W, "v": VERB_W, "t": TARGET_W}[t]
+        loss = F.binary_cross_entropy_with_logits(F.linear(s, p[f"classifier_{t}.fc.weight"], p[f"classifier_{t}.fc.bias"]), y,
+                                                  pos_weight=torch.tensor(pw, dtype=s.dtype))
+        pk = list(p)
+        g = dict(zip(pk, torch.autograd.grad(loss, [p[k] for k in pk], allow_unused=True)))
+        new = {k: ((p[k].detach() - lr * (g[k] + weight_decay * p[k].detach()) if g[k] is not None else p[k].detach().clone()) if k in p
+                   else (buf[k] + 1 if k.endswith("num_batches_tracked") else buf[k])) for k in names}
+        return new, {"loss": float(loss.detach()), "hard": float(loss.detach()), "hard_" + t: float(loss.detach())}, g
     kd = o_cnn.kd_branch(p, s, *teacher_feat)
     logit = {t: F.linear(s, p[f"classifier_{t}.fc.weight"], p[f"classifier_{t}.fc.bias"]) for t in ("i", "v", "t", "ivt")}
     y_i, y_v, y_t, y_ivt = [y.float() for y in labels]

@@ -299,3 +299,31 @@ def test_graph_replay_equals_eager_step(cuda):
             assert int(s0[k]) == int(s1[k]) == int(sd[k]) + 2
         else:
             assert (s0[k].float() - s1[k].float()).abs().max().item() <= 1e-4 * max(1.0, s0[k].float().abs().max().item()), k
+
+
+@pytest.mark.parametrize("task", ["i", "t"])
+def test_single_task_train_step_vs_oracle(cuda, task):
+    """`--loss_type i|v|t` (`Spatial_cnn/run.py:165-179`): only that classifier exists (`network.py:34-41`), the loss is its BCE(pos_weight)
+    alone -- every gradient and every updated tensor against the CPU oracle (ResNet-18: well conditioned, tight tolerance)"""
+    from computervision_codes_amd.spatial_cnn_train import SpatialCnnTrainer
+    from oracle import spatial_cnn_train as o_ct
+    cfg = dict(network="resnet18", B=3, H=64, W=96, seed=95, lr=0.05, rates=(1.0, 1.0, 1.0))
+    table = shapes.spatial_cnn_shapes("resnet18", None, 1536, task)
+    assert not any(k.startswith(("wi.", "mi.", "classifier_ivt")) for k, _ in table)
+    sd = o_ct.tie_free_bn(synth.fill_from_shapes(table, seed=cfg["seed"]), "resnet18")     # no ReLU input near zero: no gate can flip
+    tr = SpatialCnnTrainer("resnet18", lr=cfg["lr"], weight_decay=1e-5, loss_type=task).load_state_dict(sd)
+    img, labels, _, _ = _inputs(cfg)
+    acts = {}
+    new_o, terms_o, g_o = o_ct.train_step(sd, img, labels, [], [], "resnet18", cfg["lr"], 1e-5, acts=acts, loss_type=task)
+    terms = tr.train_step(img.to(cuda), labels, [], [])
+    assert abs(terms["loss"] - terms_o["loss"]) < 1e-4 * max(1.0, abs(terms_o["loss"]))
+    assert _gate_flips(tr, acts) == 0
+    gtol, ptol = 1e-3, 2e-5
+    gmax = max(float(v.abs().max()) for v in g_o.values() if v is not None)
+    for k, g in tr.grads().items():
+        ref = g_o[k]
+        assert (g - ref).abs().max().item() <= gtol * max(ref.abs().max().item(), 1e-4 * gmax), (k, (g - ref).abs().max().item())
+    new = tr.state_dict()
+    assert list(new) == [k for k, _ in table]
+    for k, _ in table:
+        assert (new[k].float() - new_o[k].float()).abs().max().item() <= ptol * max(1.0, new_o[k].abs().max().item()), k

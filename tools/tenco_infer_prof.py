@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Per-video inference of the Temporal_tenco head under rocprofv3 (GPU box): N hipGraph replays of one forward.
+  rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 tools/tenco_infer_prof.py [--T 256] [--dtype f32|bf16] [--config tenco4|config1]
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dir> -- python3 tools/tenco_infer_prof.py --replays 3      (and WRITE_SIZE)"""
+import argparse, json, os, sys, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from computervision_codes_amd import shapes, synth
+from computervision_codes_amd.graph import GraphedForward
+from computervision_codes_amd.temporal_tenco import VideoNas
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--T", type=int, default=256)
+ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+ap.add_argument("--config", default="tenco4", choices=["tenco4", "config1"])
+ap.add_argument("--replays", type=int, default=50)
+a = ap.parse_args()
+num_R, dim = (3, 512) if a.config == "tenco4" else (0, 2048)
+fpn = num_R > 0
+args = types.SimpleNamespace(fpn=fpn, output=False, hier=False, mask=True)
+sd = synth.fill_from_shapes(shapes.tenco_shapes(11, 10, num_R, 512, dim, 100, fpn=fpn), seed=47)
+m = VideoNas(args, 11, 10, num_R, 512, dim, 100, dtype=torch.float32 if a.dtype == "f32" else torch.bfloat16).eval().load_state_dict(sd)
+x = synth.synthetic_features(a.T, dim, seed=47).cuda()
+g = GraphedForward(lambda xx: m(xx, False), [x])
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.replays):
+    g(x)
+e1.record()
+torch.cuda.synchronize()
+print(json.dumps({"config": a.config, "T": a.T, "dtype": a.dtype, "replays": a.replays, "ms_per_video": round(e0.elapsed_time(e1) / a.replays, 4)}))
