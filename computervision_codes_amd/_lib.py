@@ -33,7 +33,8 @@ class ConvDesc(C.Structure):
         ("dil_h", C.c_int32), ("dil_w", C.c_int32),
         ("relu", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile", C.c_int32),
         ("out_row_map_len", C.c_int32), ("y_ld", C.c_int32), ("res_ld", C.c_int32), ("out_rows_per_image", C.c_int32),
-        ("x_pixel_stride", C.c_int32),
+        ("x_pixel_stride", C.c_int32), ("fuse_cout", C.c_int32),
+        ("fuse_w", C.c_void_p), ("fuse_bias", C.c_void_p), ("fuse_y", C.c_void_p), ("fuse_relu", C.c_int32), ("fuse_reserved", C.c_int32),
     ]
 
 

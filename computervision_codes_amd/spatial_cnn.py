@@ -39,6 +39,12 @@ class VideoNas:
         self._sd: Dict[str, torch.Tensor] = {}
         self._p: Dict[str, object] = {}
         self._streams = []
+        # conv3 + the next block's conv1 in one launch (`mt4_conv_desc.fuse_w`): bit-identical, but MEASURED SLOWER -- 19.2 -> 22.0 ms per 1336
+        # frames at 224x224, same-box A/B (tools/fuse_ab.py): the fused epilogue needs the whole 256-channel vector of a pixel in one tile,
+        # i.e. the 16-wave 256 x 256 tile at one workgroup per CU, and on these K = 64 HBM-bound layers its serial phases (operands -> MFMA ->
+        # 4 x [residual, staging, store, second GEMM]) leave nothing to overlap with; the saved re-read (1.6 MB per frame and pair) does
+        # not pay for that.  Off by default; kept for the A/B and as the starting point of a smaller-tile variant.
+        self.fuse_next_conv = False
 
     def eval(self):
         self.training = False
@@ -124,6 +130,7 @@ class VideoNas:
         """residual layers first..last (1-based, inclusive); the last conv writes into `out` when given"""
         pre = "basemodel.basemodel."
         bottleneck = self.network == "resnet50"
+        pending = None          # conv1 output of the block about to run, when the previous block's conv3 launch produced it
         for li in range(first, last + 1):
             n = _DEPTHS[self.network][li - 1]
             for bi in range(n):
@@ -132,9 +139,20 @@ class VideoNas:
                 o_buf = out if (li == last and bi == n - 1) else None
                 idt = self._conv(x, q + "ds", 1, stride=s, relu=False) if (q + "ds") in self._p else x
                 if bottleneck:  # resnet.py:101-121 (stride on the 3x3)
-                    o = self._conv(x, q + "conv1", 1)
+                    o = pending if pending is not None else self._conv(x, q + "conv1", 1)
+                    pending = None
                     o = self._conv(o, q + "conv2", 3, stride=s, pad=1)
-                    x = self._conv(o, q + "conv3", 1, residual=idt, out=o_buf)
+                    # the next Bottleneck's conv1 (a 1x1 conv on this block's output at the same resolution) rides in this conv3's epilogue
+                    # while the 256-channel tile is still in LDS: the map is written once (next residual) and not read back (bf16 only;
+                    # 256 output channels = layer1: its three blocks hand over to blocks 1, 2 and to layer2.0)
+                    nq = f"{pre}layer{li}.{bi + 1}." if bi + 1 < n else (f"{pre}layer{li + 1}.0." if li < last else None)
+                    w3, b3 = self._p[q + "conv3"]
+                    if (self.fuse_next_conv and nq is not None and o_buf is None and self.dtype == torch.bfloat16 and w3.shape[0] == 256
+                            and o.shape[0] * o.shape[1] * o.shape[2] >= 256):
+                        w1n, b1n = self._p[nq + "conv1"]
+                        x, pending = ops.conv_nhwc(o, w3, b3, kh=1, kw=1, residual=idt, relu=True, fuse_next=(w1n, b1n, True))
+                    else:
+                        x = self._conv(o, q + "conv3", 1, residual=idt, out=o_buf)
                 else:           # resnet.py:35-72
                     o = self._conv(x, q + "conv1", 3, stride=s, pad=1)
                     x = self._conv(o, q + "conv2", 3, pad=1, residual=idt, out=o_buf)
