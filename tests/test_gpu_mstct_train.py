@@ -162,3 +162,23 @@ def test_mstct_train_step_with_dropout_draw_vs_oracle(cuda):
     n1 = tr.state_dict()
     for k, _ in table:
         assert (n1[k] - n2[k]).abs().max().item() <= 1e-6 * max(1.0, n1[k].abs().max().item()), k
+
+
+@pytest.mark.parametrize("b,t,cout,cin,taps,dil", [(9, 256, 192, 128, 3, 1), (5, 500, 200, 100, 3, 4), (1, 2304, 256, 512, 1, 1), (31, 256, 128, 864, 1, 1)])
+def test_wgrad_conv1d_long_rows_vs_autograd(cuda, b, t, cout, cin, taps, dil):
+    """`mt4_wgrad_conv1d_f32` on row ranges of >= 2048 (the 128 x 128 LDS-DMA tile kernel): ragged tile edges, tap shifts across sequence
+    boundaries, the split of the row range over workgroups (atomic partial sums) -- against torch autograd"""
+    from computervision_codes_amd import ops
+    x, dy = _rand((b, t, cin), 51), _rand((b, t, cout), 52)
+    w = torch.zeros(cout, cin, taps, requires_grad=True)
+    pad = dil * (taps - 1) // 2
+    y = F.conv1d(x.permute(0, 2, 1), w, None, padding=pad, dilation=dil).permute(0, 2, 1)
+    y.backward(dy)
+    kp = ops.packed_k(cin, 1, taps, torch.float32)
+    dw = torch.full((cout, kp), 7.0, device=cuda)                      # must be overwritten, padding columns included
+    ops.wgrad_conv1d(dy.to(cuda), x.to(cuda), dw, batch=b, t=t, taps=taps, dil=dil, pad=pad)
+    got = dw[:, :taps * cin].reshape(cout, taps, cin).permute(0, 2, 1).cpu()
+    assert (got - w.grad).abs().max().item() < 2e-5 * max(1.0, w.grad.abs().max().item())
+    assert float(dw[:, taps * cin:].abs().max()) == 0.0 if kp > taps * cin else True
+    ops.wgrad_conv1d(dy.to(cuda), x.to(cuda), dw, batch=b, t=t, taps=taps, dil=dil, pad=pad, accumulate=True)
+    assert (dw[:, :taps * cin].reshape(cout, taps, cin).permute(0, 2, 1).cpu() - 2 * w.grad).abs().max().item() < 4e-5 * max(1.0, w.grad.abs().max().item())
