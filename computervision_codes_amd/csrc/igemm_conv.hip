@@ -996,161 +996,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
     }
 }
 
-// Persistent form of the stem patch kernel: a workgroup keeps the weight matrix in LDS and walks tiles blockIdx, blockIdx + grid, ...;
-// the next tile's patch is copied into the other patch buffer while the current tile is computed and written out (the non-persistent
-// form spends most of a workgroup's life waiting for its 52 KB prologue).  The epilogue stages through the current patch buffer.
-template <int BM, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void stem_patch_persistent_kernel(const ConvK a, const int pbuf) {
-    constexpr int BN = 64;
-    constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int NTH = NW * 64;
-    constexpr int PPP = NTH * 16 / 32;
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-    constexpr int MT = WM / 16, NT = WN / 16;
-    static_assert(NW == 8 && WM == 64 && WN % 16 == 0, "tile shape");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [weights KH x 8 KB][patch 0: pbuf][patch 1: pbuf]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-    const int r16 = lane & 15, q = lane >> 4;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const v4u rsx = make_srd(a.x, a.x_bytes);
-    const v4u rsw = make_srd(a.w, a.w_bytes);
-    constexpr unsigned OOB = 0x80000000u;
-    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const int wbytes = a.KH * (BN * 128);
-    const int npp = (pbuf / 32 + PPP - 1) / PPP;
-
-    auto tile_origin = [&](int t, int& m0, int& m_end) {   // first output pixel of tile t, first pixel of the next image; returns p0
-        const int img = t / a.n_tiles;
-        const int l0 = (t - img * a.n_tiles) * BM;
-        m0 = img * a.HoWo + l0;
-        m_end = (img + 1) * a.HoWo;
-        const int ho = l0 / a.Wo;
-        return (img * a.H + ho) * a.W + (l0 - ho * a.Wo);
-    };
-    auto issue_patch = [&](int p0, int buf) {
-        for (int piece = 0; piece < npp; ++piece) {
-            if ((piece * PPP + wave_u * 32) * 32 < pbuf) {
-                const int t = piece * PPP + (tid >> 1);
-                const int h = (tid & 1) ^ ((t >> 3) & 1);
-                const unsigned v[1] = {(unsigned)((p0 + t) * 32 + h * 16)};
-                lds_dma16_group<1, 0>(rsx, v, 0u, lds_base + wbytes + buf * pbuf + piece * (PPP * 32) + wave_u * 1024);
-            }
-        }
-    };
-
-    int t = blockIdx.x;
-    int m0, m_end;
-    int p0 = __builtin_amdgcn_readfirstlane(tile_origin(t, m0, m_end));
-    {
-        const int ld_row = tid >> 3, ld_chunk = tid & 7;
-        const int gch = ld_chunk ^ (ld_row & 7);
-        const unsigned woff[1] = {ld_row < a.Cout ? (unsigned)(ld_row * a.w_row_bytes + gch * 16) : OOB};
-        for (int kh = 0; kh < a.KH; ++kh)
-            lds_dma16_group<1, 0>(rsw, woff, (unsigned)__builtin_amdgcn_readfirstlane(kh * 128), lds_base + kh * (BN * 128) + wave_u * 1024);
-    }
-    issue_patch(p0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    f32x4 bias4[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int n = wave_n * WN + i * 16 + q * 4;
-        bias4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (a.bias && n < a.Cout) { const float4 b = *(const float4*)(a.bias + n); bias4[i] = (f32x4){b.x, b.y, b.z, b.w}; }
-    }
-    const int rd_w = (wave_n * WN + r16) * 128;
-    int buf = 0;
-#pragma unroll 1
-    for (; t < a.total_tiles; t += gridDim.x) {
-        const int tn = t + gridDim.x;
-        int m0n = 0, m_endn = 0, p0n = 0;
-        if (tn < a.total_tiles) {
-            p0n = __builtin_amdgcn_readfirstlane(tile_origin(tn, m0n, m_endn));
-            issue_patch(p0n, buf ^ 1);
-        }
-        int base[MT];
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            int m = m0 + wave_m * WM + j * 16 + r16;
-            m = m < m_end ? m : m_end - 1;
-            const int img = m / a.HoWo;
-            const int rem = m - img * a.HoWo;
-            const int ho = rem / a.Wo;
-            base[j] = (img * a.H + ho) * a.W + (rem - ho * a.Wo) - p0 + (q >> 1);
-        }
-        f32x4 acc[NT][MT];
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j) acc[i][j] = bias4[i];
-        const char* pb = smem + wbytes + buf * pbuf;
-#pragma unroll 1
-        for (int kh = 0; kh < a.KH; ++kh) {
-            const char* wb = smem + kh * (BN * 128);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int sww = ((kk * 4 + q) ^ (r16 & 7)) << 4;
-                uint4 fx[MT], fw[NT];
-#pragma unroll
-                for (int j = 0; j < MT; ++j) {
-                    const int pix = base[j] + kh * a.W + kk * 2;
-                    fx[j] = *(const uint4*)(pb + pix * 32 + (((q & 1) ^ ((pix >> 3) & 1)) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < NT; ++i) fw[i] = *(const uint4*)(wb + rd_w + i * 16 * 128 + sww);
-#pragma unroll
-                for (int i = 0; i < NT; ++i)
-#pragma unroll
-                    for (int j = 0; j < MT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[i]), __builtin_bit_cast(bf16x8_t, fx[j]),
-                                                                            acc[i][j], 0, 0, 0);
-            }
-        }
-        __syncthreads();   // every wave is done with this patch: the epilogue stages through it, 16 rows per wave row and pass
-
-        constexpr int ROWB = BN * 4 + 16;
-        constexpr int BMP = BM / MT;           // MT passes of one m-tile per wave: 64 rows
-        constexpr int TPR = BN / 8;            // 8 threads per row: NTH / TPR = 64 rows per read-back = one pass
-        static_assert(NTH / TPR == BMP, "one read-back iteration per pass");
-        const int rc = tid % TPR, lrow_r = tid / TPR;
-        char* eb = smem + wbytes + buf * pbuf;
-#pragma unroll
-        for (int p = 0; p < MT; ++p) {
-            if (p) __syncthreads();
-            {
-                const int lrow = wave_m * 16 + r16;
-#pragma unroll
-                for (int i = 0; i < NT; ++i) *(f32x4*)(eb + lrow * ROWB + (wave_n * WN + i * 16 + q * 4) * 4) = acc[i][p];
-            }
-            __syncthreads();
-            const int m = m0 + (lrow_r / 16) * WM + p * 16 + (lrow_r % 16);
-            const int n = rc * 8;
-            if (m < m_end && n < a.Cout) {
-                float v[8];
-                *(float4*)&v[0] = *(const float4*)(eb + lrow_r * ROWB + rc * 32);
-                *(float4*)&v[4] = *(const float4*)(eb + lrow_r * ROWB + rc * 32 + 16);
-                if (a.relu == 1) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-                char* yp = a.y + ((long long)m * a.y_ld + n) * 2;
-                if (a.nt_epi) __builtin_nontemporal_store(ov, (u32x4*)yp);
-                else *(uint4*)yp = make_uint4(ov.x, ov.y, ov.z, ov.w);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next patch has landed (and this tile's stores are acknowledged)
-        __syncthreads();
-        buf ^= 1;
-        m0 = m0n; m_end = m_endn; p0 = p0n;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ host side
 namespace {
 
@@ -1309,20 +1154,14 @@ int launch_patch3x3(const ConvK& k, hipStream_t s) {
 
 int launch_patch_tile(const ConvK& k, int tile, hipStream_t s) {
     switch (tile) {
-        case 21: return launch_patch3x3<256, 64, 4, 2, 4>(k, s);
-        case 22: return launch_patch3x3<256, 128, 4, 4, 3>(k, s);
         case 23: return launch_patch3x3<256, 256, 4, 4, 2>(k, s);
         case 24: return launch_patch3x3<256, 64, 4, 2, 2>(k, s);
-        case 25: return launch_patch3x3<256, 128, 4, 4, 4>(k, s);
         case 26: return launch_patch3x3<256, 128, 4, 4, 2>(k, s);
-        case 27: return launch_patch3x3<256, 64, 4, 2, 9>(k, s);
-        case 28: return launch_patch3x3<512, 64, 8, 2, 9>(k, s);
-        case 29: return launch_patch3x3<128, 64, 2, 2, 2>(k, s);
         case 30: return launch_patch3x3<128, 128, 2, 2, 2>(k, s);
-        case 31: return launch_patch3x3<256, 64, 4, 1, 2>(k, s);
         case 32: return launch_patch3x3<256, 128, 4, 2, 2>(k, s);
     }
-    return MT4_EINVAL;
+    return MT4_EUNSUPPORTED;   // ids 21, 22, 25, 27, 28, 29, 31: retired variants of the tuning record (deeper weight rings, weights-resident forms:
+                               // every one measured slower, profiles/r01_tile_tuning_patch3x3.txt)
 }
 
 // the space-to-depth stem: KH x 1 kernel over runs of 4 pixels x 16 channels, stride 1, valid, Cout <= 64
@@ -1361,40 +1200,6 @@ int launch_stem_patch(const ConvK& k, hipStream_t s) {
     hipLaunchKernelGGL(fn, dim3(kk.total_tiles), dim3(512), lds, s, kk, pra);
     return mt4_check_launch();
 }
-
-int launch_stem_patch_persistent(const ConvK& k, hipStream_t s) {
-    constexpr int BM = 256;
-    ConvK kk = k;
-    kk.n_tiles = cdiv(k.HoWo, BM);
-    kk.total_tiles = k.B * kk.n_tiles;
-    kk.nt_epi = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
-    {
-        const long long min_mb = MT4_ENV_INT("MT4_NT_MIN_MB", 200);
-        if ((long long)k.M * k.Cout * 2 < min_mb * 1000000LL) kk.nt_epi = 0;
-    }
-    const int span = BM + 3 * (cdiv(BM, k.Wo) + 1) + (k.KH - 1) * k.W + 4;
-    int pbuf = (span * 32 + 1023) / 1024 * 1024;
-    constexpr int epi = 64 * (64 * 4 + 16);   // one epilogue pass: 64 rows of fp32
-    if (pbuf < epi) pbuf = epi;
-    const int lds = k.KH * 64 * 128 + 2 * pbuf;
-    if (lds > 160 * 1024) return MT4_EUNSUPPORTED;
-    const int per_cu = (160 * 1024) / lds >= 2 ? 2 : 1;
-    static const int cus = []() {
-        int dev = 0, n = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n;
-    }();
-    int grid = cus * per_cu;
-    if (grid > kk.total_tiles) grid = kk.total_tiles;
-    auto fn = stem_patch_persistent_kernel<BM, 4, 2>;
-    if (lds > 65536) {
-        MT4_RAISE_LDS(fn);
-    }
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, kk, pbuf);
-    return mt4_check_launch();
-}
-
 
 int auto_tile(int M, int N, int nsteps, int es) {
     // Measured on MI355X over the ResNet-50 layer set (tools/tune_conv.py, profiles/r01_tile_tuning.txt):
@@ -1541,10 +1346,10 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     const bool latency = tile == -1;   // automatic choice, K-split tiles allowed
     if (latency) tile = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (tile == 33 || tile == 34 || (tile == 0 && stem_patch_ok(d, k, fast) && !MT4_ENV_SET("MT4_NO_STEM_PATCH"))) {   // the space-to-depth stem
+    if (tile == 34) return MT4_EUNSUPPORTED;   // (retired id: the persistent form of the stem patch kernel, measured no faster in the bench)
+    if (tile == 33 || (tile == 0 && stem_patch_ok(d, k, fast) && !MT4_ENV_SET("MT4_NO_STEM_PATCH"))) {   // the space-to-depth stem
         if (!stem_patch_ok(d, k, fast)) return MT4_EUNSUPPORTED;
-        const int persistent = MT4_ENV_INT("MT4_STEM_PERSISTENT", 0);
-        const int rc = (tile == 34 || (tile == 0 && persistent)) ? launch_stem_patch_persistent(k, s) : launch_stem_patch(k, s);
+        const int rc = launch_stem_patch(k, s);
         if (rc != MT4_EUNSUPPORTED || tile != 0) return rc;
     }
     if (tile >= 21 && tile <= 32) {   // explicit request for the 3x3 patch kernel

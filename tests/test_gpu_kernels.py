@@ -68,9 +68,8 @@ PATCH_SHAPES = [
 ]
 
 
-PATCH_TILES = {  # id: (BM, BN, waves, weight stages)   (igemm_conv.hip launch_patch_tile)
-    21: (256, 64, 8, 4), 22: (256, 128, 16, 3), 23: (256, 256, 16, 2), 24: (256, 64, 8, 2), 25: (256, 128, 16, 4), 26: (256, 128, 16, 2),
-    27: (256, 64, 8, 9), 28: (512, 64, 16, 9), 29: (128, 64, 4, 2), 30: (128, 128, 4, 2), 31: (256, 64, 4, 2), 32: (256, 128, 8, 2)}
+PATCH_TILES = {  # id: (BM, BN, waves, weight stages)   (igemm_conv.hip launch_patch_tile; the other ids of 21..32 are retired variants)
+    23: (256, 256, 16, 2), 24: (256, 64, 8, 2), 26: (256, 128, 16, 2), 30: (128, 128, 4, 2), 32: (256, 128, 8, 2)}
 
 
 def _patch_tile_fits(tile, W, Cin):
@@ -161,10 +160,13 @@ def test_conv3x3_patch_kernel_refuses_other_geometry(cuda):
     from computervision_codes_amd import ops
     x = _rand((1, 8, 8, 64), 1).to(cuda, torch.bfloat16)
     wp = ops.pack_conv_weight(_rand((64, 64, 3, 3), 2, 0.05).to(cuda), None, torch.bfloat16)
+    for retired in (21, 22, 25, 27, 28, 29, 31):      # ids of the tuning record whose instantiations were removed
+        with pytest.raises(RuntimeError):
+            ops.conv_nhwc(x, wp, None, kh=3, kw=3, pad=(1, 1), tile=retired)
     with pytest.raises(RuntimeError):
-        ops.conv_nhwc(x, wp, None, kh=3, kw=3, stride=(2, 2), pad=(1, 1), tile=21)
+        ops.conv_nhwc(x, wp, None, kh=3, kw=3, stride=(2, 2), pad=(1, 1), tile=24)
     with pytest.raises(RuntimeError):
-        ops.conv_nhwc(x.float(), ops.pack_conv_weight(_rand((64, 64, 3, 3), 2, 0.05).to(cuda), None, torch.float32), None, kh=3, kw=3, pad=(1, 1), tile=22)
+        ops.conv_nhwc(x.float(), ops.pack_conv_weight(_rand((64, 64, 3, 3), 2, 0.05).to(cuda), None, torch.float32), None, kh=3, kw=3, pad=(1, 1), tile=23)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -318,14 +318,12 @@ def test_stem_patch_kernel_bit_identical(cuda):
     from computervision_codes_amd.synth import IMAGENET_MEAN, IMAGENET_STD
     _, cfg = load_golden("cnn_resnet50_224")
     m = _cnn_model(cfg, torch.bfloat16)
-    for (b, h, w) in ((5, 224, 224), (3, 64, 96), (2, 256, 448), (7, 32, 34), (1, 32, 32), (12, 224, 224)):   # (12 frames: 588 tiles, the persistent form walks 2 per workgroup)
+    for (b, h, w) in ((5, 224, 224), (3, 64, 96), (2, 256, 448), (7, 32, 34), (1, 32, 32), (12, 224, 224)):   # (12 frames: 588 tiles)
         fr = synth.synthetic_frames(b, h, w, seed=h + w).to(cuda)
         xs = ops.preprocess_u8_s2d(fr, IMAGENET_MEAN, IMAGENET_STD)
         kw = dict(kh=4, kw=1, relu=True, run_pixels=4, out_hw=(h // 2, w // 2))
         ref = ops.conv_nhwc(xs, m._p["stem_s2d"], m._p["stem"][1], tile=20, **kw)
         got = ops.conv_nhwc(xs, m._p["stem_s2d"], m._p["stem"][1], tile=33, **kw)
-        per = ops.conv_nhwc(xs, m._p["stem_s2d"], m._p["stem"][1], tile=34, **kw)   # persistent form
-        assert torch.equal(ref.view(torch.int16), per.view(torch.int16)), (b, h, w)
         auto = ops.conv_nhwc(xs, m._p["stem_s2d"], m._p["stem"][1], **kw)
         assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), (b, h, w)
         assert torch.equal(ref.view(torch.int16), auto.view(torch.int16)), (b, h, w)
