@@ -475,6 +475,14 @@ def ddp_train_bench(dev, dist, world, rank):
                                allreduce_alone_ms=round(ar, 3), grad_MB=round(tr.G.numel() * 4 / 1e6, 1),
                                overlap_fraction=round(1.0 - min(1.0, exposed / ar), 3) if ar > 0 else None,
                                mode="hipGraph replay of forward+backward, one flat all-reduce")
+    ms_e = timed(lambda: tr.train_step(xt, zl, use_graph=False), 10)                        # eager: per-stage buckets behind the backward
+    tr.exchange = False
+    ms_e_local = timed(lambda: tr.train_step(xt, zl, use_graph=False), 10)
+    tr.exchange = True
+    exposed = max(0.0, ms_e - ms_e_local)
+    out[f"tenco4_T{T}_eager_buckets"] = dict(videos_per_s=round(world / ms_e * 1e3, 2), ms_per_step=round(ms_e, 3), ms_per_step_no_exchange=round(ms_e_local, 3),
+                                             overlap_fraction=round(1.0 - min(1.0, exposed / ar), 3) if ar > 0 else None,
+                                             mode="eager launches, per-stage all-reduce (heads, Rs.2, Rs.1, Rs.0, PG) issued behind the backward")
     return out
 
 

@@ -33,7 +33,10 @@ class _Conv:
 
 class TencoTrainer:
     def __init__(self, num_layers_PG=11, num_layers_R=10, num_R=3, num_f_maps=512, dim=512, num_classes=100, lr=0.1, weight_decay=1e-5,
-                 device: str = "cuda", process_group=None):
+                 device: str = "cuda", process_group=None, overlap: bool = True):
+        self.overlap = overlap            # DDP: all-reduce a stage's gradients as soon as its backward has written them (eager steps)
+        self._pending: list = []
+        self._capturing = False
         assert num_classes == 100 and num_R == 3, "the FPN training recipe (Scripts/train_fold1.sh:28) has PG + 3 refinement stages"
         self.LP, self.LR, self.R, self.C, self.D = num_layers_PG, num_layers_R, num_R, num_f_maps, dim
         self.lr, self.wd = lr, weight_decay
@@ -69,7 +72,10 @@ class TencoTrainer:
         wt_total = sum(cin * ops.packed_k(cout, 1, taps, f32) for _, cout, cin, taps in specs if _ != "PG.conv_1x1")
         self.WT = torch.zeros(wt_total, dtype=f32, device=self.dev)
         off = wo = 0
+        self._ranges: Dict[str, list] = {}     # flat-buffer range of every gradient bucket: "PG", "Rs.0".."Rs.2", "heads" (FPN lateral + heads)
         for name, cout, cin, taps in specs:
+            bucket = name.split(".layers.")[0] if ".layers." in name else ("PG" if name == "PG.conv_1x1" else "heads")
+            self._ranges.setdefault(bucket, [off, off])
             c = _Conv()
             c.name, c.cout, c.cin, c.taps = name, cout, cin, taps
             c.kpad = ops.packed_k(cin, 1, taps, f32)
@@ -77,6 +83,7 @@ class TencoTrainer:
             c.w, c.gw = self.P[off:off + nw].view(cout, c.kpad), self.G[off:off + nw].view(cout, c.kpad)
             c.b, c.gb = self.P[off + nw:off + nw + cout], self.G[off + nw:off + nw + cout]
             off += nw + ((cout + 3) // 4) * 4
+            self._ranges[bucket][1] = off
             if name == "heads":
                 w = torch.cat([sd[f"conv_out{s}.weight"] for s, _, _ in HEADS], 0).float()
                 b = torch.cat([sd[f"conv_out{s}.bias"] for s, _, _ in HEADS], 0).float()
@@ -169,7 +176,11 @@ class TencoTrainer:
             g = self._graphs.get(T)
             if g is None:
                 from .graph import GraphedForward
-                g = self._graphs[T] = GraphedForward(lambda xx, zz: self._fwd_bwd(xx, zz, None), [x, z])
+                self._capturing = True
+                try:
+                    g = self._graphs[T] = GraphedForward(lambda xx, zz: self._fwd_bwd(xx, zz, None), [x, z])
+                finally:
+                    self._capturing = False
             col_loss = g(x, z)
         else:
             col_loss = self._fwd_bwd(x, z, masks)
@@ -250,6 +261,7 @@ class TencoTrainer:
                 dstage[li] = self._conv(g, lat, transposed=True)
             else:
                 dstage[3] = g                                                  # p4 is the last stage's output itself
+        self._reduce_bucket("heads")
         # ---- backward through the stages, last to first
         df = dstage[3]
         idx = len(saved)
@@ -268,10 +280,27 @@ class TencoTrainer:
                 df = self._conv(du, wd, dil=d, transposed=True, residual=df)
             if si > 0:
                 df = ops.mul_add(df, torch.ones_like(df), dstage[si - 1])      # + gradient of this stage's input as lateral c
-        pin = cv["PG.conv_1x1"]
+                self._reduce_bucket(prefix)                                    # this stage's gradients are complete: exchange them behind
+        pin = cv["PG.conv_1x1"]                                                #   the backward of the earlier stages
         ops.wgrad_conv1d(df.view(T, C), h0.view(T, self.D), pin.gw, batch=1, t=T, taps=1, dil=1, pad=0)
         ops.colsum(df.view(T, C), pin.gb)
+        self._reduce_bucket("PG")
         return col_loss
+
+    def _ddp_world(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _reduce_bucket(self, name: str):
+        """DDP overlap: the bucket's all-reduce is enqueued behind the kernels that wrote it and runs while the backward of the
+        earlier stages continues; `apply_update` waits for all of them.  Eager steps only (inside a hipGraph capture the step keeps the single
+        flat all-reduce after the replay)."""
+        if not self.overlap or self._capturing or not getattr(self, "exchange", True) or self._ddp_world() == 1:
+            return
+        import torch.distributed as dist
+        a, b = self._ranges[name]
+        if b > a:
+            self._pending.append(dist.all_reduce(self.G[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _col_scale(self, T: int) -> torch.Tensor:
         cs = self._scales.get(T)
@@ -281,7 +310,13 @@ class TencoTrainer:
 
     def apply_update(self):
         """DDP exchange (one all-reduce of the flat gradient buffer, mean over ranks) + SGD + refresh of the transposed copies"""
-        scale = allreduce_sum_flat(self.G, self.pg) if getattr(self, "exchange", True) else 1.0   # exchange=False: rank-local step (bench only)
+        if self._pending:                                   # buckets were reduced during the backward
+            for h in self._pending:
+                h.wait()
+            self._pending = []
+            scale = 1.0 / self._ddp_world()
+        else:
+            scale = allreduce_sum_flat(self.G, self.pg) if getattr(self, "exchange", True) else 1.0   # exchange=False: rank-local step (bench only)
         ops.sgd_step(self.P, self.G, self.lr, self.wd, scale)
         self._refresh_transposed()
 
