@@ -1,18 +1,36 @@
 #!/bin/bash
-# round-final measurement set on the GPU box: bench line + per-layer table, rocprofv3 kernel stats, PMC traffic passes
+# round-final measurement set on the GPU box: bench line + per-layer table, rocprofv3 kernel stats, PMC traffic / MFMA passes for the
+# spatial extractor (the headline kernel) and for the temporal head (per-video latency), kernel stats of the MS-TCT training step.
+# Every rocprofv3 command has the program directly after `--`.
 set -e
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out; rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/prof_final
-timeout -k 10 500 python bench.py --per-layer gpurun_out/layers_final.json > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+O=$R/gpurun_out
+mkdir -p $O; rm -rf $O/pmc_fetch $O/pmc_write $O/prof_final $O/pmc_mfma $O/prof_tenco_f32 $O/prof_tenco_bf16 $O/pmc_tenco_FETCH_SIZE $O/pmc_tenco_WRITE_SIZE $O/prof_mstct_train
+cd $R
+timeout -k 10 900 python bench.py --per-layer gpurun_out/layers_final.json > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
 echo bench done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o final -- python3 bench.py --streams 1 --steps 10 --warmup 3 --no-cpu-baseline --no-temporal > gpurun_out/prof_final.log 2>&1
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_final -o final -- python3 $R/bench.py --streams 1 --steps 10 --warmup 3 --no-cpu-baseline --no-temporal > $O/prof_final.log 2>&1
 echo stats done
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-temporal > gpurun_out/pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-temporal > $O/pmc_fetch.log 2>&1
 echo fetch done
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-temporal > gpurun_out/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-temporal > $O/pmc_write.log 2>&1
 echo write done
-python tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 54 resnet50_bf16_b1336_224x224 gpurun_out/traffic.json
-rm -rf gpurun_out/pmc_mfma
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma -- python3 bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-temporal > gpurun_out/pmc_mfma.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-temporal > $O/pmc_mfma.log 2>&1
 echo mfma done
+for dt in f32 bf16; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tenco_$dt -o tenco -- python3 $R/tools/tenco_infer_prof.py --dtype $dt > $O/prof_tenco_$dt.log 2>&1
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_tenco_$c -- python3 $R/tools/tenco_infer_prof.py --replays 3 > $O/pmc_tenco_$c.log 2>&1
+done
+echo tenco done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_mstct_train -o mt -- python3 $R/tools/mstct_train_prof.py > $O/prof_mstct_train.log 2>&1
+echo mstct done
+cd $R
+cp profiles/traffic.json gpurun_out/traffic.json; cp profiles/mfma_util.json gpurun_out/mfma_util.json
+python tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 54 resnet50_bf16_b1336_224x224 gpurun_out/traffic.json
 python tools/collect_mfma_util.py gpurun_out/pmc_mfma 54 resnet50_bf16_b1336_224x224 gpurun_out/mfma_util.json
+python tools/collect_tcn_traffic.py gpurun_out/pmc_tenco_FETCH_SIZE gpurun_out/pmc_tenco_WRITE_SIZE tenco4_f32_T256 gpurun_out/traffic.json
+echo all done
