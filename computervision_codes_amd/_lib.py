@@ -105,6 +105,12 @@ SIGNATURES = {
     "mt4_gelu_f32": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "mt4_gelu_bwd_f32": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "mt4_dwconv1d_k3_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "mt4_gather_rows_f32": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_add_bias_mask_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _i32, _vp]),
+    "mt4_relpos_table_grad_f32": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i32, _i32, _vp]),
+    "mt4_rowscale_add_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _vp]),
+    "mt4_groupwise_linear_bwd_f32": (C.c_int, [_vp] * 6 + [_i32, _i32, _i32, _vp]),
+    "mt4_sum_over_batch_f32": (C.c_int, [_vp, _vp, _i32, C.c_int64, _i32, _vp]),
     "mt4_dropout_mask_f32": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_float, _vp]),
     "mt4_axpby_f32": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_float, _vp]),
 }

@@ -164,17 +164,18 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
 // ------------------------------------------------------------------------------------------------ LayerNorm backward
 // y = (x - mean) * rstd * gamma + beta over the last dimension (nn.LayerNorm, eps inside the sqrt, biased variance).
 //   g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dgamma += sum_rows dy * xhat;  dbeta += sum_rows dy
-// One wave per row at a time (C <= 64 * 16), statistics recomputed from x; a wave keeps its dgamma / dbeta partial sums in registers
+// One wave per row at a time (C <= 64 * NI; NI = 16 / 32 / 48 by width), statistics recomputed from x; a wave keeps its dgamma / dbeta partial sums in registers
 // over all its rows and adds them to the (caller-zeroed or accumulating) gradient buffers once, with float atomics.
+template <int NI>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                              float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              long long M, int C, float eps, int add_dx) {
     const int lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * 4;
-    float gm[16], pg[16], pb[16];
+    float gm[NI], pg[NI], pb[NI];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int c = lane + 64 * i;
         gm[i] = c < C ? gamma[c] : 0.f;
         pg[i] = pb[i] = 0.f;
@@ -183,10 +184,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (long long row = wave; row < M; row += nwaves) {
         const float* xr = x + row * C;
         const float* dr = dy + row * C;
-        float xv[16], dv[16];
+        float xv[NI], dv[NI];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int c = lane + 64 * i;
             xv[i] = c < C ? xr[c] : 0.f;
             dv[i] = c < C ? dr[c] : 0.f;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const float mean = s * invC;
         float var = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const float d = (lane + 64 * i) < C ? xv[i] - mean : 0.f;
             var += d * d;
         }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const float rstd = rsqrtf(var * invC + eps);
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const float xh = (xv[i] - mean) * rstd;
             const float g = dv[i] * gm[i];
             xv[i] = xh;                 // keep xhat
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         sgx *= invC;
         float* dxr = dx + row * C;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int c = lane + 64 * i;
             if (c < C) {
                 const float v = rstd * (dv[i] * gm[i] - sg - xv[i] * sgx);
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int c = lane + 64 * i;
         if (c < C) {
             atomicAdd(dgamma + c, pg[i]);
@@ -335,7 +336,159 @@ __global__ void dropout_mask_kernel(float* __restrict__ out, long long n, unsign
     out[i] = u >= (double)p ? keep_scale : 0.f;
 }
 
+
+// ------------------------------------------------------------------------------------------------ row gather / scatter by a per-image map
+// Swin's roll + window_partition (swin_transformer.py:241-252) and PatchMerging's 2x2 gather (:320-324) as seen from the training step:
+//   gather : y[m][g*C + c] = x[(m / l_out) * l_in + map[(m % l_out) * group + g]][c]
+//   scatter: x[(m / l_out) * l_in + map[(m % l_out) * group + g]][c] = y[m][g*C + c]      (the maps are bijections: plain stores)
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ map, float* __restrict__ y, long long m_out, int C, int group,
+                                   int l_out, int l_in, int scatter) {
+    const int c4 = C >> 2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of one (m, g)
+    const long long total = m_out * group * c4;
+    if (i >= total) return;
+    const int c = (int)(i % c4) * 4;
+    const long long mg = i / c4;
+    const int g = (int)(mg % group);
+    const long long m = mg / group;
+    const long long img = m / l_out;
+    const int lo = (int)(m - img * l_out);
+    const long long src = img * l_in + map[lo * group + g];
+    float* yp = y + (m * group + g) * C + c;
+    float* xp = const_cast<float*>(x) + src * C + c;
+    if (scatter) *(float4*)xp = *(const float4*)yp;
+    else *(float4*)yp = *(const float4*)xp;
+}
+
+// attention scores of a Swin block: S[bw][h][i][j] += bias[h][i][j] (+ mask[bw % nW][i][j])   (swin_transformer.py:127-136)
+__global__ void add_bias_mask_kernel(float* __restrict__ S, const float* __restrict__ bias, const int* __restrict__ index,
+                                     const float* __restrict__ mask, long long total, int H, int NN, int nW) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ij = (int)(i % NN);
+    const long long bh = i / NN;
+    const int h = (int)(bh % H);
+    const long long bw = bh / H;
+    // index: `bias` is the relative-position table [(2ws-1)^2][H] read through relative_position_index (swin_transformer.py:127-130)
+    float v = S[i] + (index ? bias[(long long)index[ij] * H + h] : bias[(long long)h * NN + ij]);
+    if (mask) v += mask[(bw % nW) * NN + ij];
+    S[i] = v;
+}
+
+// gradient of the relative-position bias table: dtable[idx[ij]][h] += sum_bw dS[bw][h][ij]   (the gather of swin_transformer.py:127-130
+// transposed; many (i, j) share a table row: float atomics on the small table)
+__global__ void relpos_table_grad_kernel(const float* __restrict__ dS, const int* __restrict__ idx, float* __restrict__ dtable, long long nbw, int H,
+                                         int NN) {
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (ij >= NN) return;
+    float s = 0.f;
+    for (long long bw = blockIdx.z; bw < nbw; bw += gridDim.z) s += dS[(bw * H + h) * NN + ij];
+    atomicAdd(dtable + (long long)idx[ij] * H + h, s);
+}
+
+// y[m][:] = s[m / rows_per_scale] * x[m][:] (+ r[m][:])   -- DropPath (timm, per-sample keep mask / keep_prob) on a residual branch
+__global__ void rowscale_add_kernel(const float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ r, float* __restrict__ y,
+                                    long long M, int C, int rows_per_scale) {
+    const int c4 = C >> 2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * c4) return;
+    const long long m = i / c4;
+    const float sc = s[m / rows_per_scale];
+    const float4 xv = *(const float4*)(x + i * 4);
+    float4 o = make_float4(sc * xv.x, sc * xv.y, sc * xv.z, sc * xv.w);
+    if (r) { const float4 rv = *(const float4*)(r + i * 4); o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
+    *(float4*)(y + i * 4) = o;
+}
+
+// GroupWiseLinear backward (Spatial_transformer/network.py:40-45: out[b][k] = sum_d W[k][d] hs[b][k][d] + bias[k]):
+//   dhs[b][k][d] = dy[b][k] W[k][d];  dW[k][d] += sum_b dy[b][k] hs[b][k][d];  db[k] += sum_b dy[b][k]
+__global__ void groupwise_linear_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ hs, const float* __restrict__ W,
+                                            float* __restrict__ dhs, float* __restrict__ dW, float* __restrict__ db, int B, int K, int D) {
+    const int k = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        const float w = W[(long long)k * D + d];
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float g = dy[(long long)b * K + k];
+            acc += g * hs[((long long)b * K + k) * D + d];
+            dhs[((long long)b * K + k) * D + d] = g * w;
+        }
+        dW[(long long)k * D + d] += acc;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dy[(long long)b * K + k];
+        db[k] += s;
+    }
+}
+
+// out[l][:] (+)= sum_b x[b*L + l][:]   (gradient of a row-broadcast add: the query embedding added to every image's queries)
+__global__ void sum_over_batch_kernel(const float* __restrict__ x, float* __restrict__ out, int B, long long LC, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= LC) return;
+    float s = accumulate ? out[i] : 0.f;
+    for (int b = 0; b < B; ++b) s += x[(long long)b * LC + i];
+    out[i] = s;
+}
+
 }  // namespace
+
+extern "C" int mt4_gather_rows_f32(const float* x, const int32_t* map, float* y, int64_t m_out, int32_t C, int32_t group, int32_t l_out, int32_t l_in,
+                                   int32_t scatter, void* stream) {
+    mt4_clear_error();
+    if (!x || !map || !y || m_out <= 0 || C <= 0 || (C & 3) || group <= 0 || l_out <= 0 || l_in <= 0) return MT4_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return MT4_EALIGN;
+    const long long total = m_out * group * (C >> 2);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, map, y, (long long)m_out, C, group,
+                       l_out, l_in, scatter ? 1 : 0);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_add_bias_mask_f32(float* S, const float* bias, const int32_t* index, const float* mask, int64_t n_windows, int32_t heads, int32_t N,
+                                     int32_t nW, void* stream) {
+    mt4_clear_error();
+    if (!S || !bias || n_windows <= 0 || heads <= 0 || N <= 0 || (mask && nW <= 0)) return MT4_EINVAL;
+    const long long total = n_windows * heads * (long long)N * N;
+    hipLaunchKernelGGL(add_bias_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S, bias, index, mask, total, heads,
+                       N * N, mask ? nW : 1);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_relpos_table_grad_f32(const float* dS, const int32_t* index, float* dtable, int64_t n_windows, int32_t heads, int32_t N, void* stream) {
+    mt4_clear_error();
+    if (!dS || !index || !dtable || n_windows <= 0 || heads <= 0 || N <= 0 || heads > 65535) return MT4_EINVAL;
+    const int NN = N * N;
+    int zs = (int)(n_windows < 16 ? n_windows : 16);
+    hipLaunchKernelGGL(relpos_table_grad_kernel, dim3(cdiv(NN, 256), heads, zs), dim3(256), 0, (hipStream_t)stream, dS, index, dtable, (long long)n_windows,
+                       heads, NN);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_rowscale_add_f32(const float* x, const float* scale, const float* r, float* y, int64_t M, int32_t C, int32_t rows_per_scale, void* stream) {
+    mt4_clear_error();
+    if (!x || !scale || !y || M <= 0 || C <= 0 || (C & 3) || rows_per_scale <= 0) return MT4_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)r) & 15) return MT4_EALIGN;
+    const long long total = M * (C >> 2);
+    hipLaunchKernelGGL(rowscale_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, scale, r, y, (long long)M, C,
+                       rows_per_scale);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_groupwise_linear_bwd_f32(const float* dy, const float* hs, const float* W, float* dhs, float* dW, float* db, int32_t B, int32_t K,
+                                            int32_t D, void* stream) {
+    mt4_clear_error();
+    if (!dy || !hs || !W || !dhs || !dW || !db || B <= 0 || K <= 0 || D <= 0) return MT4_EINVAL;
+    hipLaunchKernelGGL(groupwise_linear_bwd_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, dy, hs, W, dhs, dW, db, B, K, D);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_sum_over_batch_f32(const float* x, float* out, int32_t B, int64_t LC, int32_t accumulate, void* stream) {
+    mt4_clear_error();
+    if (!x || !out || B <= 0 || LC <= 0) return MT4_EINVAL;
+    hipLaunchKernelGGL(sum_over_batch_kernel, dim3((unsigned)((LC + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, B, (long long)LC, accumulate ? 1 : 0);
+    return mt4_check_launch();
+}
 
 extern "C" int mt4_dropout_mask_f32(float* out, int64_t n, int64_t seed, int64_t stream_id, float p, void* stream) {
     mt4_clear_error();
@@ -383,12 +536,13 @@ extern "C" int mt4_layernorm_bwd_f32(const float* dy, const float* x, const floa
                                      int32_t C, float eps, int32_t accumulate_dx, void* stream) {
     mt4_clear_error();
     if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || M <= 0 || C <= 0) return MT4_EINVAL;
-    if (C > 1024) return MT4_EUNSUPPORTED;
+    if (C > 3072) return MT4_EUNSUPPORTED;
     long long blocks = (M + 31) / 32;                       // a wave takes ~8 rows: few atomics, enough waves
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, dx, dgamma, dbeta, (long long)M, C,
-                       eps, accumulate_dx ? 1 : 0);
+    auto kern = C <= 1024 ? layernorm_bwd_kernel<16> : C <= 2048 ? layernorm_bwd_kernel<32> : layernorm_bwd_kernel<48>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, dx, dgamma, dbeta, (long long)M, C, eps,
+                       accumulate_dx ? 1 : 0);
     return mt4_check_launch();
 }
 

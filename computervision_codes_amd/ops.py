@@ -765,3 +765,79 @@ def dropout_mask(shape, seed: int, stream_id: int, p: float = 0.5, device="cuda"
     out = torch.empty(shape, dtype=torch.float32, device=device)
     check(lib.mt4_dropout_mask_f32(out.data_ptr(), out.numel(), seed, stream_id, p, _stream()), "mt4_dropout_mask_f32")
     return out
+
+
+# ----------------------------------------------------------------------------------------- Swin / Q2L training pieces (fp32)
+def gather_rows(x: torch.Tensor, row_map: torch.Tensor, *, l_out: int, l_in: int, group: int = 1, m_out: Optional[int] = None) -> torch.Tensor:
+    """y[m][g*C:(g+1)*C] = x[(m // l_out) * l_in + map[(m % l_out) * group + g]]  (`mt4_gather_rows_f32`)"""
+    _need_cuda(x, row_map)
+    assert x.is_contiguous() and x.dtype == torch.float32 and row_map.dtype == torch.int32 and row_map.numel() == l_out * group
+    m_in, c = x.shape
+    m_out = m_in if m_out is None else m_out
+    y = torch.empty((m_out, group * c), dtype=torch.float32, device=x.device)
+    check(lib.mt4_gather_rows_f32(x.data_ptr(), row_map.data_ptr(), y.data_ptr(), m_out, c, group, l_out, l_in, 0, _stream()), "mt4_gather_rows_f32")
+    return y
+
+
+def scatter_rows(y: torch.Tensor, row_map: torch.Tensor, *, l_out: int, l_in: int, group: int = 1, m_in: Optional[int] = None) -> torch.Tensor:
+    """the inverse of `gather_rows` (the maps are bijections): x[(m // l_out) * l_in + map[...]] = y[m][g*C:(g+1)*C]"""
+    _need_cuda(y, row_map)
+    assert y.is_contiguous() and y.dtype == torch.float32 and row_map.dtype == torch.int32
+    m_out, gc = y.shape
+    c = gc // group
+    m_in = m_out * group if m_in is None else m_in
+    x = torch.empty((m_in, c), dtype=torch.float32, device=y.device)
+    check(lib.mt4_gather_rows_f32(x.data_ptr(), row_map.data_ptr(), y.data_ptr(), m_out, c, group, l_out, l_in, 1, _stream()), "mt4_gather_rows_f32")
+    return x
+
+
+def add_bias_mask_(s: torch.Tensor, bias: torch.Tensor, mask: Optional[torch.Tensor], index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """s [nWin, H, N, N] += bias (+ mask [nW, N, N] of window nWin % nW); bias dense [H, N, N], or with `index` [N*N] (int32) the
+    relative-position table [(2ws-1)^2, H] read through it"""
+    _need_cuda(s, bias, mask, index)
+    nwin, h, n, _ = s.shape
+    assert s.is_contiguous() and bias.is_contiguous() and (mask is None or mask.is_contiguous())
+    assert (tuple(bias.shape) == (h, n, n)) if index is None else (bias.shape[1] == h and index.dtype == torch.int32 and index.numel() == n * n)
+    check(lib.mt4_add_bias_mask_f32(s.data_ptr(), bias.data_ptr(), index.data_ptr() if index is not None else None,
+                                    mask.data_ptr() if mask is not None else None, nwin, h, n, mask.shape[0] if mask is not None else 1, _stream()),
+          "mt4_add_bias_mask_f32")
+    return s
+
+
+def relpos_table_grad(ds: torch.Tensor, index: torch.Tensor, dtable: torch.Tensor) -> None:
+    """dtable [(2ws-1)^2, H] += sum over windows of ds [nWin, H, N, N] scattered through index [N*N] (int32)"""
+    _need_cuda(ds, index, dtable)
+    nwin, h, n, _ = ds.shape
+    assert ds.is_contiguous() and index.dtype == torch.int32 and index.numel() == n * n and dtable.is_contiguous() and dtable.shape[1] == h
+    check(lib.mt4_relpos_table_grad_f32(ds.data_ptr(), index.data_ptr(), dtable.data_ptr(), nwin, h, n, _stream()), "mt4_relpos_table_grad_f32")
+
+
+def rowscale_add(x: torch.Tensor, scale: torch.Tensor, r: Optional[torch.Tensor], rows_per_scale: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[m] = scale[m // rows_per_scale] * x[m] (+ r[m])"""
+    _need_cuda(x, scale, r, out)
+    m, c = x.shape
+    assert x.is_contiguous() and scale.is_contiguous() and scale.numel() * rows_per_scale == m and (r is None or r.is_contiguous())
+    y = torch.empty_like(x) if out is None else out
+    check(lib.mt4_rowscale_add_f32(x.data_ptr(), scale.data_ptr(), r.data_ptr() if r is not None else None, y.data_ptr(), m, c, rows_per_scale, _stream()),
+          "mt4_rowscale_add_f32")
+    return y
+
+
+def groupwise_linear_bwd(dy: torch.Tensor, hs: torch.Tensor, w: torch.Tensor, dw: torch.Tensor, db: torch.Tensor) -> torch.Tensor:
+    """dy [B,K]; hs [B*K, D]; w [K,D]; dw / db ADDED to; returns dhs [B*K, D]"""
+    _need_cuda(dy, hs, w, dw, db)
+    b, k = dy.shape
+    d = w.shape[1]
+    assert dy.is_contiguous() and hs.is_contiguous() and w.is_contiguous() and hs.numel() == b * k * d
+    dhs = torch.empty_like(hs)
+    check(lib.mt4_groupwise_linear_bwd_f32(dy.data_ptr(), hs.data_ptr(), w.data_ptr(), dhs.data_ptr(), dw.data_ptr(), db.data_ptr(), b, k, d, _stream()),
+          "mt4_groupwise_linear_bwd_f32")
+    return dhs
+
+
+def sum_over_batch(x: torch.Tensor, out: torch.Tensor, batch: int, accumulate: bool = False) -> torch.Tensor:
+    """out [L, C] (+)= sum_b x[b*L:(b+1)*L]"""
+    _need_cuda(x, out)
+    assert x.is_contiguous() and out.is_contiguous() and x.numel() == batch * out.numel()
+    check(lib.mt4_sum_over_batch_f32(x.data_ptr(), out.data_ptr(), batch, out.numel(), 1 if accumulate else 0, _stream()), "mt4_sum_over_batch_f32")
+    return out

@@ -342,6 +342,33 @@ int mt4_dropout_mask_f32(float* out, int64_t n, int64_t seed, int64_t stream_id,
 /* y = a * x + b * y (b == 0: y is not read); n % 4 == 0 */
 int mt4_axpby_f32(const float* x, float* y, int64_t n, float a, float b, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward pieces of the Swin + Query2Label teacher (what torch autograd derives inside Spatial_transformer/run.py:150-229 for
+ * Spatial_transformer/models/swin_transformer.py and models/transformer.py).  float32.  LayerNorm / GELU / softmax / batched-GEMM
+ * backward are the entry points above.
+ */
+/* Row gather by a per-image map: y[m][g*C + c] = x[(m / l_out) * l_in + map[(m % l_out) * group + g]][c]  -- roll + window_partition
+ * (swin_transformer.py:241-252; group 1) and PatchMerging's 2x2 gather (:320-324; group 4).  scatter != 0 runs the inverse (the maps
+ * are bijections): x[...] = y[m][...], which is both window_reverse + roll back (:255-265) and the gather's backward.  C % 4 == 0. */
+int mt4_gather_rows_f32(const float* x, const int32_t* map, float* y, int64_t m_out, int32_t C, int32_t group, int32_t l_out, int32_t l_in,
+                        int32_t scatter, void* stream);
+/* S[w][h][i][j] += bias (+ mask[w % nW][i][j]); S [n_windows][heads][N][N]; mask [nW][N][N] or NULL (swin_transformer.py:127-136).
+ * index NULL: bias is dense [heads][N][N]; else bias is the relative-position table [(2ws-1)^2][heads] read as bias[index[i*N+j]][h]
+ * (`relative_position_bias_table[relative_position_index]`, :127-130), index [N*N] int32 */
+int mt4_add_bias_mask_f32(float* S, const float* bias, const int32_t* index, const float* mask, int64_t n_windows, int32_t heads, int32_t N,
+                          int32_t nW, void* stream);
+/* dtable[index[i*N + j]][h] += sum_w dS[w][h][i][j]: gradient of `relative_position_bias_table` [(2ws-1)^2][heads] through the gather of
+ * swin_transformer.py:127-130; index [N*N] int32.  Added to (float atomics). */
+int mt4_relpos_table_grad_f32(const float* dS, const int32_t* index, float* dtable, int64_t n_windows, int32_t heads, int32_t N, void* stream);
+/* y[m][:] = scale[m / rows_per_scale] * x[m][:] (+ r[m][:]): timm DropPath on a residual branch (swin_transformer.py:266,269; scale =
+ * keep mask / keep_prob per sample) and its backward.  r may be NULL.  C % 4 == 0. */
+int mt4_rowscale_add_f32(const float* x, const float* scale, const float* r, float* y, int64_t M, int32_t C, int32_t rows_per_scale, void* stream);
+/* backward of mt4_groupwise_linear (GroupWiseLinear, Spatial_transformer/network.py:40-45): dhs written, dW / db ADDED to */
+int mt4_groupwise_linear_bwd_f32(const float* dy, const float* hs, const float* W, float* dhs, float* dW, float* db, int32_t B, int32_t K, int32_t D,
+                                 void* stream);
+/* out[i] (+)= sum_b x[b*LC + i], i < LC: gradient of a row-broadcast add (query embedding / position code added to every image) */
+int mt4_sum_over_batch_f32(const float* x, float* out, int32_t B, int64_t LC, int32_t accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -564,7 +564,87 @@ def gen_mstct_train(name):
         torch.set_grad_enabled(False)
 
 
+# ------------------------------------------------------------------------------------------ Swin + Q2L teacher train step
+Q2L_TRAIN_CASES = {
+    "q2l_train_swinT_i": dict(backbone="swin_T_224_1k", img=224, hidden=768, loss_type="i", B=2, seed=801, lr=0.05),
+    "q2l_train_swinT_t": dict(backbone="swin_T_224_1k", img=224, hidden=768, loss_type="t", B=3, seed=802, lr=0.05),
+}
+
+
+def q2l_train_inputs(cfg):
+    img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["img"], cfg["img"], seed=cfg["seed"]))
+    k = {"i": 6, "v": 10, "t": 15}[cfg["loss_type"]]
+    y = torch.from_numpy((synth.uniform01(cfg["seed"], 900, cfg["B"] * k) < 0.3).reshape(cfg["B"], k).astype(np.int64))
+    return img, y
+
+
+def gen_q2l_train(name):
+    """The reference `Qeruy2Label` in train() mode, the single-task loss of `Spatial_transformer/run.py:168-182` and torch.optim.SGD
+    (`run.py:360`) for one step.  Every random module is neutral here: nn.Dropout and nn.MultiheadAttention's dropout set to p = 0, DropPath is
+    the identity stand-in (timm is absent); those pieces are pinned oracle-vs-HIP with explicit masks instead."""
+    from oracle import q2l_train as o_qt
+    cfg = Q2L_TRAIN_CASES[name]
+    lt = cfg["loss_type"]
+    torch.set_grad_enabled(True)
+    try:
+        m = _ref_q2l(cfg["backbone"], cfg["img"], cfg["hidden"], lt)
+        m.train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        table = shapes.q2l_param_shapes(cfg["backbone"], cfg["img"], cfg["hidden"], lt)
+        sd = synth.fill_from_shapes(table, seed=cfg["seed"])
+        missing = m.load_state_dict(sd, strict=False)
+        assert not missing.unexpected_keys and all(k.endswith(shapes.SWIN_BUFFER_SUFFIXES) for k in missing.missing_keys)
+        img, y = q2l_train_inputs(cfg)
+        fn = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(o_qt.POS_W[lt]))
+        opt = torch.optim.SGD(m.parameters(), lr=cfg["lr"], weight_decay=1e-5)
+        logits = m(img)[{"i": 0, "v": 1, "t": 2}[lt]][1]
+        loss = fn(logits, y.float())
+        for p_ in m.parameters():
+            p_.grad = None
+        loss.backward()
+        grads = {k: (p_.grad.clone() if p_.grad is not None else None) for k, p_ in m.named_parameters()}
+        opt.step()
+        new_ref = {k: v.detach().clone() for k, v in m.named_parameters()}
+        keys = [k for k, _ in table]
+        assert all(grads[k] is not None for k in keys), [k for k in keys if grads[k] is None][:5]
+        new_o, loss_o, g_o = o_qt.train_step(sd, img, y, cfg["backbone"], cfg["img"], cfg["hidden"], lt, cfg["lr"], 1e-5)
+        assert abs(loss_o - float(loss)) < 2e-5 * max(1, abs(float(loss))), (loss_o, float(loss))
+        worst = 0.0
+        for k in keys:
+            e = _rel(new_o[k].float(), new_ref[k].float())
+            worst = max(worst, e)
+            assert e < 2e-4, (name, k, e)
+        _, _, g64 = o_qt.train_step_f64(sd, img, y, cfg["backbone"], cfg["img"], cfg["hidden"], lt, cfg["lr"], 1e-5)
+        outd = {"cfg": np.array(repr(cfg)), "loss": np.array(float(loss)), "logits": logits.detach().numpy(),
+                "grad_norms": np.array([float(grads[k].norm()) for k in keys], dtype=np.float64),
+                "grad_cond": np.array([float((grads[k].double() - g64[k]).abs().max() / max(float(g64[k].abs().max()), 1e-30)) for k in keys],
+                                      dtype=np.float64)}
+        d, t = f"decoder_{lt}.", f"decoder_{lt}.transformer."
+        samp = ["backbone.0.patch_embed.proj.weight", "backbone.0.patch_embed.norm.bias", "backbone.0.layers.0.blocks.0.attn.qkv.weight",
+                "backbone.0.layers.0.blocks.1.attn.relative_position_bias_table", "backbone.0.layers.0.blocks.1.attn.proj.bias",
+                "backbone.0.layers.0.downsample.reduction.weight", "backbone.0.layers.1.blocks.1.mlp.fc1.weight",
+                "backbone.0.layers.2.blocks.3.attn.relative_position_bias_table", "backbone.0.layers.2.blocks.5.mlp.fc2.weight",
+                "backbone.0.layers.2.downsample.norm.weight", "backbone.0.layers.3.blocks.1.norm2.weight", "backbone.0.norm.bias",
+                d + "input_proj.weight", d + "query_embed.weight", d + "fc.W", d + "fc.b", t + "encoder.layers.0.self_attn.in_proj_weight",
+                t + "encoder.layers.0.self_attn.in_proj_bias", t + "encoder.layers.0.linear1.weight", t + "encoder.layers.0.norm2.weight",
+                t + "decoder.layers.0.multihead_attn.in_proj_weight", t + "decoder.layers.0.multihead_attn.out_proj.weight",
+                t + "decoder.layers.1.linear2.weight", t + "decoder.layers.1.norm3.bias", t + "decoder.norm.weight"]
+        for k in samp:
+            flat = (new_ref[k].float() - sd[k].float()).flatten()
+            outd["delta::" + k] = flat[:: max(1, flat.numel() // 2048)].numpy()
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **outd)
+        print(name, "ok: loss", float(loss), "worst oracle-vs-ref rel", worst, "grad_cond median", float(np.median(outd["grad_cond"])),
+              "max", float(outd["grad_cond"].max()))
+    finally:
+        torch.set_grad_enabled(False)
+
+
 GENERATORS = {}
+GENERATORS.update({k: gen_q2l_train for k in Q2L_TRAIN_CASES})
 GENERATORS.update({k: gen_mstct_train for k in MSTCT_TRAIN_CASES})
 GENERATORS.update({k: gen_tenco for k in TENCO_CASES})
 GENERATORS.update({k: gen_cnn for k in CNN_CASES})

@@ -52,7 +52,7 @@ def test_softmax_layernorm_gelu_dwconv_backward_vs_autograd(cuda):
     ds = ops.softmax_bwd_rows_(pd, gp.to(cuda).clone(), 0.3)
     assert (ds.cpu() - st.grad).abs().max() < 1e-6
     # LayerNorm backward (recomputed statistics, accumulated dgamma / dbeta, dx accumulate)
-    for M, C in ((77, 96), (300, 864), (5, 32)):
+    for M, C in ((77, 96), (300, 864), (5, 32), (40, 1536), (33, 3072)):
         x, g, bta, dy = _rand((M, C), 13, 2.0), _rand((C,), 14) + 1.5, _rand((C,), 15), _rand((M, C), 16)
         xt, gt, bt = x.clone().requires_grad_(), g.clone().requires_grad_(), bta.clone().requires_grad_()
         F.layer_norm(xt, (C,), gt, bt, 1e-5).backward(dy)
