@@ -2,8 +2,8 @@
 # The four-stage recipe of the reference's Scripts/train_fold1.sh (lines 12-28), flag for flag, on MI355X:
 #   Swin + Q2L teacher (one task) -> its frame features -> MS-TCT teacher -> its features + raw predictions ->
 #   ResNet-18 student (hard + soft + feature distillation) -> its frame features -> TCN student.
-# NGPU>1 runs the data-parallel stages under torchrun (one process per GPU, RCCL).  Stages whose TRAINING is not built here stop
-# the script with a message that names the reference lines; every extraction / evaluation stage and the two student trainings run.
+# NGPU>1 runs the data-parallel stages under torchrun (one process per GPU, RCCL).  All four trainings and every extraction /
+# evaluation stage run here; SKIP_TEACHER_TRAIN=1 starts from existing teacher checkpoints instead.
 set -euo pipefail
 GPU=${GPU:-0}; KFOLD=${KFOLD:-1}; NGPU=${NGPU:-1}
 VERSION=${VERSION:-SwinL}; TASK=${TASK:-i}; IN_DIM=${IN_DIM:-1536}; IM_SIZE=${IM_SIZE:-384}; BACKBONE=${BACKBONE:-swin_L_${IM_SIZE}_22k}
@@ -15,7 +15,7 @@ launch() { if [ "$NGPU" -gt 1 ]; then python -m torch.distributed.run --nnodes=1
 # Teacher training
 cd "$here/../Spatial_transformer"
 if [ "$SKIP_TEACHER_TRAIN" != 1 ]; then
-python run.py -t -e --img_size ${IM_SIZE} --backbone ${BACKBONE} --hidden_dim ${IN_DIM} --loss_type ${TASK} --dataset_variant=cholect45-crossval --kfold ${KFOLD} --epochs=100 --batch=16 -l 1e-2 5e-3 1e-5 --version=${VERSION} --gpu ${GPU} --val_interval 5 "$@"
+launch run.py -t -e --img_size ${IM_SIZE} --backbone ${BACKBONE} --hidden_dim ${IN_DIM} --loss_type ${TASK} --dataset_variant=cholect45-crossval --kfold ${KFOLD} --epochs=100 --batch=16 -l 1e-2 5e-3 1e-5 --version=${VERSION} --gpu ${GPU} --val_interval 5 "$@"
 fi
 python test.py -e --img_size ${IM_SIZE} --backbone ${BACKBONE} --hidden_dim ${IN_DIM} --loss_type ${TASK} --dataset_variant=cholect45-crossval --kfold ${KFOLD} --epochs=100 --batch=16 -l 1e-2 5e-3 1e-5 --version=${VERSION} --gpu ${GPU} --val_interval 5 "$@"
 cd "$here/../Temporal_mstct"

@@ -213,6 +213,9 @@ def temporal_bench(dev, do_cpu):
         ms = _time_call(lambda: tr.train_step(xt, zl, use_graph=True), iters=10)
         out[f"tenco4_train_T{T}"] = dict(ms_per_step=round(ms, 3), T=T, note="fwd+BCE+bwd+SGD, hipGraph replay, 1 GPU")
     out["mstct_train_b31_T256"] = mstct_train_bench(dev)
+    torch.cuda.empty_cache()
+    out["q2l_train_swinL_384_b16"] = q2l_train_bench(dev)
+    torch.cuda.empty_cache()
     return out
 
 
@@ -232,6 +235,24 @@ def mstct_train_bench(dev):
     gflop = 3 * 31.2 * B     # ~3x the forward: 31.4 GFLOP per window at D = 2048, 31.2 at D = 1536 (D enters the first conv only)
     return dict(ms_per_step=round(ms, 2), ms_per_step_graph=round(ms_g, 2), windows_per_s=round(B / min(ms, ms_g) * 1e3, 1), batch=B, T=T, D=D, dtype="f32",
                 approx_tflops=round(gflop / min(ms, ms_g), 1), note="fwd + BCE(pos_weight) + bwd + SGD, dropout masks drawn outside the timed region, 1 GPU")
+
+
+def q2l_train_bench(dev, backbone="swin_L_384_22k", img=384, hidden=1536, B=16):
+    """BASELINE configs[3]'s spatial half: one training step of the Swin-L + Query2Label teacher on the reference's batch (16 frames at 384 x 384,
+    `Scripts/train_fold1.sh:12`; `Spatial_transformer/run.py:150-229`): forward + BCE(pos_weight) + backward + SGD, fp32, DropPath 0.1 and the
+    transformer's dropout 0.1 on"""
+    from computervision_codes_amd import shapes, synth
+    from computervision_codes_amd.q2l_train import Q2LTrainer
+    tr = Q2LTrainer(backbone, img, hidden, "i", lr=0.01, device=str(dev)).load_state_dict(
+        synth.fill_from_shapes(shapes.q2l_param_shapes(backbone, img, hidden, "i"), seed=47))
+    frames = device_frames(B, img, img, 7, dev)
+    z = (torch.rand(B, 6, device=dev) < 0.3).float()
+    masks = tr.draw_masks_device(B, 1, 0)
+    ms = _time_call(lambda: tr.train_step(frames, z, masks=masks), iters=5)
+    gflop_fwd = {"swin_L_384_22k": 207.8 + 13.6, "swin_B_384_22k": 94.2 + 7.0, "swin_T_224_1k": 9.0 + 1.3}[backbone]   # 2 x MACs: backbone + 1 decoder
+    return dict(ms_per_step=round(ms, 2), frames_per_s=round(B / ms * 1e3, 1), batch=B, img=img, backbone=backbone, dtype="f32",
+                approx_tflops=round(3 * gflop_fwd * B / ms, 1), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                note="fwd + BCE(pos_weight) + bwd + SGD, masks drawn outside the timed region, 1 GPU")
 
 
 def device_frames(n, h, w, seed, dev, nbase=16):

@@ -436,13 +436,108 @@ def _wants_train(argv) -> bool:
     return "-t" in argv or "--train" in argv
 
 
+def spatial_transformer_train(argv=None) -> Dict[str, float]:
+    """`Spatial_transformer/run.py -t` (:150-229, 296-470) for the single-task teachers of the recipe (`Scripts/train_fold1.sh:12`): shuffled
+    frames of all training videos in batches of --batch, the train transform at img_size x img_size (`dataloader.py:154-161`), DropPath and
+    the transformer's dropout drawn per step on the device, SGD without momentum (`run.py:360`), LinearLR warm-up -> ExponentialLR per
+    epoch, validation mAP of the task's head every --val_interval epochs with `_latest.pth` / best `.pth` (`weight_mgt`, :265-277).
+    With torchrun every rank takes its own batch of a step and the flat gradient buffer is all-reduced over RCCL once per step."""
+    import random
+
+    from .q2l_train import Q2LTrainer
+    from .spatial_transformer import build_q2l
+    from .tenco_train import lr_at_epoch
+    from . import shapes, synth
+    p = argparse.ArgumentParser()
+    _common(p)
+    p.add_argument("--backbone", type=str, default="swin_L_384_22k")
+    p.add_argument("--img_size", type=int, default=384)
+    p.add_argument("--hidden_dim", type=int, default=1536)
+    p.add_argument("--augmentation_list", type=str, nargs="*", default=["original", "vflip", "hflip", "contrast", "rot90"])
+    p.add_argument("--epochs", type=int, default=100)
+    p.add_argument("-w", "--warmups", type=int, nargs="+", default=[9, 18, 58])
+    p.add_argument("-l", "--initial_learning_rates", type=float, nargs="+", default=[0.01, 0.01, 0.01])
+    p.add_argument("--weight_decay", type=float, default=1e-5)
+    p.add_argument("--decay_rate", type=float, default=0.99)
+    p.add_argument("--power", type=float, default=0.1)
+    p.add_argument("--val_interval", type=int, default=1)
+    p.add_argument("--pretrain_dir", type=str, default="")
+    p.add_argument("--drop_path_rate", type=float, default=0.1)          # `swin_transformer.py:488`
+    F, _ = p.parse_known_args(argv)
+    if F.loss_type not in ("i", "v", "t"):
+        raise StageNotBuilt("Spatial_transformer/run.py -t --loss_type all: the recipe trains single-task teachers (Scripts/train_fold1.sh:12, "
+                            "--loss_type i | v | t); the four-decoder KD variant of run.py:183-196 is not built.")
+    rank, world = _dist()
+    kfold = F.kfold if "crossval" in F.dataset_variant else 0
+    modelname = f"{F.model}_l{F.dataset_variant}_cholect{kfold}"
+    model_dir = f"./__checkpoint__/run_{F.version}_{F.loss_type}"            # `run.py:87-88`
+    logfile = os.path.join(model_dir, modelname + ".log")
+    ckpt, latest = os.path.join(model_dir, modelname + ".pth"), os.path.join(model_dir, modelname + "_latest.pth")
+    val_interval = F.epochs - 1 if F.val_interval == -1 else F.val_interval
+    tr = Q2LTrainer(F.backbone, F.img_size, F.hidden_dim, F.loss_type, lr=F.initial_learning_rates[2], weight_decay=F.weight_decay,
+                    drop_path_rate=F.drop_path_rate)
+    table = shapes.q2l_param_shapes(F.backbone, F.img_size, F.hidden_dim, F.loss_type)
+    sd = synth.fill_from_shapes(table, seed=F.seed)          # no network for the ImageNet weights of `backbone.py:191-196`: synthetic start
+    for src in (F.pretrain_dir, latest):                     # `load_model` (:280-287): keys present in the model, strict=False
+        if src and os.path.exists(src):
+            sd.update({k: v for k, v in torch.load(src, map_location="cpu").items() if k in sd})
+    tr.load_state_dict(sd)
+    train_videos, val_videos, _ = cholect.split_videos(F.dataset_variant, kfold)
+    labels = {v: cholect.load_labels(F.data_dir, v) for v in train_videos + val_videos}
+    samples = [(v, i) for v in train_videos for i in range(len(labels[v]["ivt"]))]
+    order_rng, aug_rng = random.Random(F.seed), random.Random(F.seed * 1000003 + rank)
+    eval_args = argparse.Namespace(**vars(F))
+    best, last, step_no = 0.0, {}, 0
+    for epoch in range(F.epochs):
+        tr.lr = lr_at_epoch(epoch, F.initial_learning_rates[2], F.power, F.warmups[2], F.decay_rate)
+        order = list(samples)
+        order_rng.shuffle(order)                             # the same permutation on every rank
+        nb = (len(order) + F.batch - 1) // F.batch
+        steps = (nb + world - 1) // world
+        t0, tot = time.time(), 0.0
+        for s in range(steps):
+            bi = (s * world + rank) % nb
+            batch = order[bi * F.batch:(bi + 1) * F.batch]
+            frames = np.concatenate([load_train_frames_u8(F.data_dir, v, [labels[v]["ivt"][i, 0]], F.img_size, F.img_size, aug_rng,
+                                                          F.augmentation_list) for v, i in batch])
+            lab = torch.from_numpy(np.stack([labels[v][F.loss_type][i, 1:] for v, i in batch]))
+            masks = tr.draw_masks_device(len(batch), F.seed * 1000003 + rank, step_no)
+            tot += tr.train_step(torch.from_numpy(frames).cuda(), lab, masks)
+            step_no += 1
+        last = {"loss": tot / steps, "lr": tr.lr}
+        if rank == 0:
+            _log(logfile, f"Traning | lr: {tr.lr:.6f} | epoch {epoch} | loss {tot / steps:.4f} | {time.time() - t0:.2f} secs")
+        if epoch % val_interval == 0 and rank == 0:          # `weight_mgt`: latest every validation, best by the task's mAP (:416-421)
+            state = tr.state_dict()
+            torch.save(state, latest)
+            model = build_q2l(eval_args, dtype=torch.float32).eval()
+            model.load_state_dict(state)
+            m = Recognition({"i": 6, "v": 10, "t": 15}[F.loss_type])
+            gi = "ivt".index(F.loss_type)
+            for v in val_videos:
+                lv = labels[v][F.loss_type]
+                for s0 in range(0, len(lv), F.batch):
+                    fr = cholect.load_frames_device(F.data_dir, v, lv[s0:s0 + F.batch, 0], F.img_size, F.img_size)
+                    m.update(lv[s0:s0 + F.batch, 1:], _sigmoid(model(fr)[gi][1]))
+                m.video_end()
+            score = float(m.compute_video_AP()["mAP"]) if val_videos else 0.0
+            last["val_mAP"] = score
+            if score > best or not os.path.exists(ckpt):
+                best = max(best, score)
+                torch.save(state, ckpt)
+                _log(logfile, f">>> Saving checkpoint for epoch {epoch + 1} at {ckpt}, time {time.ctime()} ")
+            _log(logfile, f"\t\t\t\t\t\t\t video-wise | eta {time.time() - t0:.2f} secs | mAP => {F.loss_type}: [{score:.5f}] ")
+        _barrier()
+    return last
+
+
 def spatial_transformer_run(argv=None):
-    """`Spatial_transformer/run.py`: -e alone = the extraction / evaluation pass (`spatial_transformer_test`); -t (teacher training,
-    `run.py:150-229`: window-attention / LayerNorm / GELU backward, DropPath, dropout 0.1) is not built."""
+    """`Spatial_transformer/run.py`: -t trains the single-task teacher (`spatial_transformer_train`), -e alone = the extraction /
+    evaluation pass (`spatial_transformer_test`)."""
     if _wants_train(argv):
-        raise StageNotBuilt("Spatial_transformer/run.py -t: training of the Swin + Query2Label teacher (reference Spatial_transformer/run.py:150-229) "
-                            "is not built on MI355X yet.  Put a trained teacher checkpoint under ./__checkpoint__/run_<version>[_<task>]/ and "
-                            "re-run with SKIP_TEACHER_TRAIN=1 (Scripts/train_fold1.sh), or run test.py -e directly.")
+        last = spatial_transformer_train(argv)
+        if "-e" not in (sys.argv[1:] if argv is None else argv) and "--test" not in (sys.argv[1:] if argv is None else argv):
+            return last
     return spatial_transformer_test(argv)
 
 

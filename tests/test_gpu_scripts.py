@@ -240,3 +240,31 @@ def test_mstct_train_driver_runs_and_feeds_test_py(cuda, tmp_path):
     assert log.count("Traning | lr:") == 2
     mp = pickle.load(open(tree / "0-5fold" / "data_feats" / "run_X_MSTCT" / "k1_v_pred.pkl", "rb"))
     assert len(mp) == len(vids) and mp[vids[0][-2:]].shape == (20, 10)
+
+
+def test_q2l_teacher_train_driver_runs_and_feeds_test_py(cuda, tmp_path):
+    """`Spatial_transformer/run.py -t -e` (the first line of Scripts/train_fold1.sh's teacher block) with Swin-T at 224: two epochs on the
+    synthetic dataset, `_latest.pth` / best `.pth` in run_<version>_<task>/ with the reference's state-dict keys, validation mAP logged, then
+    the -e pass reads that checkpoint and writes the frame features where Temporal_mstct looks for them"""
+    tree = tmp_path / "MT4MTLKD"
+    shutil.copytree(os.path.join(ROOT, "MT4MTLKD"), tree)
+    data = str(tmp_path / "CholecT45")
+    vids = _make_dataset(data, n_frames=2, h=40, w=56)
+    r = subprocess.run([sys.executable, "run.py", "-t", "-e", "--img_size", "224", "--backbone", "swin_T_224_1k", "--hidden_dim", "768", "--loss_type", "t",
+                        "--epochs", "2", "--batch", "16", "-l", "1e-2", "5e-3", "1e-5", "--version", "T", "--val_interval", "1", "--data_dir", data,
+                        "--kfold", "1"],
+                       cwd=tree / "Spatial_transformer", env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = tree / "Spatial_transformer" / "__checkpoint__" / "run_T_t"
+    table = shapes.q2l_param_shapes("swin_T_224_1k", 224, 768, "t")
+    for name in ("rendezvous_lcholect45-crossval_cholect1_latest.pth", "rendezvous_lcholect45-crossval_cholect1.pth"):
+        sd = torch.load(d / name, map_location="cpu")
+        assert list(sd.keys()) == [k for k, _ in table] and all(tuple(sd[k].shape) == tuple(s) for k, s in table)
+        assert all(torch.isfinite(v).all() for v in sd.values())
+    sd0 = synth.fill_from_shapes(table, seed=47)
+    k = "backbone.0.layers.2.blocks.3.attn.relative_position_bias_table"
+    assert not torch.equal(sd[k], sd0[k])
+    log = open(d / "rendezvous_lcholect45-crossval_cholect1.log").read()
+    assert log.count("Traning | lr:") == 2 and "mAP => t:" in log
+    feats = pickle.load(open(tree / "0-5fold" / "data_feats" / "run_T" / "k1_t_feats.pkl", "rb"))
+    assert list(feats) == [v[3:] for v in vids] and feats["79"].shape == (2, 768) and np.isfinite(feats["79"]).all()

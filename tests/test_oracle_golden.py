@@ -182,3 +182,27 @@ def test_mstct_train_oracle_matches_reference_step(name):
             ref = torch.from_numpy(z[key])
             ulp = 2.0 ** -22 * sd[kname].abs().max().item()
             assert (flat[:: max(1, flat.numel() // 2048)] - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + ulp, kname
+
+
+def test_q2l_train_oracle_matches_reference_step():
+    """one Spatial_transformer single-task step (`run.py:150-229`, random modules neutral) vs the fixture captured from the reference
+    Qeruy2Label + torch autograd + SGD"""
+    from oracle import q2l_train as o_qt
+    z, cfg = load_golden("q2l_train_swinT_i")
+    table = shapes.q2l_param_shapes(cfg["backbone"], cfg["img"], cfg["hidden"], cfg["loss_type"])
+    sd = synth.fill_from_shapes(table, seed=cfg["seed"])
+    img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["img"], cfg["img"], seed=cfg["seed"]))
+    k = {"i": 6, "v": 10, "t": 15}[cfg["loss_type"]]
+    y = torch.from_numpy((synth.uniform01(cfg["seed"], 900, cfg["B"] * k) < 0.3).reshape(cfg["B"], k).astype(np.int64))
+    with torch.enable_grad():
+        new, loss, g = o_qt.train_step(sd, img, y, cfg["backbone"], cfg["img"], cfg["hidden"], cfg["loss_type"], cfg["lr"], 1e-5)
+    assert abs(loss - float(z["loss"])) < 2e-5 * max(1.0, abs(float(z["loss"])))
+    for kname, ref in zip([k_ for k_, _ in table], z["grad_norms"]):
+        assert abs(float(g[kname].norm()) - ref) <= 1e-4 * max(ref, 1e-6 * float(z["grad_norms"].max())), kname
+    for key in z.files:
+        if key.startswith("delta::"):
+            kname = key[len("delta::"):]
+            flat = (new[kname] - sd[kname]).flatten()
+            ref = torch.from_numpy(z[key])
+            ulp = 2.0 ** -22 * sd[kname].abs().max().item()
+            assert (flat[:: max(1, flat.numel() // 2048)] - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + ulp, kname
