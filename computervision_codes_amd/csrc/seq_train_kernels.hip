@@ -376,15 +376,33 @@ __global__ void add_bias_mask_kernel(float* __restrict__ S, const float* __restr
 }
 
 // gradient of the relative-position bias table: dtable[idx[ij]][h] += sum_bw dS[bw][h][ij]   (the gather of swin_transformer.py:127-130
-// transposed; many (i, j) share a table row: float atomics on the small table)
-__global__ void relpos_table_grad_kernel(const float* __restrict__ dS, const int* __restrict__ idx, float* __restrict__ dtable, long long nbw, int H,
-                                         int NN) {
-    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
-    const int h = blockIdx.y;
-    if (ij >= NN) return;
-    float s = 0.f;
-    for (long long bw = blockIdx.z; bw < nbw; bw += gridDim.z) s += dS[(bw * H + h) * NN + ij];
-    atomicAdd(dtable + (long long)idx[ij] * H + h, s);
+// transposed).  A workgroup owns one head and a run of `per` windows: every thread sums its (i, j) positions over the run in registers
+// (coalesced reads, four windows in flight), folds them into an LDS copy of the head's table column (ds_add_f32; many (i, j) share a row) and
+// the workgroup adds that column to the table once -- (2ws-1)^2 global atomics per workgroup instead of one per (i, j).
+__global__ __launch_bounds__(256) void relpos_table_grad_kernel(const float* __restrict__ dS, const int* __restrict__ idx, float* __restrict__ dtable,
+                                                                long long nbw, int H, int NN, int TS, int per) {
+    extern __shared__ float tab[];
+    const int h = blockIdx.x;
+    const long long w0 = (long long)blockIdx.y * per;
+    const long long w1 = w0 + per < nbw ? w0 + per : nbw;
+    for (int t = threadIdx.x; t < TS; t += 256) tab[t] = 0.f;
+    __syncthreads();
+    const long long st = (long long)H * NN;
+    for (int ij = threadIdx.x; ij < NN; ij += 256) {
+        const float* p = dS + (w0 * H + h) * (long long)NN + ij;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        long long w = w0;
+        for (; w + 4 <= w1; w += 4, p += 4 * st) {
+            s0 += p[0];
+            s1 += p[st];
+            s2 += p[2 * st];
+            s3 += p[3 * st];
+        }
+        for (; w < w1; ++w, p += st) s0 += p[0];
+        atomicAdd(&tab[idx[ij]], (s0 + s1) + (s2 + s3));
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < TS; t += 256) atomicAdd(dtable + (long long)t * H + h, tab[t]);
 }
 
 // y[m][:] = s[m / rows_per_scale] * x[m][:] (+ r[m][:])   -- DropPath (timm, per-sample keep mask / keep_prob) on a residual branch
@@ -459,9 +477,18 @@ extern "C" int mt4_relpos_table_grad_f32(const float* dS, const int32_t* index, 
     mt4_clear_error();
     if (!dS || !index || !dtable || n_windows <= 0 || heads <= 0 || N <= 0 || heads > 65535) return MT4_EINVAL;
     const int NN = N * N;
-    int zs = (int)(n_windows < 16 ? n_windows : 16);
-    hipLaunchKernelGGL(relpos_table_grad_kernel, dim3(cdiv(NN, 256), heads, zs), dim3(256), 0, (hipStream_t)stream, dS, index, dtable, (long long)n_windows,
-                       heads, NN);
+    int ws = 1;
+    while (ws * ws < N) ++ws;
+    if (ws * ws != N) return MT4_EINVAL;
+    const int TS = (2 * ws - 1) * (2 * ws - 1);
+    // ~2 workgroups per CU over heads x window runs; a run of >= 4 windows keeps four loads in flight per thread
+    long long per = (n_windows * heads + 511) / 512;
+    if (per < 4) per = 4;
+    if (per > n_windows) per = n_windows;
+    const long long zs = (n_windows + per - 1) / per;
+    if (zs > 65535) return MT4_EUNSUPPORTED;
+    hipLaunchKernelGGL(relpos_table_grad_kernel, dim3(heads, (unsigned)zs), dim3(256), TS * sizeof(float), (hipStream_t)stream, dS, index, dtable,
+                       (long long)n_windows, heads, NN, TS, (int)per);
     return mt4_check_launch();
 }
 

@@ -82,3 +82,27 @@ def test_mstct_two_rank_step_equals_mean_gradient_step(cuda, tmp_path):
     want = trs[0].state_dict()
     for k in want:
         assert (got[k].float() - want[k].float()).abs().max().item() <= 2e-6 * max(1.0, want[k].float().abs().max().item()), k
+
+
+def test_q2l_two_rank_step_equals_mean_gradient_step(cuda, tmp_path):
+    """uint8 frames, every rank its own DropPath / dropout draw (device counter generator, seed per rank): the two-rank step equals one SGD step
+    on the mean of the two single-rank gradient buffers"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "helpers"))
+    from ddp_q2l_worker import CFG, frames, trainer
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29535", os.path.join(ROOT, "tests", "helpers", "ddp_q2l_worker.py"), str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    got = torch.load(tmp_path / "ddp_q2l.pth", map_location="cpu")
+    trs = []
+    for rank in (0, 1):
+        tr = trainer()
+        img, y = frames(rank)
+        tr.train_step(img.to(cuda), y, masks=tr.draw_masks_device(CFG["B"], 77 + rank, 0), apply_update=False)
+        trs.append(tr)
+    trs[0].G.add_(trs[1].G).mul_(0.5)
+    trs[0].apply_update()
+    want = trs[0].state_dict()
+    for k in want:
+        assert (got[k].float() - want[k].float()).abs().max().item() <= 2e-6 * max(1.0, want[k].float().abs().max().item()), k

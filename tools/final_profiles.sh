@@ -6,7 +6,7 @@ set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out
-mkdir -p $O; rm -rf $O/pmc_fetch $O/pmc_write $O/prof_final $O/pmc_mfma $O/prof_tenco_f32 $O/prof_tenco_bf16 $O/pmc_tenco_FETCH_SIZE $O/pmc_tenco_WRITE_SIZE $O/prof_mstct_train
+mkdir -p $O; rm -rf $O/pmc_fetch $O/pmc_write $O/prof_final $O/pmc_mfma $O/prof_tenco_f32 $O/prof_tenco_bf16 $O/pmc_tenco_FETCH_SIZE $O/pmc_tenco_WRITE_SIZE $O/prof_mstct_train $O/prof_q2l_train
 cd $R
 timeout -k 10 900 python bench.py --per-layer gpurun_out/layers_final.json > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
 echo bench done
@@ -28,6 +28,9 @@ done
 echo tenco done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_mstct_train -o mt -- python3 $R/tools/mstct_train_prof.py > $O/prof_mstct_train.log 2>&1
 echo mstct done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_q2l_train -o q2l -- python3 $R/tools/q2l_train_prof.py > $O/prof_q2l_train.log 2>&1
+rm -f $O/prof_q2l_train/*kernel_trace.csv
+echo q2l done
 cd $R
 cp profiles/traffic.json gpurun_out/traffic.json; cp profiles/mfma_util.json gpurun_out/mfma_util.json
 python tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 54 resnet50_bf16_b1336_224x224 gpurun_out/traffic.json
