@@ -383,6 +383,25 @@ def linear_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -
     return y
 
 
+def bottleneck_fused(x: torch.Tensor, conv1, conv2, conv3, ds=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """one stride-1 ResNet Bottleneck of 64 mid channels in one launch (`mt4_bottleneck_fused_bf16`): x [B,H,W,Cin] bf16 NHWC; conv1 / conv2 /
+    conv3 / ds = (packed weight with the BatchNorm scale folded in, float32 bias); ds None = identity residual (Cin 256), else Cin 64"""
+    (w1, b1), (w2, b2), (w3, b3) = conv1, conv2, conv3
+    wd, bd = ds if ds is not None else (None, None)
+    _need_cuda(x, w1, b1, w2, b2, w3, b3, wd, bd, out)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
+    b, h, w, cin = x.shape
+    assert w1.dtype == w2.dtype == w3.dtype == torch.bfloat16 and tuple(w1.shape) == (64, packed_k(cin, 1, 1, torch.bfloat16)) and \
+        tuple(w2.shape) == (64, packed_k(64, 3, 3, torch.bfloat16)) and tuple(w3.shape) == (256, packed_k(64, 1, 1, torch.bfloat16))
+    assert wd is None or tuple(wd.shape) == (256, packed_k(cin, 1, 1, torch.bfloat16))
+    y = torch.empty((b, h, w, 256), dtype=torch.bfloat16, device=x.device) if out is None else out
+    assert y.is_contiguous() and tuple(y.shape) == (b, h, w, 256) and y.dtype == torch.bfloat16
+    check(lib.mt4_bottleneck_fused_bf16(x.data_ptr(), y.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
+                                        b3.data_ptr(), wd.data_ptr() if wd is not None else None, bd.data_ptr() if bd is not None else None,
+                                        b, h, w, cin, 64, _stream()), "mt4_bottleneck_fused_bf16")
+    return y
+
+
 # ----------------------------------------------------------------------------------------- transformer-stage pieces
 def linear(x2d: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, act: Optional[str] = None,
            residual: Optional[torch.Tensor] = None, out_row_map: Optional[torch.Tensor] = None,

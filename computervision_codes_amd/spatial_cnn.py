@@ -45,6 +45,8 @@ class VideoNas:
         # 4 x [residual, staging, store, second GEMM]) leave nothing to overlap with; the saved re-read (1.6 MB per frame and pair) does
         # not pay for that.  Off by default; kept for the A/B and as the starting point of a smaller-tile variant.
         self.fuse_next_conv = False
+        import os
+        self.fuse_bottleneck = not os.environ.get("MT4_NO_BNECK_FUSE")   # layer1 Bottlenecks in one launch each (bf16 ResNet-50)
 
     def eval(self):
         self.training = False
@@ -137,6 +139,10 @@ class VideoNas:
                 q = f"{pre}layer{li}.{bi}."
                 s = 2 if (bi == 0 and li > 1) else 1
                 o_buf = out if (li == last and bi == n - 1) else None
+                if (bottleneck and li == 1 and self.fuse_bottleneck and self.dtype == torch.bfloat16 and pending is None):
+                    # conv1 -> conv2 -> conv3 (+ downsample) of a 64-channel stride-1 block in one launch, intermediates in LDS (bit-identical)
+                    x = ops.bottleneck_fused(x, self._p[q + "conv1"], self._p[q + "conv2"], self._p[q + "conv3"], self._p.get(q + "ds"), out=o_buf)
+                    continue
                 idt = self._conv(x, q + "ds", 1, stride=s, relu=False) if (q + "ds") in self._p else x
                 if bottleneck:  # resnet.py:101-121 (stride on the 3x3)
                     o = pending if pending is not None else self._conv(x, q + "conv1", 1)

@@ -269,3 +269,28 @@ def test_conv_fused_following_1x1_is_bit_identical(cuda, c2, relu2, res):
         t = ops.conv_nhwc(y, w1, b1, kh=1, kw=1, relu=relu2)
         yf, tf = ops.conv_nhwc(x, w3, b3, kh=1, kw=1, residual=r, relu=True, fuse_next=(w1, b1, relu2))
         assert torch.equal(yf, y) and torch.equal(tf, t), (cin, (yf.float() - y.float()).abs().max().item(), (tf.float() - t.float()).abs().max().item())
+
+
+@pytest.mark.parametrize("b,h,w", [(3, 56, 56), (2, 16, 24), (1, 9, 15), (2, 8, 14), (1, 1, 1)])
+@pytest.mark.parametrize("ds", [False, True])
+def test_bottleneck_fused_bit_identical_to_three_launches(cuda, b, h, w, ds):
+    """`mt4_bottleneck_fused_bf16` (layer1 of ResNet-50 in one launch, intermediates in LDS) == conv1 -> conv2 -> conv3 (+ downsample) through
+    `mt4_conv_nhwc`, bit for bit: full tiles, ragged edge tiles, images smaller than a tile"""
+    from computervision_codes_amd import ops
+    bf = torch.bfloat16
+    cin = 64 if ds else 256
+    g = torch.Generator().manual_seed(7 + h)
+    x = torch.randn((b, h, w, cin), generator=g).to(cuda).to(bf)
+
+    def mk(cout, ci, k, s):
+        wt = (torch.randn((cout, ci, k, k), generator=g) * s).to(cuda)
+        return ops.pack_conv_weight(wt, None, bf), (torch.randn(cout, generator=g) * 0.3).to(cuda)
+    c1, c2, c3 = mk(64, cin, 1, cin ** -0.5), mk(64, 64, 3, 1 / 24), mk(256, 64, 1, 1 / 8)
+    cd = mk(256, cin, 1, cin ** -0.5) if ds else None
+    idt = ops.conv_nhwc(x, cd[0], cd[1], kh=1, kw=1, relu=False) if ds else x
+    o = ops.conv_nhwc(x, c1[0], c1[1], kh=1, kw=1, relu=True)
+    o = ops.conv_nhwc(o, c2[0], c2[1], kh=3, kw=3, pad=(1, 1), relu=True)
+    ref = ops.conv_nhwc(o, c3[0], c3[1], kh=1, kw=1, residual=idt, relu=True)
+    y = ops.bottleneck_fused(x, c1, c2, c3, cd)
+    assert float(ref.float().abs().max()) > 0.5
+    assert torch.equal(y.view(torch.int16), ref.view(torch.int16)), float((y.float() - ref.float()).abs().max())
