@@ -58,8 +58,8 @@ def conv_flops_per_frame(model, h, w):
 
 
 def time_conv_kernels(model, frames, iters=3):
-    """Average duration of the implicit-GEMM conv launches of one step, measured with HIP events recorded on
-    the stream the kernels are launched on (torch's current stream), one event pair per launch."""
+    """Average duration of the conv launches of one step (implicit-GEMM kernels and the fused layer1 Bottlenecks), measured with HIP events
+    recorded on the stream the kernels are launched on (torch's current stream), one event pair per launch."""
     from computervision_codes_amd import ops
     pairs = []
     orig = ops.conv_nhwc
@@ -73,7 +73,19 @@ def time_conv_kernels(model, frames, iters=3):
         pairs.append((e0, e1))
         return y
 
+    orig_b = ops.bottleneck_fused
+
+    def timed_b(*a, **k):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig_b(*a, **k)
+        e1.record()
+        pairs.append((e0, e1))
+        return y
+
     ops.conv_nhwc = timed
+    ops.bottleneck_fused = timed_b
     try:
         per_iter = []
         for _ in range(iters):
@@ -83,6 +95,7 @@ def time_conv_kernels(model, frames, iters=3):
             per_iter.append([a.elapsed_time(b) for a, b in pairs])
     finally:
         ops.conv_nhwc = orig
+        ops.bottleneck_fused = orig_b
     n = len(per_iter[0])
     per_launch_ms = [min(it[i] for it in per_iter) for i in range(n)]
     return per_launch_ms
@@ -594,16 +607,19 @@ def main():
                 mfma_util = rec["mfma_util"] if rec else None
             except Exception:
                 mfma_util = None
-        roofline = dict(bound="mfma", kernel="mt4_conv_nhwc launches of one step (igemm_conv_kernel, conv3x3_patch_kernel, stem_patch_kernel)", achieved=round(achieved, 2),
+        roofline = dict(bound="mfma", kernel="conv launches of one step (igemm_conv_kernel, conv3x3_patch_kernel, stem_patch_kernel, bottleneck64_fused_kernel)", achieved=round(achieved, 2),
                         peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic, mfma_util_pmc=mfma_util,
                         launches_per_step=len(per_launch), conv_ms_per_step=round(conv_ms, 4),
                         gflop_per_frame=round(flops_frame / 1e9, 3), traffic_unit="HBM bytes per step (all conv launches)",
                         note="launch durations from a single-stream pass over one stream's part of the step (HIP events on the launch stream)")
         if a.per_layer:
             plan = model.conv_plan(a.height, a.width)
+            groups = model.launch_groups(a.height, a.width)
+            assert len(groups) + 1 == len(per_launch), (len(groups), len(per_launch))   # (the last launch is the heads GEMM)
             rows = []
-            for rec, ms in zip(plan, per_launch):
-                fl = 2 * a.batch * rec["Ho"] * rec["Wo"] * rec["Cout"] * rec["Cin"] * rec["kh"] * rec["kw"]
+            for g, ms in zip(groups, per_launch):
+                fl = sum(2 * a.batch * plan[i]["Ho"] * plan[i]["Wo"] * plan[i]["Cout"] * plan[i]["Cin"] * plan[i]["kh"] * plan[i]["kw"] for i in g)
+                rec = dict(plan[g[0]]) if len(g) == 1 else dict(name=plan[g[0]]["name"].rsplit(".", 1)[0] + " (one launch)", fused=[plan[i]["name"] for i in g])
                 rows.append(dict(rec, ms=round(ms, 4), tflops=round(fl / (ms * 1e-3) / 1e12, 1)))
             os.makedirs(os.path.dirname(os.path.abspath(a.per_layer)), exist_ok=True)
             json.dump(rows, open(a.per_layer, "w"), indent=1)

@@ -41,7 +41,6 @@ struct BneckK {
     int B, H, W, tiles_h, tiles_w;
     int w1_row, w2_row, w3_row, wds_row;     // bytes per packed weight row
     int nt;                                  // non-temporal output stores
-    int variant;                             // timing-only experiments (MT4_BNECK_VARIANT): results are wrong when non-zero
 };
 
 __device__ __forceinline__ f32x4 bias4(const float* b, int n) {
@@ -108,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             stg[i] = make_uint4(0, 0, 0, 0);
-            if (xoff[i] >= 0 && !(a.variant & 1)) stg[i] = *(const uint4*)(ximg + xoff[i] + kc * 128);
+            if (xoff[i] >= 0) stg[i] = *(const uint4*)(ximg + xoff[i] + kc * 128);
         }
     };
     auto store_chunk = [&](int buf, const uint4 (&stg)[5]) {
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
     const int ch1 = wave * 16;                       // this wave's 16 channels of t1 / t2
     uint4 wf1[KC * 2];
     {
-        const char* wr = (a.variant & 2) ? a.w1 : a.w1 + (long long)(ch1 + r16) * a.w1_row + q * 16;
+        const char* wr = a.w1 + (long long)(ch1 + r16) * a.w1_row + q * 16;
 #pragma unroll
         for (int s = 0; s < KC * 2; ++s) wf1[s] = *(const uint4*)(wr + s * 64);
     }
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
     // weights of conv2 and the residual pixels go in flight now; they are consumed after the t1 hand-off
     uint4 wf2[18];
     {
-        const char* wr = (a.variant & 2) ? a.w2 : a.w2 + (long long)(ch1 + r16) * a.w2_row + q * 16;
+        const char* wr = a.w2 + (long long)(ch1 + r16) * a.w2_row + q * 16;
 #pragma unroll
         for (int s = 0; s < 18; ++s) wf2[s] = *(const uint4*)(wr + s * 64);
     }
@@ -171,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 res[i][j] = make_uint2(0, 0);
-                if (col_ok && h0 + j < a.H && !(a.variant & 8))
+                if (col_ok && h0 + j < a.H)
                     res[i][j] = *(const uint2*)(ximg + (unsigned)((h0 + j) * a.W * 512) + (roff + i * 128));
             }
     }
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
     uint4 wf3[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const char* wr = (a.variant & 2) ? a.w3 : a.w3 + (long long)((4 * i + wave) * 16 + r16) * a.w3_row + q * 16;
+        const char* wr = a.w3 + (long long)((4 * i + wave) * 16 + r16) * a.w3_row + q * 16;
         wf3[i][0] = *(const uint4*)wr;
         wf3[i][1] = *(const uint4*)(wr + 64);
     }
@@ -298,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
         {
             const int w = w0 + st_tx;
             const int rd_off = st_tx * 256 + ((st_chunk ^ st_tx) << 4);
-            if (st_tx < TW && w < a.W && !(a.variant & 4)) {
+            if (st_tx < TW && w < a.W) {
 #pragma unroll
                 for (int ty = 0; ty < 8; ++ty) {
                     if (h0 + ty < a.H) {
@@ -314,6 +313,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
     }
 }
 
+// A persistent form of this kernel (one workgroup of 8 waves per CU walking tiles, the next tile's whole x halo fetched by LDS-DMA while the
+// current tile computes, conv1 / conv2 weights resident in registers) was built and measured: bit-identical, but SLOWER -- 2.4-2.7 ms per
+// 1336-frame block against 1.47 ms here (compute alone 1.1-1.3 ms against 0.74 ms: eight waves meeting at ten barriers per tile leave the CU
+// idle where two independent workgroups fill each other's stalls; and at 256 registers every spill reload in front of a DMA or store costs a
+// vmcnt(0)).
 template <int CIN, bool DS>
 int launch(const BneckK& a, hipStream_t stream) {
     constexpr int NXS = CIN > 64 ? 2 : 1;
@@ -350,7 +354,6 @@ extern "C" int mt4_bottleneck_fused_bf16(const void* x, void* y, const void* w1,
     a.w3_row = (int)mt4_conv_packed_k(64, 1, 1, MT4_BF16) * 2;
     a.wds_row = a.w1_row;
     a.nt = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
-    a.variant = getenv("MT4_BNECK_VARIANT") ? atoi(getenv("MT4_BNECK_VARIANT")) : 0;
     if ((long long)B * a.tiles_h * a.tiles_w > 0x7fffffffLL) return MT4_EUNSUPPORTED;
     return wds ? launch<64, true>(a, (hipStream_t)stream) : launch<256, false>(a, (hipStream_t)stream);
 }

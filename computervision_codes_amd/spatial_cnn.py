@@ -198,6 +198,26 @@ class VideoNas:
                 cin, hh, ww = cout, h2, w2
         return plan
 
+    def launch_groups(self, h: int, w: int):
+        """indices into `conv_plan(h, w)` per kernel launch of one forward, in launch order: one conv per launch, except the layer1 Bottlenecks of
+        the bf16 ResNet-50, which run as one `mt4_bottleneck_fused_bf16` launch each"""
+        plan = self.conv_plan(h, w)
+        fused = self.network == "resnet50" and self.fuse_bottleneck and self.dtype == torch.bfloat16
+        groups, i = [], 0
+        while i < len(plan):
+            name = plan[i]["name"]
+            if fused and name.startswith("layer1."):
+                blk = name.split(".")[1]
+                j = i
+                while j < len(plan) and plan[j]["name"].startswith(f"layer1.{blk}."):
+                    j += 1
+                groups.append(list(range(i, j)))
+                i = j
+            else:
+                groups.append([i])
+                i += 1
+        return groups
+
     def _finish(self, feat: torch.Tensor):
         b = feat.shape[0]
         logits = ops.conv_nhwc(feat.view(b, 1, 1, -1), self._p["heads.w"], self._p["heads.b"], kh=1, kw=1).view(b, -1)

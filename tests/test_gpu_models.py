@@ -176,11 +176,38 @@ def test_spatial_cnn_fused_conv3_conv1_is_bit_identical(cuda):
     m = _cnn_model(cfg, torch.bfloat16)
     for (n, h, w) in ((5, 224, 224), (3, 256, 448), (2, 64, 96)):
         frames = synth.synthetic_frames(n, h, w, seed=13).to(cuda)
+        m.fuse_bottleneck = False                         # (this fusion acts on the one-launch-per-conv layer1)
         m.fuse_next_conv = True
         a = m.extract_u8(frames)
         m.fuse_next_conv = False
         b = m.extract_u8(frames)
         assert torch.equal(a[3][0], b[3][0]) and all(torch.equal(a[i][1], b[i][1]) for i in range(4)), (n, h, w)
+
+
+def test_spatial_cnn_fused_layer1_bottlenecks_are_bit_identical(cuda):
+    """ResNet-50 bf16 (the default path): every layer1 Bottleneck is ONE launch (`mt4_bottleneck_fused_bf16`: conv1 + conv2 + conv3 (+ downsample),
+    intermediates in LDS); features and logits equal the one-launch-per-conv path bit for bit at 224x224, the reference's 256x448 and a small
+    ragged size; the launch grouping bench.py accounts with matches what runs"""
+    from computervision_codes_amd import ops
+    _, cfg = load_golden("cnn_resnet50_224")
+    m = _cnn_model(cfg, torch.bfloat16)
+    assert m.fuse_bottleneck
+    for (n, h, w) in ((5, 224, 224), (3, 256, 448), (2, 64, 96), (1, 36, 60)):
+        frames = synth.synthetic_frames(n, h, w, seed=13).to(cuda)
+        calls = []
+        orig = ops.bottleneck_fused
+        ops.bottleneck_fused = lambda *a_, **k_: (calls.append(1), orig(*a_, **k_))[1]
+        try:
+            a = m.extract_u8(frames)
+        finally:
+            ops.bottleneck_fused = orig
+        assert len(calls) == 3
+        m.fuse_bottleneck = False
+        b = m.extract_u8(frames)
+        m.fuse_bottleneck = True
+        assert torch.equal(a[3][0], b[3][0]) and all(torch.equal(a[i][1], b[i][1]) for i in range(4)), (n, h, w)
+    groups = m.launch_groups(224, 224)
+    assert len(groups) == 46 and [len(g) for g in groups[1:4]] == [4, 3, 3] and sum(len(g) for g in groups) == 53   # (+ the heads GEMM = 47 launches)
 
 
 def test_spatial_cnn_batch_independence(cuda):
