@@ -436,6 +436,11 @@ def _wants_train(argv) -> bool:
     return "-t" in argv or "--train" in argv
 
 
+# `Spatial_transformer/models/backbone.py:31-41` (get_model_path)
+SWIN_PRETRAIN_FILES = {"swin_L_384_22k": "swin_large_patch4_window12_384_22k.pth", "swin_B_384_22k": "swin_base_patch4_window12_384_22k.pth",
+                       "swin_T_224_1k": "swin_tiny_patch4_window7_224.pth"}
+
+
 def spatial_transformer_train(argv=None) -> Dict[str, float]:
     """`Spatial_transformer/run.py -t` (:150-229, 296-470) for the single-task teachers of the recipe (`Scripts/train_fold1.sh:12`): shuffled
     frames of all training videos in batches of --batch, the train transform at img_size x img_size (`dataloader.py:154-161`), DropPath and
@@ -477,7 +482,16 @@ def spatial_transformer_train(argv=None) -> Dict[str, float]:
     tr = Q2LTrainer(F.backbone, F.img_size, F.hidden_dim, F.loss_type, lr=F.initial_learning_rates[2], weight_decay=F.weight_decay,
                     drop_path_rate=F.drop_path_rate)
     table = shapes.q2l_param_shapes(F.backbone, F.img_size, F.hidden_dim, F.loss_type)
-    sd = synth.fill_from_shapes(table, seed=F.seed)          # no network for the ImageNet weights of `backbone.py:191-196`: synthetic start
+    sd = synth.fill_from_shapes(table, seed=F.seed)          # deterministic synthetic start when no pretrained file is on disk
+    # `build_backbone` (`backbone.py:188-196`): the upstream Swin checkpoint ../Pretrain/<file> ('model' entry, `head.*` dropped) into the backbone
+    swin_file = os.path.join("..", "Pretrain", SWIN_PRETRAIN_FILES.get(F.backbone, ""))
+    if os.path.isfile(swin_file):
+        up = torch.load(swin_file, map_location="cpu")
+        up = up.get("model", up)
+        hit = {"backbone.0." + k: v for k, v in up.items() if "head" not in k and ("backbone.0." + k) in sd and tuple(v.shape) == tuple(sd["backbone.0." + k].shape)}
+        sd.update(hit)
+        if rank == 0:
+            _log(logfile, f"backbone: {len(hit)} tensors from {swin_file}")
     for src in (F.pretrain_dir, latest):                     # `load_model` (:280-287): keys present in the model, strict=False
         if src and os.path.exists(src):
             sd.update({k: v for k, v in torch.load(src, map_location="cpu").items() if k in sd})

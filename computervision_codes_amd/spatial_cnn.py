@@ -48,6 +48,21 @@ class VideoNas:
         import os
         self.fuse_bottleneck = not os.environ.get("MT4_NO_BNECK_FUSE")   # layer1 Bottlenecks in one launch each (bf16 ResNet-50)
 
+    def train(self, mode: bool = True):
+        self.training = bool(mode)
+        return self
+
+    def _train_engine(self):
+        """the forward of train mode lives in `SpatialCnnTrainer` (batch-statistics BatchNorm kernels, KD branch); built on first use from
+        this module's parameters"""
+        if getattr(self, "_trainer", None) is None:
+            from .spatial_cnn_train import SpatialCnnTrainer
+            self._trainer = SpatialCnnTrainer(self.network, teacher_dim=int(getattr(self.args, "teacher_dim", 1536)), loss_type=self.loss_type,
+                                              device=str(self.device))
+            self._trainer.exchange = False
+            self._trainer.load_state_dict(self.state_dict())
+        return self._trainer
+
     def eval(self):
         self.training = False
         return self
@@ -68,6 +83,7 @@ class VideoNas:
                 if tuple(sd[k].shape) != tuple(shp):
                     raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != {shp}")
                 self._sd[k] = sd[k].detach()
+        self._trainer = None          # (the train-mode engine is rebuilt from the new parameters on first use)
         self._pack()
         return self
 
@@ -112,6 +128,9 @@ class VideoNas:
         # the heads run as one fp32 GEMM (exact fp32 MFMA) through the 1x1 mode of the conv kernel
         p["heads.w"] = ops.pack_conv_weight(torch.cat(ws, 0).to(self.device)[:, :, None, None], None, torch.float32)
         p["heads.b"] = torch.cat(bs, 0).to(self.device).contiguous()
+        if self.loss_type == "all":   # KD adaptors (`network.py:27-33`), fp32 like the heads
+            for n in ("wi", "wv", "wt", "mi", "mv", "mt"):
+                p[n] = (ops.pack_linear_weight(self._sd[n + ".weight"].float().to(self.device), torch.float32), self._sd[n + ".bias"].float().to(self.device).contiguous())
         self._p = p
 
     # ------------------------------------------------------------------ trunk
@@ -232,12 +251,27 @@ class VideoNas:
 
     def forward(self, inputs: torch.Tensor, tool=None, verb=None, target=None):
         """inputs: normalised float32 NCHW [B,3,H,W] on the GPU (the reference's module boundary)."""
-        if self.training or getattr(self.args, "train", False):
-            raise NotImplementedError("training / KD branch (network.py:47-71) is not part of the extraction path yet")
         if not self._p:
             raise RuntimeError("load_state_dict first")
+        kd = self.loss_type == "all" and getattr(self.args, "train", False)     # `network.py:47`: gated by args.train, not by the module mode
+        if kd and (tool is None or verb is None or target is None):
+            raise TypeError("args.train with loss_type 'all' runs the KD branch (network.py:47-71): pass tool, verb, target features")
+        if self.training:
+            # `model.train(); model(img, feat_i, feat_v, feat_t)` (`run.py:152-157`): BatchNorm on batch statistics.  fp32, through the trainer's
+            # forward kernels; running statistics advance and are written back to this module
+            tr = self._train_engine()
+            out = tr.forward_train(inputs, (tool, verb, target) if kd else None)
+            self._sd.update(tr.running_stats())
+            self._pack()
+            return out
         _, _, h, w = inputs.shape
-        return self._finish(self.trunk_from_padded(ops.pad_nchw(inputs, self.dtype), h, w))
+        out = self._finish(self.trunk_from_padded(ops.pad_nchw(inputs, self.dtype), h, w))
+        if kd:   # the validation loop of `run.py:231-256` calls the module in eval mode with the teacher features: the branch still runs
+            feat = out[3][0]
+            teas = [ops.linear(t.to(feat.device, torch.float32).contiguous(), *self._p[m]) for m, t in zip(("mi", "mv", "mt"), (tool, verb, target))]
+            cams = [ops.linear(mx, *self._p[w_]) for mx, w_ in zip(ops.kd_mix(feat, *teas), ("wi", "wv", "wt"))]
+            out = tuple((c, o[1]) for c, o in zip(cams, out[:3])) + (out[3],)
+        return out
 
     __call__ = forward
 

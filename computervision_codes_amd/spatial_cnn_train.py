@@ -182,6 +182,14 @@ class SpatialCnnTrainer:
                             u.phase_w[(ph, pw)][0].copy_(packed)
         # (the linear layers' data gradients transpose their small weights on the fly in _linear_bwd)
 
+    def running_stats(self) -> Dict[str, torch.Tensor]:
+        """the BatchNorm buffers only (what a train-mode forward changes)"""
+        out = {}
+        for u in self.units.values():
+            out[u.bn + ".running_mean"], out[u.bn + ".running_var"] = u.rmean.clone().cpu(), u.rvar.clone().cpu()
+            out[u.bn + ".num_batches_tracked"] = torch.tensor(self.nbt[u.bn], dtype=torch.int64)
+        return out
+
     def state_dict(self) -> Dict[str, torch.Tensor]:
         out = dict(self._extra)
         for u in self.units.values():
@@ -230,7 +238,8 @@ class SpatialCnnTrainer:
         z2 = z.view(-1, c)
         mean, invstd = ops.bn_stats(z2, u.rmean, u.rvar, sums=u.sums_f)
         a = ops.bn_apply(z2, mean, invstd, u.gamma, u.beta, residual.view(-1, c) if residual is not None else None, relu).view(b, ho, wo, c)
-        saved.append((u, x, z, mean, invstd, a, relu))
+        if saved is not None:
+            saved.append((u, x, z, mean, invstd, a, relu))
         return a
 
     def _dgrad(self, u: _Unit, dz, x_shape, residual=None):
@@ -329,6 +338,48 @@ class SpatialCnnTrainer:
         if apply_update:
             self.apply_update()
         return terms
+
+    def forward_train(self, frames, teacher_feats=None):
+        """The reference module call under `model.train()` (`Spatial_cnn/network.py:43-92`): BatchNorm on batch statistics (running statistics and
+        num_batches_tracked advance, as in torch), the KD branch when teacher features are given (`loss_type all` and `args.train`, `network.py:47`).  frames uint8 NHWC or normalised float32 NCHW on the
+        GPU; teacher_feats = (feat_i, feat_v, feat_t) [B, teacher_dim].  Returns ((kd_i | 0, logit_i), (kd_v | 0, logit_v), (kd_t | 0, logit_t),
+        (feat, logit_ivt)) with zeros for heads the model does not have (`network.py:79-82`).  Forward only: gradients come from `train_step`."""
+        from .synth import IMAGENET_MEAN, IMAGENET_STD
+        if frames.dtype == torch.uint8:
+            xp = ops.preprocess_u8(frames, IMAGENET_MEAN, IMAGENET_STD, F32)
+        else:
+            xp = ops.pad_nchw(frames, F32)
+        B = frames.shape[0]
+        self._arena.zero_()
+        pre, U = "basemodel.basemodel.", self.units
+        x = ops.maxpool3x3s2(self._fwd_unit(U[pre + "conv1"], xp))
+        bott = self.network == "resnet50"
+        for li, n in enumerate(_DEPTHS[self.network], start=1):
+            for bi in range(n):
+                q = f"{pre}layer{li}.{bi}."
+                idt = self._fwd_unit(U[q + "downsample.0"], x, relu=False) if (q + "downsample.0") in U else x
+                o = self._fwd_unit(U[q + "conv1"], x)
+                if bott:
+                    o = self._fwd_unit(U[q + "conv2"], o)
+                    x = self._fwd_unit(U[q + "conv3"], o, residual=idt)
+                else:
+                    x = self._fwd_unit(U[q + "conv2"], o, residual=idt)
+        for bn in self.nbt:
+            self.nbt[bn] += 1
+        feat = ops.global_avgpool(x)
+        logits = self._linear_fwd("heads", feat)
+        outs, o = {}, 0
+        for t, k in self.heads:
+            outs[t] = logits[:, o:o + k]
+            o += k
+        for t, k in _ALL_HEADS:
+            outs.setdefault(t, torch.zeros((B, k), device=self.dev))
+        cams = [0, 0, 0]
+        if teacher_feats is not None:
+            assert self.loss_type == "all" and len(teacher_feats) == 3
+            teas = [self._linear_fwd(m, t.to(self.dev, F32).contiguous()) for m, t in zip(("mi", "mv", "mt"), teacher_feats)]
+            cams = [self._linear_fwd(wn, mx) for wn, mx in zip(("wi", "wv", "wt"), ops.kd_mix(feat, *teas))]
+        return (cams[0], outs["i"]), (cams[1], outs["v"]), (cams[2], outs["t"]), (feat, outs["ivt"])
 
     def _fwd_bwd(self, frames, z, tp, tf):
         """device part of a step (enqueue only): forward, losses, backward into self.G.  Returns (per-column BCE sums, soft, kd)."""

@@ -443,7 +443,11 @@ def gen_cnn_train(name):
         m.load_state_dict(sd, strict=True)
         img, labels, tpred, tfeat = cnn_train_inputs(cfg)
         opt = torch.optim.SGD(m.parameters(), lr=cfg["lr"], weight_decay=1e-5)
-        (cam_i, li), (cam_v, lv), (cam_t, lt), (_, livt) = m(img, *tfeat)
+        (cam_i, li), (cam_v, lv), (cam_t, lt), (feat_f, livt) = m(img, *tfeat)
+        # the module call itself under train() (`network.py:43-92`): what `spatial_cnn.VideoNas.train()(img, feat_i, feat_v, feat_t)` must return
+        fwd = {"fwd_logit_i": li, "fwd_logit_v": lv, "fwd_logit_t": lt, "fwd_logit_ivt": livt, "fwd_feat": feat_f, "fwd_kd_i": cam_i, "fwd_kd_v": cam_v,
+               "fwd_kd_t": cam_t}
+        fwd = {k: v.detach().clone().numpy() for k, v in fwd.items()}
         f_i = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(o_ct.TOOL_W))
         f_v = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(o_ct.VERB_W))
         f_t = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(o_ct.TARGET_W))
@@ -471,6 +475,9 @@ def gen_cnn_train(name):
             assert e < 5e-4, (name, k, e)
         outd = {"cfg": np.array(repr(cfg)), "loss": np.array(float(loss)), "hard": np.array(float(hard)), "soft": np.array(float(soft)),
                 "kd": np.array(float(kd))}
+        outd.update(fwd)
+        for k in ("basemodel.basemodel.bn1.running_mean", "basemodel.basemodel.layer3.0.bn2.running_var"):
+            outd["after::" + k] = new_ref[k].float().numpy()
         keys = list(new_ref)
         outd["grad_norms"] = np.array([float(grads[k].norm()) if (k in grads and grads[k] is not None) else -1.0 for k in keys], dtype=np.float64)
         # conditioning: how far the reference's own fp32 gradient is from the fp64 gradient of the same step (max-abs, relative to the

@@ -250,13 +250,18 @@ def test_q2l_teacher_train_driver_runs_and_feeds_test_py(cuda, tmp_path):
     shutil.copytree(os.path.join(ROOT, "MT4MTLKD"), tree)
     data = str(tmp_path / "CholecT45")
     vids = _make_dataset(data, n_frames=2, h=40, w=56)
+    # an upstream-style Swin checkpoint where `build_backbone` looks for it (`backbone.py:31-41,191-196`): {'model': {...}} with head.* entries
+    table = shapes.q2l_param_shapes("swin_T_224_1k", 224, 768, "t")
+    up = {k[len("backbone.0."):]: v for k, v in synth.fill_from_shapes(table, seed=5).items() if k.startswith("backbone.0.")}
+    up["head.weight"], up["head.bias"] = torch.zeros(1000, 768), torch.zeros(1000)
+    os.makedirs(tree / "Pretrain")
+    torch.save({"model": up}, tree / "Pretrain" / "swin_tiny_patch4_window7_224.pth")
     r = subprocess.run([sys.executable, "run.py", "-t", "-e", "--img_size", "224", "--backbone", "swin_T_224_1k", "--hidden_dim", "768", "--loss_type", "t",
                         "--epochs", "2", "--batch", "16", "-l", "1e-2", "5e-3", "1e-5", "--version", "T", "--val_interval", "1", "--data_dir", data,
                         "--kfold", "1"],
                        cwd=tree / "Spatial_transformer", env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     d = tree / "Spatial_transformer" / "__checkpoint__" / "run_T_t"
-    table = shapes.q2l_param_shapes("swin_T_224_1k", 224, 768, "t")
     for name in ("rendezvous_lcholect45-crossval_cholect1_latest.pth", "rendezvous_lcholect45-crossval_cholect1.pth"):
         sd = torch.load(d / name, map_location="cpu")
         assert list(sd.keys()) == [k for k, _ in table] and all(tuple(sd[k].shape) == tuple(s) for k, s in table)
@@ -265,6 +270,6 @@ def test_q2l_teacher_train_driver_runs_and_feeds_test_py(cuda, tmp_path):
     k = "backbone.0.layers.2.blocks.3.attn.relative_position_bias_table"
     assert not torch.equal(sd[k], sd0[k])
     log = open(d / "rendezvous_lcholect45-crossval_cholect1.log").read()
-    assert log.count("Traning | lr:") == 2 and "mAP => t:" in log
+    assert log.count("Traning | lr:") == 2 and "mAP => t:" in log and f"backbone: {len(up) - 2} tensors from" in log
     feats = pickle.load(open(tree / "0-5fold" / "data_feats" / "run_T" / "k1_t_feats.pkl", "rb"))
     assert list(feats) == [v[3:] for v in vids] and feats["79"].shape == (2, 768) and np.isfinite(feats["79"]).all()
