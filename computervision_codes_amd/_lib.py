@@ -92,6 +92,13 @@ SIGNATURES = {
     "mt4_bce_logits_pw_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_distill_kl_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _i32, _vp]),
     "mt4_mse_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, _vp]),
+    "mt4_bn_stats_t": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, C.c_float, C.c_float, _vp]),
+    "mt4_bn_apply_t": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _vp]),
+    "mt4_bn_backward_t": (C.c_int, [_vp, _vp, _vp, _i32] + [_vp] * 8 + [C.c_int64, _i32, _i32, _vp]),
+    "mt4_wgrad_conv2d_bf16": (C.c_int, [_vp, _vp, _vp] + [_i32] * 9 + [_vp]),
+    "mt4_maxpool3x3s2_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_avgpool_bwd_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "mt4_repack_weight_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_kd_mix_bwd_f32": (C.c_int, [_vp] * 9 + [_i32, _i32, _vp]),
     "mt4_tcn_conv": (C.c_int, [C.POINTER(TcnDesc), _vp]),
     "mt4_tcn_dilated_residual_layer": (C.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),

@@ -1,0 +1,479 @@
+// bf16-operand training mode of the spatial stage (Spatial_cnn/run.py:145-224 with the convolutions' GEMM operands in bf16): activations and
+// activation gradients are stored in bf16, every sum runs in fp32 (MFMA accumulators) or fp64 (BatchNorm reductions), the master weights, their
+// gradients and the optimizer stay fp32.  Forward and data-gradient convolutions are mt4_conv_nhwc in bf16; this file holds what that mode adds:
+//   * the weight gradient on bf16 MFMA (`v_mfma_f32_16x16x32_bf16`, operands transposed on the way out of LDS by `ds_read_b64_tr_b16`),
+//   * train-mode BatchNorm forward / backward with bf16 tensors (the stem keeps an fp32 convolution output: its 7x7x3 geometry runs in fp32),
+//   * pooling backward with bf16 gradients, and the fp32 -> bf16 copy of a packed weight matrix.
+#include "mt4_common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ element access
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ __forceinline__ float4 ld4<u16>(const u16* p) {
+    const uint2 v = *(const uint2*)p;
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, float4 v) { *(float4*)p = v; }
+template <> __device__ __forceinline__ void st4<u16>(u16* p, float4 v) { *(uint2*)p = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+
+// ------------------------------------------------------------------------------------------------ BatchNorm2d (training), typed tensors
+// same arithmetic and work split as train2d_kernels.hip: float64 per-channel reductions, a thread owns 4 consecutive channels
+__device__ __forceinline__ void bn_block_reduce(double (&acc)[8], double* __restrict__ sums, int C, int c0) {
+    __shared__ double red[16][8][17];
+    const int cg = threadIdx.x & 15, r = threadIdx.x >> 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[r][j][cg] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int g = threadIdx.x & 15, j = threadIdx.x >> 4;
+        double t = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) t += red[rr][j][g];
+        const int c = c0 + g * 4 + (j & 3);
+        if (c < C) atomicAdd(sums + (j >> 2) * C + c, t);
+    }
+}
+
+template <typename TZ>
+__global__ __launch_bounds__(256) void bn_stats_t_kernel(const TZ* __restrict__ x, double* __restrict__ sums, long long M, int C) {
+    const int c0 = blockIdx.x * 64, c = c0 + (threadIdx.x & 15) * 4;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < C)
+        for (long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4); m < M; m += (long long)gridDim.y * 16) {
+            const float4 v = ld4<TZ>(x + m * C + c);
+            acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
+            acc[4] += (double)v.x * v.x; acc[5] += (double)v.y * v.y; acc[6] += (double)v.z * v.z; acc[7] += (double)v.w * v.w;
+        }
+    bn_block_reduce(acc, sums, C, c0);
+}
+
+int bn_row_slabs(long long M, int C) {
+    long long gy = (M + 63) / 64;
+    const long long cap = (2048 + cdiv(C, 64) - 1) / cdiv(C, 64);
+    if (gy > cap) gy = cap;
+    return gy < 1 ? 1 : (int)gy;
+}
+
+__global__ void bn_finalize_t_kernel(const double* __restrict__ sums, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
+                                     float* __restrict__ run_var, long long M, int C, float momentum, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = sums[c] / (double)M;
+    double var = sums[C + c] / (double)M - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mu;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+    }
+}
+
+// y (bf16) = act( (x - mean) * invstd * gamma + beta [+ residual (bf16)] )
+template <typename TZ>
+__global__ void bn_apply_t_kernel(const TZ* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, const u16* __restrict__ res, u16* __restrict__ y, long long n4, int C, int relu) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % C);
+    const float4 xv = ld4<TZ>(x + i * 4);
+    const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c), g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    float4 o = make_float4((xv.x - mu.x) * is.x * g.x + b.x, (xv.y - mu.y) * is.y * g.y + b.y, (xv.z - mu.z) * is.z * g.z + b.z,
+                           (xv.w - mu.w) * is.w * g.w + b.w);
+    if (res) { const float4 r = ld4<u16>(res + i * 4); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    st4<u16>(y + i * 4, o);
+}
+
+template <typename TZ>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_t_kernel(const u16* __restrict__ dy, const u16* __restrict__ y, const TZ* __restrict__ x,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ sums,
+                                                              long long M, int C, int relu) {
+    const int c0 = blockIdx.x * 64, c = c0 + (threadIdx.x & 15) * 4;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < C) {
+        const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
+        for (long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4); m < M; m += (long long)gridDim.y * 16) {
+            float4 g = ld4<u16>(dy + m * C + c);
+            const float4 xv = ld4<TZ>(x + m * C + c);
+            if (relu) {
+                const float4 yv = ld4<u16>(y + m * C + c);
+                if (!(yv.x > 0.f)) g.x = 0.f;
+                if (!(yv.y > 0.f)) g.y = 0.f;
+                if (!(yv.z > 0.f)) g.z = 0.f;
+                if (!(yv.w > 0.f)) g.w = 0.f;
+            }
+            acc[0] += (double)g.x; acc[1] += (double)g.y; acc[2] += (double)g.z; acc[3] += (double)g.w;
+            acc[4] += (double)g.x * (double)((xv.x - mu.x) * is.x); acc[5] += (double)g.y * (double)((xv.y - mu.y) * is.y);
+            acc[6] += (double)g.z * (double)((xv.z - mu.z) * is.z); acc[7] += (double)g.w * (double)((xv.w - mu.w) * is.w);
+        }
+    }
+    bn_block_reduce(acc, sums, C, c0);
+}
+
+// dx has the type of x (the convolution output: bf16, or fp32 for the stem); dres = the gated gradient, bf16
+template <typename TZ>
+__global__ void bn_bwd_apply_t_kernel(const u16* __restrict__ dy, const u16* __restrict__ y, const TZ* __restrict__ x, const float* __restrict__ mean,
+                                      const float* __restrict__ invstd, const float* __restrict__ gamma, const double* __restrict__ sums, TZ* __restrict__ dx,
+                                      u16* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta, long long M, int C, int relu) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) { dbeta[i] = (float)sums[i]; dgamma[i] = (float)sums[C + i]; }
+    if (i >= M * C / 4) return;
+    const int c = (int)((i * 4) % C);
+    float4 g = ld4<u16>(dy + i * 4);
+    if (relu) {
+        const float4 yv = ld4<u16>(y + i * 4);
+        if (!(yv.x > 0.f)) g.x = 0.f;
+        if (!(yv.y > 0.f)) g.y = 0.f;
+        if (!(yv.z > 0.f)) g.z = 0.f;
+        if (!(yv.w > 0.f)) g.w = 0.f;
+    }
+    const float4 xv = ld4<TZ>(x + i * 4), mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c), ga = *(const float4*)(gamma + c);
+    const double invM = 1.0 / (double)M;
+    float4 o;
+    o.x = ga.x * is.x * (g.x - (float)(sums[c] * invM) - (xv.x - mu.x) * is.x * (float)(sums[C + c] * invM));
+    o.y = ga.y * is.y * (g.y - (float)(sums[c + 1] * invM) - (xv.y - mu.y) * is.y * (float)(sums[C + c + 1] * invM));
+    o.z = ga.z * is.z * (g.z - (float)(sums[c + 2] * invM) - (xv.z - mu.z) * is.z * (float)(sums[C + c + 2] * invM));
+    o.w = ga.w * is.w * (g.w - (float)(sums[c + 3] * invM) - (xv.w - mu.w) * is.w * (float)(sums[C + c + 3] * invM));
+    st4<TZ>(dx + i * 4, o);
+    if (dres) st4<u16>(dres + i * 4, g);
+}
+
+// ------------------------------------------------------------------------------------------------ Conv2d weight gradient, bf16 operands
+//   dW[n][tap][c] += sum over output pixels p of dy[p][n] * x[in(p, tap)][c]        n = output channel, c = input channel
+// A GEMM whose reduction index (the pixel) is the SLOW index of both operands in memory ([pixel][channel] rows).  The MFMA wants 8 consecutive
+// reduction elements per lane for both, i.e. both operands transposed: each is staged [pixel][64 channels] (128-byte rows, as it arrives from
+// HBM) and read with ds_read_b64_tr_b16 -- per 16-lane group a block of 4 pixels x 16 channels, delivered channel-major: lane i of the group
+// gets channel i of the 4 pixels, exactly the A (dy^T) and B (x) fragment halves of v_mfma_f32_16x16x32_bf16.
+// A workgroup (4 waves) owns a 64 x 64 (n, c) tile for ONE kernel row kh (its K taps) and walks spatial tiles of TH x 16 output pixels of the
+// frames (its share of them); per tile it stages the dy tile and the TH input rows that kernel row reads (16 S + K - 1 pixels each, zeros
+// outside the image), then per 32 pixels (two tile rows) runs K x 4 MFMAs per wave: wave (wm, wn) holds dW[32 n][kh][K][32 c] in registers
+// across all its tiles and adds it to the fp32 gradient buffer with atomics at the end (the split of the pixel range over workgroups makes the sum order
+// run-dependent, like mt4_wgrad_conv2d_f32's).
+// LDS rows are 128 B; the 16-byte chunk index is XOR-ed with 2 * (bit 1 | bit 3 << 1) of the row index: the 8 (pixel, group) blocks a 32-lane
+// half of a transposed read touches (pixels R .. R + 3 and R + 8 .. R + 11) then fall on 8 different 32-byte bank spans for any R.  The halo
+// tile's row pitch is a multiple of 16 pixels, so the swizzle of a fragment address depends on the lane and the column shift kw only: six
+// per-lane offsets, everything else is an immediate.
+constexpr int WG_ROWB = 128;
+
+__device__ __forceinline__ int wg_swz(int row, int chunk) { return row * WG_ROWB + ((chunk ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1)) << 4); }
+
+// two fragments (two channel tiles) = four transposed reads, one wait.  (The reads are issued from inline asm -- there is no builtin -- so the
+// compiler cannot track their latency: the statement only returns once the data is in the registers.)
+__device__ __forceinline__ void ds_read_tr_x4(const char* p0, const char* p1, const char* p2, const char* p3, uint4& f0, uint4& f1) {
+    uint2 a, b, c, d;
+    const unsigned a0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p0;
+    const unsigned a1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p1;
+    const unsigned a2 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p2;
+    const unsigned a3 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p3;
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+                 : "memory");
+    f0 = make_uint4(a.x, a.y, b.x, b.y);
+    f1 = make_uint4(c.x, c.y, d.x, d.y);
+}
+
+struct WgK {
+    const u16* dy;
+    const u16* x;
+    float* dw;
+    int B, H, W, Cin, Ho, Wo, Cout;
+    int kpad, tapw;           // fp32 packed row length, elements per tap
+    int tiles_h, tiles_w, ntiles, nsplit, cin_tiles;
+};
+
+template <int K, int S, int TH>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgK a) {
+    constexpr int PAD = K / 2;
+    constexpr int IW = S * 15 + K;                              // input pixels per tile row (with the column halo)
+    constexpr int PITCH = (IW + 15) / 16 * 16;                  // pixels per LDS row of the input tile
+    constexpr int DY_BYTES = TH * 16 * WG_ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sdy = smem;
+    char* const sx = smem + DY_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    // workgroup = (64 x 64 (n, c) tile, kernel row kh, share of the spatial tiles): a kernel row's K taps = K x 16 accumulator registers
+    int bid = blockIdx.x;
+    const int split = bid % a.nsplit;
+    bid /= a.nsplit;
+    const int kh = bid % K;
+    const int pair = bid / K;
+    const int n0 = (pair / a.cin_tiles) * 64, c0 = (pair % a.cin_tiles) * 64;
+
+    f32x4 acc[K][2][2];
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[t][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane fragment offsets.  A block's row for this lane: output pixel (tile row 2 s + (g >> 1), column 8 (g & 1) + 4 h + q); it supplies
+    // the 8 bytes of channels 4 p .. 4 p + 3 of the fragment's 16 channels: chunk (ch0 >> 3) + (p >> 1), half p & 1
+    int yo[2][2], xo[K][2][2];            // [half h][channel tile of the wave]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = 8 * (g & 1) + 4 * h + q;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            yo[h][ti] = wg_swz((g >> 1) * 16 + col, (wm * 32 + ti * 16) / 8 + (p >> 1)) + (p & 1) * 8;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+                xo[kw][h][ti] = wg_swz(S * col + kw, (wn * 32 + ti * 16) / 8 + (p >> 1)) + (p & 1) * 8 + (g >> 1) * (PITCH * WG_ROWB);
+        }
+    }
+
+    const int ld_row = tid >> 3, ld_chunk = tid & 7;
+    for (int t = split; t < a.ntiles; t += a.nsplit) {
+        const int tpi = a.tiles_h * a.tiles_w;
+        const int img = t / tpi;
+        const int tr = t - img * tpi;
+        const int th = tr / a.tiles_w;
+        const int ho0 = th * TH, wo0 = (tr - th * a.tiles_w) * 16;
+        __syncthreads();                                   // the previous tile's fragment reads are done
+        // ---- dy tile: TH x 16 output pixels x 64 output channels
+        for (int r = ld_row; r < TH * 16; r += 32) {
+            const int ho = ho0 + (r >> 4), wo = wo0 + (r & 15);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ho < a.Ho && wo < a.Wo) v = *(const uint4*)(a.dy + (((long long)img * a.Ho + ho) * a.Wo + wo) * a.Cout + n0 + ld_chunk * 8);
+            *(uint4*)(sdy + wg_swz(r, ld_chunk)) = v;
+        }
+        // ---- input tile for this kernel row: LDS row iy = the input row of output row ho0 + iy, IW pixels (rows of PITCH pixels), zeros outside
+        for (int r = ld_row; r < TH * PITCH; r += 32) {
+            const int iy = r / PITCH, ix = r - iy * PITCH;
+            const int hi = S * (ho0 + iy) - PAD + kh, wi = S * wo0 - PAD + ix;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ix < IW && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
+                v = *(const uint4*)(a.x + (((long long)img * a.H + hi) * a.W + wi) * a.Cin + c0 + ld_chunk * 8);
+            *(uint4*)(sx + wg_swz(r, ld_chunk)) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < TH / 2; ++s) {
+            uint4 fa[2];
+            {
+                const char* yb = sdy + s * (32 * WG_ROWB);
+                ds_read_tr_x4(yb + yo[0][0], yb + yo[1][0], yb + yo[0][1], yb + yo[1][1], fa[0], fa[1]);
+            }
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                uint4 fb[2];
+                {
+                    const char* xb = sx + (2 * s) * (PITCH * WG_ROWB);
+                    ds_read_tr_x4(xb + xo[kw][0][0], xb + xo[kw][1][0], xb + xo[kw][0][1], xb + xo[kw][1][1], fb[0], fb[1]);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[kw][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[mi]), __builtin_bit_cast(bf16x8_t, fb[ni]),
+                                                                                  acc[kw][mi][ni], 0, 0, 0);
+            }
+        }
+    }
+    // ---- dW += the wave's 32 x K x 32 block: lane (r16 = c, q4 = lane >> 4) holds output channels 4 q4 + e of input channel r16
+    const int r16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + wm * 32 + mi * 16 + q4 * 4 + e;
+                    const int c = c0 + wn * 32 + ni * 16 + r16;
+                    atomicAdd(a.dw + (long long)n * a.kpad + (kh * K + kw) * a.tapw + c, acc[kw][mi][ni][e]);
+                }
+}
+
+template <int K, int S, int TH>
+int launch_wgrad(WgK a, hipStream_t stream) {
+    constexpr int IW = S * 15 + K, PITCH = (IW + 15) / 16 * 16;
+    constexpr int LDS = TH * 16 * WG_ROWB + TH * PITCH * WG_ROWB;
+    static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+    a.tiles_h = cdiv(a.Ho, TH);
+    a.tiles_w = cdiv(a.Wo, 16);
+    a.ntiles = a.B * a.tiles_h * a.tiles_w;
+    a.cin_tiles = a.Cin / 64;
+    const int pairs = (a.Cout / 64) * a.cin_tiles * K;
+    int nsplit = (1024 + pairs - 1) / pairs;
+    if (nsplit > a.ntiles) nsplit = a.ntiles;
+    if (nsplit < 1) nsplit = 1;
+    a.nsplit = nsplit;
+    auto fn = wgrad_bf16_kernel<K, S, TH>;
+    MT4_RAISE_LDS(fn);
+    hipLaunchKernelGGL(fn, dim3((unsigned)(pairs * nsplit)), dim3(256), LDS, stream, a);
+    return mt4_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ pooling backward, packed-weight copy
+// MaxPool2d(3,2,1) backward in gather form (bf16 has no float atomics worth using: a thread owns one INPUT element and sums the gradients of
+// the at most four windows whose first maximum -- (kh, kw) scan order, what torch's backward picks -- it is; one rounding)
+__global__ void maxpool3x3s2_bwd_bf16_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, u16* __restrict__ dx, int B, int H, int W, int C,
+                                             int Ho, int Wo) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * H * W * C) return;
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H), b = (int)(r / H);
+    float acc = 0.f;
+    for (int ho = h >> 1; ho <= ((h + 1) >> 1) && ho < Ho; ++ho)
+        for (int wo = w >> 1; wo <= ((w + 1) >> 1) && wo < Wo; ++wo) {
+            float best = -INFINITY;
+            int bh = -1, bw = -1;
+            for (int kh = 0; kh < 3; ++kh) {
+                const int hh = 2 * ho - 1 + kh;
+                if ((unsigned)hh >= (unsigned)H) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ww = 2 * wo - 1 + kw;
+                    if ((unsigned)ww >= (unsigned)W) continue;
+                    const float v = bf16_to_f32(x[(((long long)b * H + hh) * W + ww) * C + c]);
+                    if (v > best || bh < 0) { best = v; bh = hh; bw = ww; }
+                }
+            }
+            if (bh == h && bw == w) acc += bf16_to_f32(dy[(((long long)b * Ho + ho) * Wo + wo) * C + c]);
+        }
+    dx[i] = f32_to_bf16(acc);
+}
+
+__global__ void avgpool_bwd_bf16_kernel(const float* __restrict__ df, u16* __restrict__ dx, int HW, int C, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const long long e = i * 4;
+    const int c = (int)(e % C);
+    const long long b = e / ((long long)HW * C);
+    const float4 v = *(const float4*)(df + b * C + c);
+    const float s = 1.0f / (float)HW;
+    st4<u16>(dx + e, make_float4(v.x * s, v.y * s, v.z * s, v.w * s));
+}
+
+__global__ void repack_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, int taps, int tapw32, long long kpad32, int tapw16, long long kpad16,
+                                   long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long long n = idx / kpad16;
+    const int k = (int)(idx - n * kpad16);
+    const int tap = k / tapw16, c = k - tap * tapw16;
+    float v = 0.f;
+    if (tap < taps && c < tapw32) v = src[n * kpad32 + tap * tapw32 + c];
+    dst[idx] = f32_to_bf16(v);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" int mt4_bn_stats_t(const void* x, int32_t x_dtype, double* sums_zeroed, float* mean, float* invstd, float* running_mean, float* running_var,
+                              int64_t M, int32_t C, float momentum, float eps, void* stream) {
+    mt4_clear_error();
+    if (!x || !sums_zeroed || !mean || !invstd || M <= 0 || C <= 0) return MT4_EINVAL;
+    if (C % 4) return MT4_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(cdiv(C, 64), bn_row_slabs(M, C));
+    if (x_dtype == MT4_BF16) hipLaunchKernelGGL(bn_stats_t_kernel<u16>, grid, dim3(256), 0, s, (const u16*)x, sums_zeroed, (long long)M, C);
+    else if (x_dtype == MT4_F32) hipLaunchKernelGGL(bn_stats_t_kernel<float>, grid, dim3(256), 0, s, (const float*)x, sums_zeroed, (long long)M, C);
+    else return MT4_EUNSUPPORTED;
+    hipLaunchKernelGGL(bn_finalize_t_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, sums_zeroed, mean, invstd, running_mean, running_var, (long long)M, C,
+                       momentum, eps);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_bn_apply_t(const void* x, int32_t x_dtype, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              const void* residual_bf16, void* y_bf16, int64_t M, int32_t C, int32_t relu, void* stream) {
+    mt4_clear_error();
+    if (!x || !mean || !invstd || !gamma || !beta || !y_bf16 || M <= 0 || C <= 0) return MT4_EINVAL;
+    if (C % 4) return MT4_EALIGN;
+    const long long n4 = M * C / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == MT4_BF16)
+        hipLaunchKernelGGL(bn_apply_t_kernel<u16>, grid, dim3(256), 0, s, (const u16*)x, mean, invstd, gamma, beta, (const u16*)residual_bf16, (u16*)y_bf16, n4, C, relu);
+    else if (x_dtype == MT4_F32)
+        hipLaunchKernelGGL(bn_apply_t_kernel<float>, grid, dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const u16*)residual_bf16, (u16*)y_bf16, n4, C, relu);
+    else return MT4_EUNSUPPORTED;
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_bn_backward_t(const void* dy_bf16, const void* y_post_bf16, const void* x, int32_t x_dtype, const float* mean, const float* invstd,
+                                 const float* gamma, double* sums_zeroed, void* dx, void* dres_bf16, float* dgamma, float* dbeta, int64_t M, int32_t C,
+                                 int32_t relu, void* stream) {
+    mt4_clear_error();
+    if (!dy_bf16 || !x || !mean || !invstd || !gamma || !sums_zeroed || !dx || !dgamma || !dbeta || M <= 0 || C <= 0) return MT4_EINVAL;
+    if (relu && !y_post_bf16) return MT4_EINVAL;
+    if (C % 4) return MT4_EALIGN;
+    if (x_dtype != MT4_BF16 && x_dtype != MT4_F32) return MT4_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g1(cdiv(C, 64), bn_row_slabs(M, C));
+    long long n = M * C / 4;
+    if (n < C) n = C;
+    const dim3 g2((unsigned)((n + 255) / 256));
+    const u16 *dy = (const u16*)dy_bf16, *yp = (const u16*)y_post_bf16;
+    if (x_dtype == MT4_BF16) {
+        hipLaunchKernelGGL(bn_bwd_reduce_t_kernel<u16>, g1, dim3(256), 0, s, dy, yp, (const u16*)x, mean, invstd, sums_zeroed, (long long)M, C, relu);
+        hipLaunchKernelGGL(bn_bwd_apply_t_kernel<u16>, g2, dim3(256), 0, s, dy, yp, (const u16*)x, mean, invstd, gamma, sums_zeroed, (u16*)dx, (u16*)dres_bf16,
+                           dgamma, dbeta, (long long)M, C, relu);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_t_kernel<float>, g1, dim3(256), 0, s, dy, yp, (const float*)x, mean, invstd, sums_zeroed, (long long)M, C, relu);
+        hipLaunchKernelGGL(bn_bwd_apply_t_kernel<float>, g2, dim3(256), 0, s, dy, yp, (const float*)x, mean, invstd, gamma, sums_zeroed, (float*)dx,
+                           (u16*)dres_bf16, dgamma, dbeta, (long long)M, C, relu);
+    }
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_wgrad_conv2d_bf16(const void* dy, const void* x, float* dw_packed, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Ho, int32_t Wo,
+                                     int32_t Cout, int32_t K, int32_t stride, void* stream) {
+    mt4_clear_error();
+    if (!dy || !x || !dw_packed || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return MT4_EINVAL;
+    if ((K != 1 && K != 3) || (stride != 1 && stride != 2) || (Cin % 64) || (Cout % 64)) return MT4_EUNSUPPORTED;
+    if (Ho != (H + 2 * (K / 2) - K) / stride + 1 || Wo != (W + 2 * (K / 2) - K) / stride + 1) return MT4_EINVAL;
+    if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw_packed) & 15) return MT4_EALIGN;
+    WgK a;
+    a.dy = (const u16*)dy; a.x = (const u16*)x; a.dw = dw_packed;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+    a.kpad = (int)mt4_conv_packed_k(Cin, K, K, MT4_F32);
+    a.tapw = (Cin + 3) / 4 * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (K == 1 && stride == 1) return launch_wgrad<1, 1, 8>(a, s);
+    if (K == 1) return launch_wgrad<1, 2, 8>(a, s);
+    if (stride == 1) return launch_wgrad<3, 1, 8>(a, s);
+    return launch_wgrad<3, 2, 8>(a, s);
+}
+
+extern "C" int mt4_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+    mt4_clear_error();
+    if (!x || !dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0) return MT4_EINVAL;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long n = (long long)B * H * W * C;
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u16*)x, (const u16*)dy,
+                       (u16*)dx, B, H, W, C, Ho, Wo);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_avgpool_bwd_bf16(const float* dfeat, void* dx, int32_t B, int32_t HW, int32_t C, void* stream) {
+    mt4_clear_error();
+    if (!dfeat || !dx || B <= 0 || HW <= 0 || C <= 0 || (C & 3)) return MT4_EINVAL;
+    const long long n4 = (long long)B * HW * C / 4;
+    hipLaunchKernelGGL(avgpool_bwd_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dfeat, (u16*)dx, HW, C, n4);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_repack_weight_bf16(const float* w_f32_packed, void* w_bf16_packed, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, void* stream) {
+    mt4_clear_error();
+    if (!w_f32_packed || !w_bf16_packed || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return MT4_EINVAL;
+    const long long k32 = mt4_conv_packed_k(Cin, KH, KW, MT4_F32), k16 = mt4_conv_packed_k(Cin, KH, KW, MT4_BF16);
+    const long long total = (long long)Cout * k16;
+    hipLaunchKernelGGL(repack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_f32_packed, (u16*)w_bf16_packed, KH * KW,
+                       (Cin + 3) / 4 * 4, k32, (Cin + 7) / 8 * 8, k16, total);
+    return mt4_check_launch();
+}

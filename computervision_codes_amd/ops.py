@@ -699,6 +699,79 @@ def kd_mix_bwd(s, teas, gs):
     return ds, dtau
 
 
+# ----------------------------------------------------------------------------------------- bf16-operand training pieces
+BF16 = torch.bfloat16
+
+
+def bn_stats_t(x2d, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, sums=None):
+    """`bn_stats` for a bf16 (or fp32) convolution output"""
+    _need_cuda(x2d)
+    m, c = x2d.shape
+    assert sums is not None and sums.dtype == torch.float64 and sums.numel() == 2 * c and x2d.is_contiguous()
+    mean, invstd = torch.empty(c, device=x2d.device), torch.empty(c, device=x2d.device)
+    check(lib.mt4_bn_stats_t(x2d.data_ptr(), dt_code(x2d.dtype), sums.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                             running_mean.data_ptr() if running_mean is not None else None,
+                             running_var.data_ptr() if running_var is not None else None, m, c, momentum, eps, _stream()), "mt4_bn_stats_t")
+    return mean, invstd
+
+
+def bn_apply_t(x2d, mean, invstd, gamma, beta, residual=None, relu=True):
+    """bf16 output; x2d bf16 or fp32, residual bf16"""
+    m, c = x2d.shape
+    assert x2d.is_contiguous() and (residual is None or (residual.dtype == BF16 and residual.is_contiguous()))
+    y = torch.empty((m, c), dtype=BF16, device=x2d.device)
+    check(lib.mt4_bn_apply_t(x2d.data_ptr(), dt_code(x2d.dtype), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                             residual.data_ptr() if residual is not None else None, y.data_ptr(), m, c, 1 if relu else 0, _stream()), "mt4_bn_apply_t")
+    return y
+
+
+def bn_backward_t(dy, y_post, x2d, mean, invstd, gamma, dgamma, dbeta, relu=True, want_dres=False, sums=None):
+    """dy / y_post bf16; x2d (the convolution output) bf16 or fp32 -> dx of that type; dres bf16"""
+    m, c = x2d.shape
+    assert sums is not None and sums.dtype == torch.float64 and sums.numel() == 2 * c
+    assert dy.dtype == BF16 and dy.is_contiguous() and x2d.is_contiguous() and (y_post is None or (y_post.dtype == BF16 and y_post.is_contiguous()))
+    dx = torch.empty_like(x2d)
+    dres = torch.empty((m, c), dtype=BF16, device=x2d.device) if want_dres else None
+    check(lib.mt4_bn_backward_t(dy.data_ptr(), y_post.data_ptr() if y_post is not None else None, x2d.data_ptr(), dt_code(x2d.dtype), mean.data_ptr(),
+                                invstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(), dx.data_ptr(), dres.data_ptr() if want_dres else None,
+                                dgamma.data_ptr(), dbeta.data_ptr(), m, c, 1 if relu else 0, _stream()), "mt4_bn_backward_t")
+    return dx, dres
+
+
+def wgrad_conv2d_bf16(dy, x, dw_packed, k, stride):
+    """dw_packed (fp32 packed, ADDED to) from dy [B,Ho,Wo,Cout] and x [B,H,W,Cin], both bf16"""
+    _need_cuda(dy, x, dw_packed)
+    b, ho, wo, cout = dy.shape
+    _, h, w, cin = x.shape
+    assert dy.dtype == x.dtype == BF16 and dy.is_contiguous() and x.is_contiguous() and dw_packed.dtype == torch.float32
+    assert dw_packed.shape == (cout, packed_k(cin, k, k, torch.float32))
+    check(lib.mt4_wgrad_conv2d_bf16(dy.data_ptr(), x.data_ptr(), dw_packed.data_ptr(), b, h, w, cin, ho, wo, cout, k, stride, _stream()),
+          "mt4_wgrad_conv2d_bf16")
+
+
+def maxpool3x3s2_bwd_bf16(x, dy):
+    b, h, w, c = x.shape
+    assert x.dtype == dy.dtype == BF16 and x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x)
+    check(lib.mt4_maxpool3x3s2_bwd_bf16(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), b, h, w, c, _stream()), "mt4_maxpool3x3s2_bwd_bf16")
+    return dx
+
+
+def avgpool_bwd_bf16(dfeat, b, hw, c):
+    dx = torch.empty((b, hw, c), dtype=BF16, device=dfeat.device)
+    check(lib.mt4_avgpool_bwd_bf16(dfeat.data_ptr(), dx.data_ptr(), b, hw, c, _stream()), "mt4_avgpool_bwd_bf16")
+    return dx
+
+
+def repack_weight_bf16(w_f32_packed, cout, cin, kh, kw, out=None):
+    """packed fp32 weights -> packed bf16 weights of the same geometry (into `out` when given: captured graphs keep the address)"""
+    _need_cuda(w_f32_packed, out)
+    assert w_f32_packed.dtype == torch.float32 and w_f32_packed.is_contiguous() and tuple(w_f32_packed.shape) == (cout, packed_k(cin, kh, kw, torch.float32))
+    o = torch.empty((cout, packed_k(cin, kh, kw, BF16)), dtype=BF16, device=w_f32_packed.device) if out is None else out
+    check(lib.mt4_repack_weight_bf16(w_f32_packed.data_ptr(), o.data_ptr(), cout, cin, kh, kw, _stream()), "mt4_repack_weight_bf16")
+    return o
+
+
 # ----------------------------------------------------------------------------------------- MS-TCT training pieces (fp32)
 def bgemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, m: int, n: int, k: int, nb0: int, nb1: int, a_strides, b_strides, c_strides,
           alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:

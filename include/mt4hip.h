@@ -280,6 +280,35 @@ int mt4_kd_mix_bwd_f32(const float* s, const float* tea_i, const float* tea_v, c
                        const float* g_t, float* ds, float* dtau, int32_t B, int32_t C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * bf16-operand training mode of the spatial stage (the same step as above -- Spatial_cnn/run.py:145-224 -- with the convolutions' GEMM operands
+ * in bf16): activations and activation gradients are bf16 tensors, sums run in fp32 (MFMA) / fp64 (BatchNorm reductions), master weights,
+ * gradients and SGD stay fp32.  Forward and data-gradient convolutions are mt4_conv_nhwc with dtype MT4_BF16 on bf16 copies of the packed
+ * weights (mt4_repack_weight_bf16).  `x_dtype` is the type of the convolution output the BatchNorm reads (MT4_BF16; MT4_F32 for the stem, whose
+ * 7x7x3 convolution and weight gradient stay fp32).
+ */
+int mt4_bn_stats_t(const void* x, int32_t x_dtype, double* sums_zeroed, float* mean, float* invstd, float* running_mean, float* running_var,
+                   int64_t M, int32_t C, float momentum, float eps, void* stream);
+/* y (bf16) = act( (x - mean) * invstd * gamma + beta [+ residual (bf16)] ) */
+int mt4_bn_apply_t(const void* x, int32_t x_dtype, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                   const void* residual_bf16, void* y_bf16, int64_t M, int32_t C, int32_t relu, void* stream);
+/* as mt4_bn_backward_f32 with dy / y_post / dres in bf16 and dx in the type of x */
+int mt4_bn_backward_t(const void* dy_bf16, const void* y_post_bf16, const void* x, int32_t x_dtype, const float* mean, const float* invstd,
+                      const float* gamma, double* sums_zeroed, void* dx, void* dres_bf16, float* dgamma, float* dbeta, int64_t M, int32_t C,
+                      int32_t relu, void* stream);
+/* Conv2d weight gradient on bf16 MFMA: dw_packed (fp32, the layout of mt4_pack_conv_weight(MT4_F32)) += sum_pixels dy[p][n] * x[in(p, tap)][c].
+ * dy [B][Ho][Wo][Cout] bf16, x [B][H][W][Cin] bf16; K = 1 or 3 (square, pad K / 2), stride 1 or 2, Cin % 64 == 0 and Cout % 64 == 0;
+ * MT4_EUNSUPPORTED otherwise.  The pixel range is split over workgroups and summed with fp32 atomics (order run-dependent). */
+int mt4_wgrad_conv2d_bf16(const void* dy, const void* x, float* dw_packed, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Ho, int32_t Wo,
+                          int32_t Cout, int32_t K, int32_t stride, void* stream);
+/* MaxPool2d(3,2,1) backward, bf16, gather form (no atomics; dx need not be zeroed) */
+int mt4_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+/* AdaptiveAvgPool2d(1) backward: dfeat [B][C] fp32 -> dx [B][HW][C] bf16 */
+int mt4_avgpool_bwd_bf16(const float* dfeat, void* dx, int32_t B, int32_t HW, int32_t C, void* stream);
+/* packed fp32 weight matrix (mt4_pack_conv_weight(MT4_F32) layout, e.g. the master weights or their transposed copies) -> the packed bf16
+ * layout of the same geometry */
+int mt4_repack_weight_bf16(const float* w_f32_packed, void* w_bf16_packed, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Temporal head, latency path: Conv1d (k = 1 or 3, any dilation, stride 1, padding = dilation*(k-1)/2) over frame-major rows,
  * fused epilogue   y = act( conv(x, w) + bias [+ residual] )
  * for ONE short video (or a few): replaces `DilatedResidualLayer` (Temporal_tenco/network.py:186-198: conv_dilated -> ReLU ->

@@ -1,0 +1,107 @@
+"""GPU: the bf16-operand training mode of the spatial stage -- its kernels against torch fp32 on the CPU evaluated on the SAME bf16-valued
+inputs (bf16 products are exact in fp32, so only the summation order and the final rounding differ), and the whole step against the fp32
+fixtures of the reference step at the tolerance the operand rounding allows."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from computervision_codes_amd import shapes, synth
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _rand(shape, seed, scale=1.0):
+    n = int(np.prod(shape))
+    return torch.from_numpy(((synth.uniform01(seed, 1, n) * 2 - 1) * scale).astype(np.float32).reshape(shape))
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,k,s", [(2, 16, 32, 64, 64, 3, 1), (3, 13, 21, 128, 64, 3, 1), (2, 9, 40, 64, 128, 1, 1), (2, 16, 32, 64, 64, 3, 2),
+                                                (3, 14, 22, 128, 128, 3, 2), (2, 14, 30, 64, 128, 1, 2), (5, 8, 14, 256, 64, 1, 1), (1, 1, 1, 64, 64, 3, 1)])
+def test_wgrad_conv2d_bf16_vs_autograd(cuda, b, h, w, cin, cout, k, s):
+    """`mt4_wgrad_conv2d_bf16` (bf16 MFMA, transposed LDS reads, kernel rows split over workgroups, fp32 atomics): full and ragged spatial tiles,
+    both strides, 1x1 and 3x3, several channel tiles; accumulation into a non-zero buffer"""
+    from computervision_codes_amd import ops
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    x = _rand((b, h, w, cin), 1).to(BF)
+    dy = _rand((b, ho, wo, cout), 2).to(BF)
+    wt = torch.zeros(cout, cin, k, k, requires_grad=True)
+    with torch.enable_grad():
+        y = F.conv2d(x.float().permute(0, 3, 1, 2), wt, None, stride=s, padding=pad)
+        y.backward(dy.float().permute(0, 3, 1, 2))
+    kp = ops.packed_k(cin, k, k, torch.float32)
+    base = _rand((cout, kp), 3)
+    dw = base.to(cuda).clone()
+    ops.wgrad_conv2d_bf16(dy.to(cuda), x.to(cuda), dw, k, s)
+    got = (dw.cpu() - base)[:, :k * k * cin].reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+    ref = wt.grad
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()) + 1e-5, (got - ref).abs().max().item()
+    assert float((dw.cpu() - base)[:, k * k * cin:].abs().max()) == 0.0 if kp > k * k * cin else True
+
+
+@pytest.mark.parametrize("m,c,relu,res,xf32", [(200, 64, True, False, False), (1031, 128, True, True, False), (77, 256, False, False, False), (300, 64, True, False, True)])
+def test_batchnorm_bf16_fwd_bwd(cuda, m, c, relu, res, xf32):
+    """train-mode BatchNorm with bf16 tensors (fp32 convolution output for the stem variant): statistics, output, and the three gradients against
+    torch on the same bf16-valued inputs; outputs are bf16, so one rounding of tolerance"""
+    from computervision_codes_amd import ops
+    x = (_rand((m, c), 1, 2.0) + 0.3)
+    x = x if xf32 else x.to(BF)
+    g, bta = _rand((c,), 2) + 1.5, _rand((c,), 3)
+    r = _rand((m, c), 4).to(BF) if res else None
+    dy = _rand((m, c), 5).to(BF)
+    rm, rv = _rand((c,), 6), _rand((c,), 7).abs() + 0.5
+    xt, gt, bt = x.float().clone().requires_grad_(), g.clone().requires_grad_(), bta.clone().requires_grad_()
+    rt = r.float().clone().requires_grad_() if res else None
+    rm_t, rv_t = rm.clone(), rv.clone()
+    with torch.enable_grad():
+        y_ref = F.batch_norm(xt, rm_t, rv_t, gt, bt, training=True, momentum=0.1, eps=1e-5)
+        if res:
+            y_ref = y_ref + rt
+        if relu:
+            y_ref = torch.relu(y_ref)
+    sums = torch.zeros(4 * c, dtype=torch.float64, device=cuda)
+    rmd, rvd = rm.to(cuda), rv.to(cuda)
+    mean, invstd = ops.bn_stats_t(x.to(cuda), rmd, rvd, sums=sums[:2 * c])
+    y = ops.bn_apply_t(x.to(cuda), mean, invstd, g.to(cuda), bta.to(cuda), r.to(cuda) if res else None, relu)
+    assert y.dtype == BF
+    assert (rmd.cpu() - rm_t).abs().max() < 1e-5 and (rvd.cpu() - rv_t).abs().max() < 1e-5
+    assert (y.float().cpu() - y_ref.detach()).abs().max().item() <= 2 ** -8 * max(1.0, y_ref.abs().max().item())
+    # backward on the bf16 output the kernel produced (the ReLU gate is read from it)
+    with torch.enable_grad():
+        y_ref.backward(dy.float())
+    dg, db = torch.zeros(c, device=cuda), torch.zeros(c, device=cuda)
+    dx, dres = ops.bn_backward_t(dy.to(cuda), y if relu else None, x.to(cuda), mean, invstd, g.to(cuda), dg, db, relu=relu, want_dres=res, sums=sums[2 * c:])
+    assert dx.dtype == x.dtype
+    tol = 2 ** -8 if not xf32 else 1e-4
+    assert (dx.float().cpu() - xt.grad).abs().max().item() <= tol * max(1.0, xt.grad.abs().max().item())
+    assert (dg.cpu() - gt.grad).abs().max().item() <= 2e-3 * max(1.0, gt.grad.abs().max().item())
+    assert (db.cpu() - bt.grad).abs().max().item() <= 2e-3 * max(1.0, bt.grad.abs().max().item())
+    if res:
+        assert (dres.float().cpu() - rt.grad).abs().max().item() <= 2 ** -8 * max(1.0, rt.grad.abs().max().item())
+
+
+def test_pool_backward_and_repack_bf16(cuda):
+    from computervision_codes_amd import ops
+    b, h, w, c = 2, 13, 18, 64
+    x = _rand((b, h, w, c), 1).to(BF)
+    x[0, 2:5, 2:5, :8] = 1.5                                        # ties: the first maximum in scan order takes the gradient
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    dy = _rand((b, ho, wo, c), 2).to(BF)
+    xt = x.float().permute(0, 3, 1, 2).clone().requires_grad_()
+    with torch.enable_grad():
+        F.max_pool2d(xt, 3, 2, 1).backward(dy.float().permute(0, 3, 1, 2))
+    dx = ops.maxpool3x3s2_bwd_bf16(x.to(cuda), dy.to(cuda))
+    ref = xt.grad.permute(0, 2, 3, 1)
+    assert (dx.float().cpu() - ref).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
+    df = _rand((3, 128), 3)
+    dxa = ops.avgpool_bwd_bf16(df.to(cuda), 3, 21, 128)
+    assert (dxa.float().cpu() - (df / 21)[:, None, :].expand(3, 21, 128)).abs().max().item() <= 2 ** -8 * float(df.abs().max()) / 21
+    # packed fp32 -> packed bf16 == packing the bf16-rounded weights directly
+    wt = _rand((128, 64, 3, 3), 4).to(cuda)
+    w32 = ops.pack_conv_weight(wt, None, torch.float32)
+    assert torch.equal(ops.repack_weight_bf16(w32, 128, 64, 3, 3), ops.pack_conv_weight(wt, None, BF))
+    w1 = _rand((64, 256, 1, 1), 5).to(cuda)
+    assert torch.equal(ops.repack_weight_bf16(ops.pack_conv_weight(w1, None, torch.float32), 64, 256, 1, 1), ops.pack_conv_weight(w1, None, BF))
