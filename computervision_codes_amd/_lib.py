@@ -38,6 +38,13 @@ class ConvDesc(C.Structure):
     ]
 
 
+class RefreshEntry(C.Structure):
+    """mt4_refresh_entry (include/mt4hip.h)"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("block0", C.c_int64), ("dst_bf16", C.c_int32), ("transposed", C.c_int32), ("cout", C.c_int32),
+                ("cin", C.c_int32), ("ntaps_dst", C.c_int32), ("tapw_src", C.c_int32), ("kpad_src", C.c_int32), ("tapw_dst", C.c_int32),
+                ("kpad_dst", C.c_int32), ("tap_map", C.c_int32 * 9)]
+
+
 class TcnDesc(C.Structure):
     """mirror of `mt4_tcn_desc` (include/mt4hip.h)"""
     _fields_ = [
@@ -98,6 +105,7 @@ SIGNATURES = {
     "mt4_wgrad_conv2d_bf16": (C.c_int, [_vp, _vp, _vp] + [_i32] * 9 + [_vp]),
     "mt4_maxpool3x3s2_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_avgpool_bwd_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "mt4_refresh_weights": (C.c_int, [_vp, _i32, C.c_int64, _vp]),
     "mt4_repack_weight_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_kd_mix_bwd_f32": (C.c_int, [_vp] * 9 + [_i32, _i32, _vp]),
     "mt4_tcn_conv": (C.c_int, [C.POINTER(TcnDesc), _vp]),

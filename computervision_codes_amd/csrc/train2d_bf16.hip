@@ -317,35 +317,54 @@ int launch_wgrad(WgK a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------ pooling backward, packed-weight copy
-// MaxPool2d(3,2,1) backward in gather form (bf16 has no float atomics worth using: a thread owns one INPUT element and sums the gradients of
-// the at most four windows whose first maximum -- (kh, kw) scan order, what torch's backward picks -- it is; one rounding)
+// MaxPool2d(3,2,1) backward in gather form (no atomics): a thread owns 8 channels of one INPUT pixel and sums the gradients of the at most four
+// windows whose first maximum -- (kh, kw) scan order, what torch's backward picks -- it is; one rounding.  16-byte loads throughout.
+__device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(u[e] << 16); f[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
+}
+
 __global__ void maxpool3x3s2_bwd_bf16_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, u16* __restrict__ dx, int B, int H, int W, int C,
                                              int Ho, int Wo) {
+    const int CV = C >> 3;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)B * H * W * C) return;
-    const int c = (int)(i % C);
-    long long r = i / C;
+    if (i >= (long long)B * H * W * CV) return;
+    const int cv = (int)(i % CV);
+    long long r = i / CV;
     const int w = (int)(r % W);
     r /= W;
     const int h = (int)(r % H), b = (int)(r / H);
-    float acc = 0.f;
+    float own[8], acc[8];
+    unpack8(*(const uint4*)(x + (((long long)b * H + h) * W + w) * C + cv * 8), own);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     for (int ho = h >> 1; ho <= ((h + 1) >> 1) && ho < Ho; ++ho)
         for (int wo = w >> 1; wo <= ((w + 1) >> 1) && wo < Wo; ++wo) {
-            float best = -INFINITY;
-            int bh = -1, bw = -1;
+            // this pixel takes the window's gradient in channel e iff no EARLIER position holds a value >= own[e] and no LATER one a value > own[e]
+            unsigned win = 0xffu;
             for (int kh = 0; kh < 3; ++kh) {
                 const int hh = 2 * ho - 1 + kh;
                 if ((unsigned)hh >= (unsigned)H) continue;
                 for (int kw = 0; kw < 3; ++kw) {
                     const int ww = 2 * wo - 1 + kw;
-                    if ((unsigned)ww >= (unsigned)W) continue;
-                    const float v = bf16_to_f32(x[(((long long)b * H + hh) * W + ww) * C + c]);
-                    if (v > best || bh < 0) { best = v; bh = hh; bw = ww; }
+                    if ((unsigned)ww >= (unsigned)W || (hh == h && ww == w)) continue;
+                    float v[8];
+                    unpack8(*(const uint4*)(x + (((long long)b * H + hh) * W + ww) * C + cv * 8), v);
+                    const bool before = hh < h || (hh == h && ww < w);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (before ? v[e] >= own[e] : v[e] > own[e]) win &= ~(1u << e);
                 }
             }
-            if (bh == h && bw == w) acc += bf16_to_f32(dy[(((long long)b * Ho + ho) * Wo + wo) * C + c]);
+            float g[8];
+            unpack8(*(const uint4*)(dy + (((long long)b * Ho + ho) * Wo + wo) * C + cv * 8), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (win & (1u << e)) acc[e] += g[e];
         }
-    dx[i] = f32_to_bf16(acc);
+    *(uint4*)(dx + (((long long)b * H + h) * W + w) * C + cv * 8) =
+        make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
 }
 
 __global__ void avgpool_bwd_bf16_kernel(const float* __restrict__ df, u16* __restrict__ dx, int HW, int C, long long n4) {
@@ -371,7 +390,39 @@ __global__ void repack_bf16_kernel(const float* __restrict__ src, u16* __restric
     dst[idx] = f32_to_bf16(v);
 }
 
+// ------------------------------------------------------------------------------------------------ derived weight matrices in one launch
+// After every optimizer step the trainer rebuilds, from the fp32 master weights, the matrices its kernels read: bf16 copies for the forward
+// convolutions, transposed (tap-flipped) copies for the stride-1 data gradients, the four sub-pixel phase kernels of a stride-2 3x3 data
+// gradient -- some 200 small matrices.  One launch walks a table of them (a launch each cost 1.5 ms per step of ~4 us launches).
+__global__ void refresh_weights_kernel(const mt4_refresh_entry* __restrict__ tab, int n_entries) {
+    int lo = 0, hi = n_entries - 1;                        // the entry of this block: last one whose first block is <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].block0 <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const mt4_refresh_entry e = tab[lo];
+    const int rows = e.transposed ? e.cin : e.cout, cols = e.transposed ? e.cout : e.cin;
+    const long long idx = ((long long)blockIdx.x - e.block0) * 256 + threadIdx.x;
+    if (idx >= (long long)rows * e.kpad_dst) return;
+    const int row = (int)(idx / e.kpad_dst), kk = (int)(idx - (long long)row * e.kpad_dst);
+    const int tp = kk / e.tapw_dst, col = kk - tp * e.tapw_dst;
+    float v = 0.f;
+    if (tp < e.ntaps_dst && col < cols) {
+        const int n = e.transposed ? col : row, c = e.transposed ? row : col;
+        v = e.src[(long long)n * e.kpad_src + e.tap_map[tp] * e.tapw_src + c];
+    }
+    if (e.dst_bf16) ((u16*)e.dst)[idx] = f32_to_bf16(v);
+    else ((float*)e.dst)[idx] = v;
+}
+
 }  // namespace
+
+extern "C" int mt4_refresh_weights(const mt4_refresh_entry* table_dev, int32_t n_entries, int64_t n_blocks, void* stream) {
+    mt4_clear_error();
+    if (!table_dev || n_entries <= 0 || n_blocks <= 0 || n_blocks > 0x7fffffffLL) return MT4_EINVAL;
+    hipLaunchKernelGGL(refresh_weights_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n_entries);
+    return mt4_check_launch();
+}
 
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" int mt4_bn_stats_t(const void* x, int32_t x_dtype, double* sums_zeroed, float* mean, float* invstd, float* running_mean, float* running_var,
@@ -453,8 +504,9 @@ extern "C" int mt4_wgrad_conv2d_bf16(const void* dy, const void* x, float* dw_pa
 extern "C" int mt4_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
     mt4_clear_error();
     if (!x || !dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0) return MT4_EINVAL;
+    if ((C & 7) || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15)) return MT4_EALIGN;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long long n = (long long)B * H * W * C;
+    const long long n = (long long)B * H * W * (C / 8);
     hipLaunchKernelGGL(maxpool3x3s2_bwd_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u16*)x, (const u16*)dy,
                        (u16*)dx, B, H, W, C, Ho, Wo);
     return mt4_check_launch();

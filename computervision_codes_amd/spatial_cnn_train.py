@@ -34,17 +34,23 @@ _POS_W = {"i": TOOL_W, "v": VERB_W, "t": TARGET_W, "ivt": [1.0] * 100}
 class _Unit:
     """conv + BatchNorm (+ReLU) with its parameter / gradient views"""
     __slots__ = ("name", "bn", "cin", "cout", "k", "stride", "pad", "w", "gw", "gamma", "beta", "ggamma", "gbeta", "rmean", "rvar", "wt", "phase_w",
-                 "sums_f", "sums_b")
+                 "sums_f", "sums_b", "w16", "wt16", "phase_w16")
 
 
 class SpatialCnnTrainer:
+    op16 = False                # (class defaults: GEMM operands fp32; no derived-weight table built yet)
+    _refresh_table = None
     def __init__(self, network: str = "resnet50", lr: float = 0.01, weight_decay: float = 1e-5, rates: Sequence[float] = (1.0, 1.0, 1.0),
                  temp: float = 4.0, device: str = "cuda", process_group=None, overlap: bool = True, teacher_dim: int = 1536,
-                 loss_type: str = "all"):
+                 loss_type: str = "all", operand_dtype: torch.dtype = torch.float32):
         """loss_type 'all': the distillation recipe (four heads, KD branch, hard + soft + feature losses: `run.py:180-192`);
         'i' | 'v' | 't': a single-task student -- only that classifier exists (`network.py:34-41`) and the loss is its BCE alone
         (`run.py:165-179`)"""
         assert loss_type in ("all", "i", "v", "t")
+        assert operand_dtype in (torch.float32, torch.bfloat16)
+        # bfloat16: the convolutions' GEMM operands (activations, activation gradients, weight copies) are bf16, sums fp32 / fp64, master
+        # weights + gradients + SGD fp32 (csrc/train2d_bf16.hip); the stem's 7x7x3 convolution and the heads / KD branch stay fp32
+        self.op16 = operand_dtype == torch.bfloat16
         self.loss_type = loss_type
         self.heads = _ALL_HEADS if loss_type == "all" else tuple(h for h in _ALL_HEADS if h[0] == loss_type)
         self.NH = sum(k for _, k in self.heads)
@@ -123,6 +129,7 @@ class SpatialCnnTrainer:
             u.rmean, u.rvar = sd[bn + ".running_mean"].float().to(dev).clone(), sd[bn + ".running_var"].float().to(dev).clone()
             self.nbt[bn] = int(sd[bn + ".num_batches_tracked"])
             u.wt, u.phase_w = None, None
+            u.w16, u.wt16, u.phase_w16 = None, None, None
             self.units[conv] = u
             self._ranges[bucket][1] = off
             trained |= {conv + ".weight", bn + ".weight", bn + ".bias", bn + ".running_mean", bn + ".running_var", bn + ".num_batches_tracked"}
@@ -154,32 +161,66 @@ class SpatialCnnTrainer:
         self._graphs: Dict[tuple, object] = {}
         self._extra = {k: sd[k].detach().clone() for k, _ in self._table if k not in trained}   # the trunk's unused 1000-way fc
         self.pos_weight = torch.tensor(sum((_POS_W[t] for t, _ in self.heads), []), dtype=F32, device=dev)
+        self._refresh_table = None
         self._refresh_transposed()
         return self
 
     def _refresh_transposed(self):
-        """weights of the data-gradient convolutions, rebuilt from the master weights after every update"""
-        for u in self.units.values():
-            if u.cin == 4:
-                continue   # stem: the image needs no gradient
-            taps = u.k * u.k
-            if u.stride == 1 or u.k == 1:
-                u.wt = ops.transpose_pack_conv1d(u.w, u.cout, u.cin, taps, out=u.wt)
-            else:   # 3x3 stride 2 pad 1: sub-pixel phases (device index/permute copies of 1-4 taps each)
-                w9 = u.w[:, :9 * u.cin].view(u.cout, 3, 3, u.cin)
-                sel = {0: [1], 1: [2, 0]}   # phase parity -> original taps, in the order of the data-gradient offsets 0, +1
-                first = u.phase_w is None
-                if first:
-                    u.phase_w = {}
-                for ph in (0, 1):
-                    for pw in (0, 1):
-                        sub = w9[:, sel[ph]][:, :, sel[pw]]                               # [Cout, kh', kw', Cin]
-                        sub = sub.permute(3, 1, 2, 0).contiguous()                        # [Cin, kh', kw', Cout]
-                        packed = ops.pack_conv_weight(sub.permute(0, 3, 1, 2).contiguous(), None, F32)
-                        if first:
-                            u.phase_w[(ph, pw)] = (packed, len(sel[ph]), len(sel[pw]))
-                        else:                                                             # in place: captured graphs keep the address
-                            u.phase_w[(ph, pw)][0].copy_(packed)
+        """every weight matrix derived from the master weights -- data-gradient operators (transposed with flipped taps; the four sub-pixel phase
+        kernels of a stride-2 3x3), in bf16 mode also the bf16 copies the forward convolutions read -- rebuilt by ONE launch over a table
+        (`mt4_refresh_weights`; a launch per matrix was ~350 launches = 1.5 ms per step).  Destinations are allocated once: captured graphs keep
+        their addresses."""
+        if getattr(self, "_refresh_table", None) is None:
+            import ctypes as C
+            from ._lib import RefreshEntry
+            dt = torch.bfloat16 if self.op16 else F32
+            entries, block = [], 0
+
+            def add(u, dst, transposed, taps_dst, tap_map):
+                nonlocal block
+                e = RefreshEntry()
+                e.src, e.dst, e.block0 = u.w.data_ptr(), dst.data_ptr(), block
+                e.dst_bf16, e.transposed, e.cout, e.cin, e.ntaps_dst = int(dst.dtype == torch.bfloat16), int(transposed), u.cout, u.cin, taps_dst
+                e.tapw_src, e.kpad_src = (u.cin + 3) // 4 * 4, u.w.shape[1]
+                cols = u.cout if transposed else u.cin
+                e.tapw_dst, e.kpad_dst = (cols + 7) // 8 * 8 if dst.dtype == torch.bfloat16 else (cols + 3) // 4 * 4, dst.shape[1]
+                for i, t in enumerate(tap_map):
+                    e.tap_map[i] = t
+                entries.append(e)
+                block += (dst.numel() + 255) // 256
+
+            for u in self.units.values():
+                if u.cin == 4:
+                    continue   # stem: the image needs no gradient; it stays fp32
+                taps = u.k * u.k
+                if self.op16:
+                    u.w16 = torch.empty((u.cout, ops.packed_k(u.cin, u.k, u.k, dt)), dtype=dt, device=self.dev)
+                    add(u, u.w16, False, taps, range(taps))
+                if u.stride == 1 or u.k == 1:
+                    wt = torch.empty((u.cin, ops.packed_k(u.cout, u.k, u.k, dt)), dtype=dt, device=self.dev)
+                    add(u, wt, True, taps, [taps - 1 - t for t in range(taps)])
+                    if self.op16:
+                        u.wt16 = wt
+                    else:
+                        u.wt = wt
+                else:   # 3x3 stride 2 pad 1: sub-pixel phases, phase parity -> original taps in the order of the data-gradient offsets 0, +1
+                    sel = {0: [1], 1: [2, 0]}
+                    ph_w = {}
+                    for ph in (0, 1):
+                        for pw in (0, 1):
+                            khs, kws = len(sel[ph]), len(sel[pw])
+                            dst = torch.empty((u.cin, ops.packed_k(u.cout, khs, kws, dt)), dtype=dt, device=self.dev)
+                            add(u, dst, True, khs * kws, [sel[ph][a] * 3 + sel[pw][b] for a in range(khs) for b in range(kws)])
+                            ph_w[(ph, pw)] = (dst, khs, kws)
+                    if self.op16:
+                        u.phase_w16 = ph_w
+                    else:
+                        u.phase_w = ph_w
+            raw = b"".join(bytes(e) for e in entries)
+            self._refresh_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
+            self._refresh_n, self._refresh_blocks = len(entries), block
+        from ._lib import lib, check
+        check(lib.mt4_refresh_weights(self._refresh_table.data_ptr(), self._refresh_n, self._refresh_blocks, ops._stream()), "mt4_refresh_weights")
         # (the linear layers' data gradients transpose their small weights on the fly in _linear_bwd)
 
     def running_stats(self) -> Dict[str, torch.Tensor]:
@@ -233,11 +274,16 @@ class SpatialCnnTrainer:
 
     # ------------------------------------------------------------------ building blocks
     def _fwd_unit(self, u: _Unit, x, residual=None, relu=True, saved=None):
-        z = ops.conv_nhwc(x, u.w, None, kh=u.k, kw=u.k, stride=(u.stride, u.stride), pad=(u.pad, u.pad))
+        w = u.w16 if (self.op16 and u.cin != 4) else u.w            # (bf16 mode: the stem reads the fp32 image with its fp32 weights)
+        z = ops.conv_nhwc(x, w, None, kh=u.k, kw=u.k, stride=(u.stride, u.stride), pad=(u.pad, u.pad))
         b, ho, wo, c = z.shape
         z2 = z.view(-1, c)
-        mean, invstd = ops.bn_stats(z2, u.rmean, u.rvar, sums=u.sums_f)
-        a = ops.bn_apply(z2, mean, invstd, u.gamma, u.beta, residual.view(-1, c) if residual is not None else None, relu).view(b, ho, wo, c)
+        if self.op16:
+            mean, invstd = ops.bn_stats_t(z2, u.rmean, u.rvar, sums=u.sums_f)
+            a = ops.bn_apply_t(z2, mean, invstd, u.gamma, u.beta, residual.view(-1, c) if residual is not None else None, relu).view(b, ho, wo, c)
+        else:
+            mean, invstd = ops.bn_stats(z2, u.rmean, u.rvar, sums=u.sums_f)
+            a = ops.bn_apply(z2, mean, invstd, u.gamma, u.beta, residual.view(-1, c) if residual is not None else None, relu).view(b, ho, wo, c)
         if saved is not None:
             saved.append((u, x, z, mean, invstd, a, relu))
         return a
@@ -245,18 +291,19 @@ class SpatialCnnTrainer:
     def _dgrad(self, u: _Unit, dz, x_shape, residual=None):
         """gradient w.r.t. the unit's input [B,H,W,Cin] from dz [B,Ho,Wo,Cout]"""
         b, h, w, cin = x_shape
+        wt, phase_w, dt = (u.wt16, u.phase_w16, dz.dtype) if self.op16 else (u.wt, u.phase_w, F32)
         if u.stride == 1:
             p = u.k - 1 - u.pad
-            return ops.conv_nhwc(dz, u.wt, None, kh=u.k, kw=u.k, pad=(p, p), residual=residual)
+            return ops.conv_nhwc(dz, wt, None, kh=u.k, kw=u.k, pad=(p, p), residual=residual)
         assert h % 2 == 0 and w % 2 == 0, "stride-2 data gradient is built for even input sizes"
         ho, wo = dz.shape[1], dz.shape[2]
-        dx = torch.zeros((b, h, w, cin), dtype=F32, device=dz.device) if (u.k == 1 and residual is None) else \
-            (residual.clone() if u.k == 1 else torch.empty((b, h, w, cin), dtype=F32, device=dz.device))
+        dx = torch.zeros((b, h, w, cin), dtype=dt, device=dz.device) if (u.k == 1 and residual is None) else \
+            (residual.clone() if u.k == 1 else torch.empty((b, h, w, cin), dtype=dt, device=dz.device))
         if u.k == 1:   # dX[2a][2b] = W^T dY[a][b]; every other position keeps the residual (or zero)
             rm = self._row_map(ho, wo, w, 0, 0)
-            ops.conv_nhwc(dz, u.wt, None, kh=1, kw=1, residual=dx if residual is not None else None, out=dx, out_row_map=rm, out_rows_per_image=h * w)
+            ops.conv_nhwc(dz, wt, None, kh=1, kw=1, residual=dx if residual is not None else None, out=dx, out_row_map=rm, out_rows_per_image=h * w)
             return dx
-        for (ph, pw), (wsub, khs, kws) in u.phase_w.items():
+        for (ph, pw), (wsub, khs, kws) in phase_w.items():
             rm = self._row_map(ho, wo, w, ph, pw)
             ops.conv_nhwc(dz, wsub, None, kh=khs, kw=kws, out_hw=(ho, wo), residual=residual, out=dx, out_row_map=rm, out_rows_per_image=h * w)
         return dx
@@ -272,10 +319,14 @@ class SpatialCnnTrainer:
     def _bwd_unit(self, rec, dy, residual_for_dx=None, want_dres=False, need_dx=True):
         u, x, z, mean, invstd, a, relu = rec
         c = z.shape[-1]
-        dz, dres = ops.bn_backward(dy.reshape(-1, c), a.view(-1, c) if relu else None, z.view(-1, c), mean, invstd, u.gamma, u.ggamma, u.gbeta,
-                                   relu=relu, want_dres=want_dres, sums=u.sums_b)
+        bnb = ops.bn_backward_t if self.op16 else ops.bn_backward
+        dz, dres = bnb(dy.reshape(-1, c), a.view(-1, c) if relu else None, z.view(-1, c), mean, invstd, u.gamma, u.ggamma, u.gbeta,
+                       relu=relu, want_dres=want_dres, sums=u.sums_b)
         dz = dz.view(z.shape)
-        ops.wgrad_conv2d(dz, x, u.gw, u.k, u.k, (u.stride, u.stride), (u.pad, u.pad), zero=False)     # G is zeroed once per step
+        if self.op16 and u.cin != 4:
+            ops.wgrad_conv2d_bf16(dz, x, u.gw, u.k, u.stride)                                         # (adds to G, zeroed once per step)
+        else:
+            ops.wgrad_conv2d(dz, x, u.gw, u.k, u.k, (u.stride, u.stride), (u.pad, u.pad), zero=False)     # G is zeroed once per step
         dx = self._dgrad(u, dz, x.shape, residual_for_dx) if need_dx else None
         return dx, (dres.view(z.shape) if dres is not None else None)
 
@@ -447,7 +498,7 @@ class SpatialCnnTrainer:
                 self._linear_bwd(m, dte, t, need_dx=False)
         self._reduce_bucket("heads")
         # ---- backward through the trunk
-        dx = ops.avgpool_bwd(dfeat, Bh, Hh * Wh, C).view(Bh, Hh, Wh, C)
+        dx = (ops.avgpool_bwd_bf16 if self.op16 else ops.avgpool_bwd)(dfeat, Bh, Hh * Wh, C).view(Bh, Hh, Wh, C)
         for bi_, (first, has_ds, bott, li) in reversed(list(enumerate(blocks))):
             recs = saved[first:first + (1 if has_ds else 0) + (3 if bott else 2)]
             main = recs[1:] if has_ds else recs
@@ -461,7 +512,7 @@ class SpatialCnnTrainer:
                 dx, _ = self._bwd_unit(main[0], d, residual_for_dx=dres)
             if bi_ == 0 or blocks[bi_ - 1][3] != li:      # first block of the layer done: the layer's gradients are complete
                 self._reduce_bucket(f"layer{li}")
-        da0 = ops.maxpool3x3s2_bwd(a0, dx)
+        da0 = (ops.maxpool3x3s2_bwd_bf16 if self.op16 else ops.maxpool3x3s2_bwd)(a0, dx)
         self._bwd_unit(saved[0], da0, need_dx=False)
         self._reduce_bucket("stem")
         return col_loss, soft, kdl

@@ -306,6 +306,20 @@ int mt4_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, void* dx, int32_t B
 int mt4_avgpool_bwd_bf16(const float* dfeat, void* dx, int32_t B, int32_t HW, int32_t C, void* stream);
 /* packed fp32 weight matrix (mt4_pack_conv_weight(MT4_F32) layout, e.g. the master weights or their transposed copies) -> the packed bf16
  * layout of the same geometry */
+/* One launch that rebuilds every weight matrix derived from the fp32 master weights (after an optimizer step): entry i fills dst (fp32 or bf16,
+ * packed layout: rows x (ntaps_dst taps of tapw_dst elements, zero padded to kpad_dst)) from the packed master matrix src ([cout][kpad_src],
+ * taps of tapw_src elements):
+ *     transposed == 0:  dst[n][t][c] = src[n][tap_map[t]][c]      (a bf16 copy of a forward weight)
+ *     transposed == 1:  dst[c][t][n] = src[n][tap_map[t]][c]      (data-gradient operators: flipped taps, sub-pixel phases of a strided conv)
+ * block0 = the first workgroup of the entry (256 elements of dst per workgroup; entries ordered by block0).  The table lives in device memory. */
+typedef struct {
+    const float* src;
+    void* dst;
+    int64_t block0;
+    int32_t dst_bf16, transposed, cout, cin, ntaps_dst, tapw_src, kpad_src, tapw_dst, kpad_dst;
+    int32_t tap_map[9];
+} mt4_refresh_entry;
+int mt4_refresh_weights(const mt4_refresh_entry* table_dev, int32_t n_entries, int64_t n_blocks, void* stream);
 int mt4_repack_weight_bf16(const float* w_f32_packed, void* w_bf16_packed, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
