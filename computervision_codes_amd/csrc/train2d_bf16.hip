@@ -163,20 +163,15 @@ constexpr int WG_ROWB = 128;
 
 __device__ __forceinline__ int wg_swz(int row, int chunk) { return row * WG_ROWB + ((chunk ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1)) << 4); }
 
-// two fragments (two channel tiles) = four transposed reads, one wait.  (The reads are issued from inline asm -- there is no builtin -- so the
-// compiler cannot track their latency: the statement only returns once the data is in the registers.)
-__device__ __forceinline__ void ds_read_tr_x4(const char* p0, const char* p1, const char* p2, const char* p3, uint4& f0, uint4& f1) {
-    uint2 a, b, c, d;
-    const unsigned a0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p0;
-    const unsigned a1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p1;
-    const unsigned a2 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p2;
-    const unsigned a3 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p3;
-    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
-                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
-                 : "memory");
-    f0 = make_uint4(a.x, a.y, b.x, b.y);
-    f1 = make_uint4(c.x, c.y, d.x, d.y);
+// one MFMA fragment = two transposed reads (4 + 4 reduction elements per lane), through the compiler's builtin so that it schedules the reads
+// against the MFMAs and counts lgkmcnt itself
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint4 ds_read_tr_frag(const char* p_lo, const char* p_hi) {
+    const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(uintptr_t)p_lo);
+    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(uintptr_t)p_hi);
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 
 struct WgK {
@@ -188,129 +183,168 @@ struct WgK {
     int tiles_h, tiles_w, ntiles, nsplit, cin_tiles;
 };
 
-template <int K, int S, int TH>
+template <int K, int S, int TH, int BMT, int BNT>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgK a) {
+    constexpr bool PREFETCH = true;
+    static_assert(!(K == 3 && BMT * BNT > 1), "3x3: 64 x 64 tiles (registers)");
     constexpr int PAD = K / 2;
     constexpr int IW = S * 15 + K;                              // input pixels per tile row (with the column halo)
     constexpr int PITCH = (IW + 15) / 16 * 16;                  // pixels per LDS row of the input tile
-    constexpr int DY_BYTES = TH * 16 * WG_ROWB;
+    constexpr int DY_BYTES = TH * 16 * WG_ROWB;                 // one 64-channel plane of the dy tile
+    constexpr int X_BYTES = TH * PITCH * WG_ROWB;               // one 64-channel plane of the input tile
+    constexpr int MT = 2 * BMT, NT = 2 * BNT;                   // MFMA tiles per wave: the workgroup tile is (64 BMT) x (64 BNT), waves 2 x 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sdy = smem;
-    char* const sx = smem + DY_BYTES;
+    char* const sx = smem + BMT * DY_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
-    // workgroup = (64 x 64 (n, c) tile, kernel row kh, share of the spatial tiles): a kernel row's K taps = K x 16 accumulator registers
+    // workgroup = ((64 BMT) x (64 BNT) (n, c) tile, kernel row kh, share of the spatial tiles): a kernel row's K taps = K x MT x NT accumulators
     int bid = blockIdx.x;
     const int split = bid % a.nsplit;
     bid /= a.nsplit;
     const int kh = bid % K;
     const int pair = bid / K;
-    const int n0 = (pair / a.cin_tiles) * 64, c0 = (pair % a.cin_tiles) * 64;
+    const int n0 = (pair / a.cin_tiles) * (64 * BMT), c0 = (pair % a.cin_tiles) * (64 * BNT);
 
-    f32x4 acc[K][2][2];
+    f32x4 acc[K][MT][NT];
 #pragma unroll
     for (int t = 0; t < K; ++t)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[t][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int ni = 0; ni < NT; ++ni) acc[t][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // per-lane fragment offsets.  A block's row for this lane: output pixel (tile row 2 s + (g >> 1), column 8 (g & 1) + 4 h + q); it supplies
-    // the 8 bytes of channels 4 p .. 4 p + 3 of the fragment's 16 channels: chunk (ch0 >> 3) + (p >> 1), half p & 1
-    int yo[2][2], xo[K][2][2];            // [half h][channel tile of the wave]
+    // the 8 bytes of channels 4 p .. 4 p + 3 of the fragment's 16 channels: plane ch / 64, chunk (ch % 64) / 8 + (p >> 1), half p & 1
+    int yo[2][MT], xo[K][2][NT];          // [half h][channel tile of the wave]
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int col = 8 * (g & 1) + 4 * h + q;
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-            yo[h][ti] = wg_swz((g >> 1) * 16 + col, (wm * 32 + ti * 16) / 8 + (p >> 1)) + (p & 1) * 8;
+        for (int mi = 0; mi < MT; ++mi) {
+            const int ch = wm * (32 * BMT) + mi * 16;
+            yo[h][mi] = (ch >> 6) * DY_BYTES + wg_swz((g >> 1) * 16 + col, (ch & 63) / 8 + (p >> 1)) + (p & 1) * 8;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const int ch = wn * (32 * BNT) + ni * 16;
 #pragma unroll
             for (int kw = 0; kw < K; ++kw)
-                xo[kw][h][ti] = wg_swz(S * col + kw, (wn * 32 + ti * 16) / 8 + (p >> 1)) + (p & 1) * 8 + (g >> 1) * (PITCH * WG_ROWB);
+                xo[kw][h][ni] = (ch >> 6) * X_BYTES + wg_swz(S * col + kw, (ch & 63) / 8 + (p >> 1)) + (p & 1) * 8 + (g >> 1) * (PITCH * WG_ROWB);
         }
     }
 
     const int ld_row = tid >> 3, ld_chunk = tid & 7;
-    for (int t = split; t < a.ntiles; t += a.nsplit) {
+    // staging through registers, one tile ahead: the next tile's global loads are in flight while this tile's MFMAs run
+    constexpr int NY = TH * 16 / 32, NX = TH * PITCH / 32;      // row passes of 32 rows (256 threads x 16 bytes = 32 rows of 128 B)
+    uint4 ry[NY][BMT], rx[NX][BNT];
+    auto load_tile = [&](int t) {
         const int tpi = a.tiles_h * a.tiles_w;
         const int img = t / tpi;
         const int tr = t - img * tpi;
         const int th = tr / a.tiles_w;
         const int ho0 = th * TH, wo0 = (tr - th * a.tiles_w) * 16;
-        __syncthreads();                                   // the previous tile's fragment reads are done
-        // ---- dy tile: TH x 16 output pixels x 64 output channels
-        for (int r = ld_row; r < TH * 16; r += 32) {
+        // dy tile: TH x 16 output pixels x (64 BMT) output channels
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int r = ld_row + 32 * i;
             const int ho = ho0 + (r >> 4), wo = wo0 + (r & 15);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ho < a.Ho && wo < a.Wo) v = *(const uint4*)(a.dy + (((long long)img * a.Ho + ho) * a.Wo + wo) * a.Cout + n0 + ld_chunk * 8);
-            *(uint4*)(sdy + wg_swz(r, ld_chunk)) = v;
+            const bool ok = ho < a.Ho && wo < a.Wo;
+            const u16* src = a.dy + (((long long)img * a.Ho + ho) * a.Wo + wo) * a.Cout + n0 + ld_chunk * 8;
+#pragma unroll
+            for (int pm = 0; pm < BMT; ++pm) {
+                ry[i][pm] = make_uint4(0, 0, 0, 0);
+                if (ok) ry[i][pm] = *(const uint4*)(src + pm * 64);
+            }
         }
-        // ---- input tile for this kernel row: LDS row iy = the input row of output row ho0 + iy, IW pixels (rows of PITCH pixels), zeros outside
-        for (int r = ld_row; r < TH * PITCH; r += 32) {
+        // input tile for this kernel row: LDS row iy = the input row of output row ho0 + iy, IW pixels (rows of PITCH pixels), zeros outside
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int r = ld_row + 32 * i;
             const int iy = r / PITCH, ix = r - iy * PITCH;
             const int hi = S * (ho0 + iy) - PAD + kh, wi = S * wo0 - PAD + ix;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ix < IW && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
-                v = *(const uint4*)(a.x + (((long long)img * a.H + hi) * a.W + wi) * a.Cin + c0 + ld_chunk * 8);
-            *(uint4*)(sx + wg_swz(r, ld_chunk)) = v;
+            const bool ok = ix < IW && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const u16* src = a.x + (((long long)img * a.H + hi) * a.W + wi) * a.Cin + c0 + ld_chunk * 8;
+#pragma unroll
+            for (int pn = 0; pn < BNT; ++pn) {
+                rx[i][pn] = make_uint4(0, 0, 0, 0);
+                if (ok) rx[i][pn] = *(const uint4*)(src + pn * 64);
+            }
         }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NY; ++i)
+#pragma unroll
+            for (int pm = 0; pm < BMT; ++pm) *(uint4*)(sdy + pm * DY_BYTES + wg_swz(ld_row + 32 * i, ld_chunk)) = ry[i][pm];
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int pn = 0; pn < BNT; ++pn) *(uint4*)(sx + pn * X_BYTES + wg_swz(ld_row + 32 * i, ld_chunk)) = rx[i][pn];
+    };
+    if (split < a.ntiles) load_tile(split);
+    for (int t = split; t < a.ntiles; t += a.nsplit) {
+        __syncthreads();                                   // the previous tile's fragment reads are done
+        store_tile();
         __syncthreads();
+        if (PREFETCH && t + a.nsplit < a.ntiles) load_tile(t + a.nsplit);
 #pragma unroll
         for (int s = 0; s < TH / 2; ++s) {
-            uint4 fa[2];
-            {
-                const char* yb = sdy + s * (32 * WG_ROWB);
-                ds_read_tr_x4(yb + yo[0][0], yb + yo[1][0], yb + yo[0][1], yb + yo[1][1], fa[0], fa[1]);
-            }
+            uint4 fa[MT];
+            const char* yb = sdy + s * (32 * WG_ROWB);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) fa[mi] = ds_read_tr_frag(yb + yo[0][mi], yb + yo[1][mi]);
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) {
-                uint4 fb[2];
-                {
-                    const char* xb = sx + (2 * s) * (PITCH * WG_ROWB);
-                    ds_read_tr_x4(xb + xo[kw][0][0], xb + xo[kw][1][0], xb + xo[kw][0][1], xb + xo[kw][1][1], fb[0], fb[1]);
-                }
+                uint4 fb[NT];
+                const char* xb = sx + (2 * s) * (PITCH * WG_ROWB);
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int ni = 0; ni < NT; ++ni) fb[ni] = ds_read_tr_frag(xb + xo[kw][0][ni], xb + xo[kw][1][ni]);
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni)
                         acc[kw][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[mi]), __builtin_bit_cast(bf16x8_t, fb[ni]),
                                                                                   acc[kw][mi][ni], 0, 0, 0);
             }
         }
+        if (!PREFETCH && t + a.nsplit < a.ntiles) load_tile(t + a.nsplit);      // (no registers to spare: staged after the MFMAs)
     }
-    // ---- dW += the wave's 32 x K x 32 block: lane (r16 = c, q4 = lane >> 4) holds output channels 4 q4 + e of input channel r16
+    // ---- dW += the wave's block: lane (r16 = c, q4 = lane >> 4) holds output channels 4 q4 + e of input channel r16
     const int r16 = lane & 15, q4 = lane >> 4;
 #pragma unroll
     for (int kw = 0; kw < K; ++kw)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int n = n0 + wm * 32 + mi * 16 + q4 * 4 + e;
-                    const int c = c0 + wn * 32 + ni * 16 + r16;
+                    const int n = n0 + wm * (32 * BMT) + mi * 16 + q4 * 4 + e;
+                    const int c = c0 + wn * (32 * BNT) + ni * 16 + r16;
                     atomicAdd(a.dw + (long long)n * a.kpad + (kh * K + kw) * a.tapw + c, acc[kw][mi][ni][e]);
                 }
 }
 
-template <int K, int S, int TH>
+template <int K, int S, int TH, int BMT, int BNT>
 int launch_wgrad(WgK a, hipStream_t stream) {
     constexpr int IW = S * 15 + K, PITCH = (IW + 15) / 16 * 16;
-    constexpr int LDS = TH * 16 * WG_ROWB + TH * PITCH * WG_ROWB;
+    constexpr int LDS = BMT * TH * 16 * WG_ROWB + BNT * TH * PITCH * WG_ROWB;
     static_assert(LDS <= 80 * 1024, "two workgroups per CU");
     a.tiles_h = cdiv(a.Ho, TH);
     a.tiles_w = cdiv(a.Wo, 16);
     a.ntiles = a.B * a.tiles_h * a.tiles_w;
-    a.cin_tiles = a.Cin / 64;
-    const int pairs = (a.Cout / 64) * a.cin_tiles * K;
-    int nsplit = (1024 + pairs - 1) / pairs;
+    a.cin_tiles = a.Cin / (64 * BNT);
+    const int pairs = (a.Cout / (64 * BMT)) * a.cin_tiles * K;
+    // workgroups per launch: every one ends with (64 BMT)(64 BNT) K fp32 atomics, so as few as keep the CUs busy (two per CU)
+    const int target = MT4_ENV_INT("MT4_WGRAD_WGS", 512);
+    int nsplit = (target + pairs - 1) / pairs;
     if (nsplit > a.ntiles) nsplit = a.ntiles;
     if (nsplit < 1) nsplit = 1;
     a.nsplit = nsplit;
-    auto fn = wgrad_bf16_kernel<K, S, TH>;
+    auto fn = wgrad_bf16_kernel<K, S, TH, BMT, BNT>;
     MT4_RAISE_LDS(fn);
     hipLaunchKernelGGL(fn, dim3((unsigned)(pairs * nsplit)), dim3(256), LDS, stream, a);
     return mt4_check_launch();
@@ -394,25 +428,51 @@ __global__ void repack_bf16_kernel(const float* __restrict__ src, u16* __restric
 // After every optimizer step the trainer rebuilds, from the fp32 master weights, the matrices its kernels read: bf16 copies for the forward
 // convolutions, transposed (tap-flipped) copies for the stride-1 data gradients, the four sub-pixel phase kernels of a stride-2 3x3 data
 // gradient -- some 200 small matrices.  One launch walks a table of them (a launch each cost 1.5 ms per step of ~4 us launches).
-__global__ void refresh_weights_kernel(const mt4_refresh_entry* __restrict__ tab, int n_entries) {
+__global__ __launch_bounds__(256) void refresh_weights_kernel(const mt4_refresh_entry* __restrict__ tab, int n_entries) {
+    // a workgroup moves one 32 (n) x 32 (c) tile of one tap through LDS: reads coalesced along c, writes coalesced along the destination's
+    // fast index (n when transposed).  Only valid elements are written: the destinations' padding was zeroed once, at allocation.
+    __shared__ float tile[32][33];
     int lo = 0, hi = n_entries - 1;                        // the entry of this block: last one whose first block is <= blockIdx.x
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (tab[mid].block0 <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const mt4_refresh_entry e = tab[lo];
-    const int rows = e.transposed ? e.cin : e.cout, cols = e.transposed ? e.cout : e.cin;
-    const long long idx = ((long long)blockIdx.x - e.block0) * 256 + threadIdx.x;
-    if (idx >= (long long)rows * e.kpad_dst) return;
-    const int row = (int)(idx / e.kpad_dst), kk = (int)(idx - (long long)row * e.kpad_dst);
-    const int tp = kk / e.tapw_dst, col = kk - tp * e.tapw_dst;
-    float v = 0.f;
-    if (tp < e.ntaps_dst && col < cols) {
-        const int n = e.transposed ? col : row, c = e.transposed ? row : col;
-        v = e.src[(long long)n * e.kpad_src + e.tap_map[tp] * e.tapw_src + c];
+    int b = (int)((long long)blockIdx.x - e.block0);
+    const int ct = (e.cin + 31) / 32, nt = (e.cout + 31) / 32;
+    const int tc = b % ct;
+    b /= ct;
+    const int tn = b % nt, tp = b / nt;
+    const int n0 = tn * 32, c0 = tc * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = c0 + tx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i;
+        tile[ty + 8 * i][tx] = (n < e.cout && c < e.cin) ? e.src[(long long)n * e.kpad_src + e.tap_map[tp] * e.tapw_src + c] : 0.f;
     }
-    if (e.dst_bf16) ((u16*)e.dst)[idx] = f32_to_bf16(v);
-    else ((float*)e.dst)[idx] = v;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        long long o;
+        float v;
+        bool ok;
+        if (e.transposed) {
+            const int cc = c0 + ty + 8 * i, nn = n0 + tx;
+            ok = cc < e.cin && nn < e.cout;
+            o = (long long)cc * e.kpad_dst + tp * e.tapw_dst + nn;
+            v = tile[tx][ty + 8 * i];
+        } else {
+            const int nn = n0 + ty + 8 * i;
+            ok = nn < e.cout && c < e.cin;
+            o = (long long)nn * e.kpad_dst + tp * e.tapw_dst + c;
+            v = tile[ty + 8 * i][tx];
+        }
+        if (ok) {
+            if (e.dst_bf16) ((u16*)e.dst)[o] = f32_to_bf16(v);
+            else ((float*)e.dst)[o] = v;
+        }
+    }
 }
 
 }  // namespace
@@ -495,10 +555,21 @@ extern "C" int mt4_wgrad_conv2d_bf16(const void* dy, const void* x, float* dw_pa
     a.kpad = (int)mt4_conv_packed_k(Cin, K, K, MT4_F32);
     a.tapw = (Cin + 3) / 4 * 4;
     hipStream_t s = (hipStream_t)stream;
-    if (K == 1 && stride == 1) return launch_wgrad<1, 1, 8>(a, s);
-    if (K == 1) return launch_wgrad<1, 2, 8>(a, s);
-    if (stride == 1) return launch_wgrad<3, 1, 8>(a, s);
-    return launch_wgrad<3, 2, 8>(a, s);
+    // wider (n, c) tiles where the channel counts allow: twice the FLOPs per staged byte
+    const bool m2 = Cout % 128 == 0, n2 = Cin % 128 == 0;
+    if (K == 1 && stride == 1) {
+        if (m2 && n2) return launch_wgrad<1, 1, 8, 2, 2>(a, s);
+        if (m2) return launch_wgrad<1, 1, 8, 2, 1>(a, s);
+        if (n2) return launch_wgrad<1, 1, 8, 1, 2>(a, s);
+        return launch_wgrad<1, 1, 8, 1, 1>(a, s);
+    }
+    if (K == 1) {
+        if (m2) return launch_wgrad<1, 2, 8, 2, 1>(a, s);
+        return launch_wgrad<1, 2, 8, 1, 1>(a, s);
+    }
+    // 3x3: 64 x 64 per kernel row (K x 16 accumulator registers per wave leave room for the one-tile-ahead staging registers)
+    if (stride == 1) return launch_wgrad<3, 1, 8, 1, 1>(a, s);
+    return launch_wgrad<3, 2, 8, 1, 1>(a, s);
 }
 
 extern "C" int mt4_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {

@@ -187,17 +187,17 @@ class SpatialCnnTrainer:
                 for i, t in enumerate(tap_map):
                     e.tap_map[i] = t
                 entries.append(e)
-                block += (dst.numel() + 255) // 256
+                block += taps_dst * ((u.cout + 31) // 32) * ((u.cin + 31) // 32)
 
             for u in self.units.values():
                 if u.cin == 4:
                     continue   # stem: the image needs no gradient; it stays fp32
                 taps = u.k * u.k
                 if self.op16:
-                    u.w16 = torch.empty((u.cout, ops.packed_k(u.cin, u.k, u.k, dt)), dtype=dt, device=self.dev)
+                    u.w16 = torch.zeros((u.cout, ops.packed_k(u.cin, u.k, u.k, dt)), dtype=dt, device=self.dev)
                     add(u, u.w16, False, taps, range(taps))
                 if u.stride == 1 or u.k == 1:
-                    wt = torch.empty((u.cin, ops.packed_k(u.cout, u.k, u.k, dt)), dtype=dt, device=self.dev)
+                    wt = torch.zeros((u.cin, ops.packed_k(u.cout, u.k, u.k, dt)), dtype=dt, device=self.dev)
                     add(u, wt, True, taps, [taps - 1 - t for t in range(taps)])
                     if self.op16:
                         u.wt16 = wt
@@ -209,7 +209,7 @@ class SpatialCnnTrainer:
                     for ph in (0, 1):
                         for pw in (0, 1):
                             khs, kws = len(sel[ph]), len(sel[pw])
-                            dst = torch.empty((u.cin, ops.packed_k(u.cout, khs, kws, dt)), dtype=dt, device=self.dev)
+                            dst = torch.zeros((u.cin, ops.packed_k(u.cout, khs, kws, dt)), dtype=dt, device=self.dev)
                             add(u, dst, True, khs * kws, [sel[ph][a] * 3 + sel[pw][b] for a in range(khs) for b in range(kws)])
                             ph_w[(ph, pw)] = (dst, khs, kws)
                     if self.op16:

@@ -311,7 +311,8 @@ int mt4_avgpool_bwd_bf16(const float* dfeat, void* dx, int32_t B, int32_t HW, in
  * taps of tapw_src elements):
  *     transposed == 0:  dst[n][t][c] = src[n][tap_map[t]][c]      (a bf16 copy of a forward weight)
  *     transposed == 1:  dst[c][t][n] = src[n][tap_map[t]][c]      (data-gradient operators: flipped taps, sub-pixel phases of a strided conv)
- * block0 = the first workgroup of the entry (256 elements of dst per workgroup; entries ordered by block0).  The table lives in device memory. */
+ * A workgroup moves one 32 (n) x 32 (c) tile of one tap: an entry takes ntaps_dst * ceil(cout / 32) * ceil(cin / 32) workgroups, block0 = its first one
+ * (entries ordered by block0).  Only valid elements are written: zero the destinations once at allocation.  The table lives in device memory. */
 typedef struct {
     const float* src;
     void* dst;

@@ -19,7 +19,8 @@ def _rand(shape, seed, scale=1.0):
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,k,s", [(2, 16, 32, 64, 64, 3, 1), (3, 13, 21, 128, 64, 3, 1), (2, 9, 40, 64, 128, 1, 1), (2, 16, 32, 64, 64, 3, 2),
-                                                (3, 14, 22, 128, 128, 3, 2), (2, 14, 30, 64, 128, 1, 2), (5, 8, 14, 256, 64, 1, 1), (1, 1, 1, 64, 64, 3, 1)])
+                                                (3, 14, 22, 128, 128, 3, 2), (2, 14, 30, 64, 128, 1, 2), (5, 8, 14, 256, 64, 1, 1), (1, 1, 1, 64, 64, 3, 1),
+                                                (2, 9, 17, 128, 256, 1, 1), (2, 9, 17, 256, 128, 3, 1), (2, 10, 18, 128, 256, 3, 2), (2, 10, 18, 64, 256, 1, 2)])
 def test_wgrad_conv2d_bf16_vs_autograd(cuda, b, h, w, cin, cout, k, s):
     """`mt4_wgrad_conv2d_bf16` (bf16 MFMA, transposed LDS reads, kernel rows split over workgroups, fp32 atomics): full and ragged spatial tiles,
     both strides, 1x1 and 3x3, several channel tiles; accumulation into a non-zero buffer"""
