@@ -474,9 +474,9 @@ def ddp_train_bench(dev, dist, world, rank):
         return timed(lambda: dist.all_reduce(buf), 5)
 
     out = {}
-    for net, B in (("resnet50", 8), ("resnet50", 64)):
+    for net, B, odt in (("resnet50", 8, torch.float32), ("resnet50", 64, torch.float32), ("resnet50", 8, torch.bfloat16), ("resnet50", 64, torch.bfloat16)):
         H, W = 256, 448
-        tr = SpatialCnnTrainer(net, lr=0.01, device=str(dev)).load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes(net), seed=5))
+        tr = SpatialCnnTrainer(net, lr=0.01, device=str(dev), operand_dtype=odt).load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes(net), seed=5))
         frames = synth.synthetic_frames(B, H, W, seed=1 + rank).to(dev)
         z = torch.cat([torch.from_numpy((synth.uniform01(5 + rank, i, B * k) < 0.15).reshape(B, k).astype(np.float32)) for i, k in
                        enumerate((6, 10, 15, 100))], 1).to(dev)
@@ -489,10 +489,11 @@ def ddp_train_bench(dev, dist, world, rank):
         tr.exchange = True
         ar = allreduce_alone(tr.G)
         exposed = max(0.0, ms - ms_local)
-        out[f"spatial_{net}_b{B}"] = dict(frames_per_s=round(world * B / ms * 1e3, 1), ms_per_step=round(ms, 3), ms_per_step_no_exchange=round(ms_local, 3),
+        out[f"spatial_{net}_b{B}" + ("_bf16" if odt == torch.bfloat16 else "")] = dict(frames_per_s=round(world * B / ms * 1e3, 1), ms_per_step=round(ms, 3), ms_per_step_no_exchange=round(ms_local, 3),
                                           allreduce_alone_ms=round(ar, 3), grad_MB=round(tr.G.numel() * 4 / 1e6, 1),
                                           overlap_fraction=round(1.0 - min(1.0, exposed / ar), 3) if ar > 0 else None,
-                                          frames_per_rank=B, dtype="f32", mode="eager, bucketed all-reduce issued behind the backward")
+                                          frames_per_rank=B, dtype="f32" if odt == torch.float32 else "bf16 GEMM operands, fp32 master weights / sums",
+                                          mode="eager, bucketed all-reduce issued behind the backward")
         del tr
     T = 1000
     tr = TencoTrainer(lr=0.01, device=str(dev)).load_state_dict(synth.fill_from_shapes(shapes.tenco_shapes(), seed=47))

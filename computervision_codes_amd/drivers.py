@@ -167,6 +167,8 @@ def spatial_cnn_train(argv=None) -> Dict[str, float]:
     p.add_argument("--power", type=float, default=0.1)
     p.add_argument("--val_interval", type=int, default=1)
     p.add_argument("--pretrain_dir", type=str, default="")
+    p.add_argument("--operand_dtype", type=str, default="fp32", choices=["fp32", "bf16"],
+                   help="bf16: the convolutions' GEMM operands in bf16 (activations, gradients, weight copies), master weights and sums fp32")
     F, _ = p.parse_known_args(argv)
     if F.loss_type not in ("all", "i", "v", "t"):
         raise ValueError("--loss_type all | i | v | t (`Spatial_cnn/run.py:165-192`)")
@@ -179,7 +181,8 @@ def spatial_cnn_train(argv=None) -> Dict[str, float]:
     ckpt, latest = os.path.join(model_dir, modelname + ".pth"), os.path.join(model_dir, modelname + "_latest.pth")
     val_interval = F.epochs - 1 if F.val_interval == -1 else F.val_interval
     tr = SpatialCnnTrainer(F.network, lr=F.initial_learning_rates[2], weight_decay=F.weight_decay, rates=F.rates, temp=float(F.temp),
-                           teacher_dim=F.teacher_dim, loss_type=F.loss_type)
+                           teacher_dim=F.teacher_dim, loss_type=F.loss_type,
+                           operand_dtype=torch.bfloat16 if F.operand_dtype == "bf16" else torch.float32)
     table = shapes.spatial_cnn_shapes(F.network, F.student_dim, F.teacher_dim, F.loss_type)
     sd = synth.fill_from_shapes(table, seed=F.seed)          # no torch.nn init here: deterministic synthetic start
     for src in (F.pretrain_dir, latest):                     # `load_model` (:272-278): keys present in the model, strict=False

@@ -177,6 +177,15 @@ def test_teacher_pipeline_scripts_chain_into_student_training(cuda, tmp_path):
                        cwd=tree / "Spatial_cnn", env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert os.path.exists(tree / "Spatial_cnn" / "__checkpoint__" / "run_S" / "rendezvous_lcholect45-crossval_cholect1_latest.pth")
+    # the same line with the convolutions' GEMM operands in bf16 (`--operand_dtype bf16`): trains, validates, checkpoints in the reference layout
+    r = subprocess.run([sys.executable, "run.py", "-t", "--rates", "1", "1", "1", "--temp", "4", "--network", "resnet18", "--teacher_feat_version", "T",
+                        "--teacher_pred_version", "T_MSTCT", "--teacher_dim", "768", "--student_dim", "512", "--loss_type", "all", "--epochs", "1",
+                        "--batch", "8", "-l", "1e-2", "5e-3", "1e-3", "--version", "S16", "--val_interval", "1", "--data_dir", data, "--image_height", "32",
+                        "--image_width", "32", "--kfold", "1", "--operand_dtype", "bf16"],
+                       cwd=tree / "Spatial_cnn", env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    sd16 = torch.load(tree / "Spatial_cnn" / "__checkpoint__" / "run_S16" / "rendezvous_lcholect45-crossval_cholect1_latest.pth", map_location="cpu")
+    assert all(v.dtype in (torch.float32, torch.int64) and torch.isfinite(v.float()).all() for v in sd16.values())
 
 
 def test_mstct_test_evaluates_non_overlapping_256_frame_chunks(cuda, tmp_path):

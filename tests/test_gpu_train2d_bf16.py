@@ -106,3 +106,66 @@ def test_pool_backward_and_repack_bf16(cuda):
     assert torch.equal(ops.repack_weight_bf16(w32, 128, 64, 3, 3), ops.pack_conv_weight(wt, None, BF))
     w1 = _rand((64, 256, 1, 1), 5).to(cuda)
     assert torch.equal(ops.repack_weight_bf16(ops.pack_conv_weight(w1, None, torch.float32), 64, 256, 1, 1), ops.pack_conv_weight(w1, None, BF))
+
+
+def _inputs(cfg):
+    img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["H"], cfg["W"], seed=cfg["seed"]))
+    labels = [torch.from_numpy((synth.uniform01(cfg["seed"], 700 + i, cfg["B"] * k) < 0.15).reshape(cfg["B"], k).astype(np.int64))
+              for i, k in enumerate((6, 10, 15, 100))]
+    tpred = [synth.synthetic_features(cfg["B"], k, seed=cfg["seed"] + 10 + i)[0] * 2.0 for i, k in enumerate((6, 10, 15))]
+    tfeat = [synth.synthetic_features(cfg["B"], 1536, seed=cfg["seed"] + 20 + i)[0] for i in range(3)]
+    return img, labels, tpred, tfeat
+
+
+@pytest.mark.parametrize("name", ["cnn_train_resnet18", "cnn_train_resnet50"])
+def test_bf16_operand_step_vs_reference_fixture(cuda, name):
+    """the bf16-operand step against the fp32 fixtures captured from the reference module + torch autograd.  DECLARED tolerance of the mode (bf16
+    operands carry 8 mantissa bits; sums are fp32 / fp64): every loss term within 3e-3 relative; per-parameter gradient norms within 2 % in the
+    median, 8 % at the 90th percentile and 20 % at worst (norm floor 1e-6 of the largest); the SGD step moves the parameters in the fixture's
+    direction (cosine > 0.9 on the sampled deltas of the large tensors; the stem, at the far end of the backward chain, is the noisiest at 0.92)"""
+    from computervision_codes_amd.spatial_cnn_train import SpatialCnnTrainer
+    from oracle.spatial_cnn_train import damp_residual_gamma
+    z, cfg = load_golden(name)
+    table = shapes.spatial_cnn_shapes(cfg["network"])
+    sd = damp_residual_gamma(synth.fill_from_shapes(table, seed=cfg["seed"]), cfg["network"], cfg.get("damp", 1.0))
+    img, labels, tpred, tfeat = _inputs(cfg)
+    tr = SpatialCnnTrainer(cfg["network"], lr=cfg["lr"], weight_decay=1e-5, rates=cfg["rates"], temp=4.0, operand_dtype=BF).load_state_dict(sd)
+    terms = tr.train_step(img.to(cuda), labels, tpred, tfeat, apply_update=False)
+    for k in ("loss", "hard", "soft", "kd"):
+        assert abs(terms[k] - float(z[k])) <= 3e-3 * max(1.0, abs(float(z[k]))), (k, terms[k], float(z[k]))
+    g = tr.grads()
+    ref = z["grad_norms"]
+    rel = np.array([abs(float(g[k].norm()) - r) / max(r, 1e-6 * ref.max()) for (k, _), r in zip(table, ref) if r > 0 and k in g])
+    assert np.median(rel) < 2e-2 and np.percentile(rel, 90) < 8e-2 and rel.max() < 0.2, (np.median(rel), np.percentile(rel, 90), rel.max())
+    tr.apply_update()
+    new = tr.state_dict()
+    for key in z.files:
+        if key.startswith("delta::") and "running" not in key:
+            k = key[len("delta::"):]
+            flat = (new[k].float() - sd[k].float()).flatten()
+            got, want = flat[:: max(1, flat.numel() // 2048)], torch.from_numpy(z[key])
+            if want.numel() >= 512:
+                cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-30))
+                assert cos > 0.9, (k, cos)
+
+
+def test_bf16_operand_training_tracks_fp32(cuda):
+    """six SGD steps on the same batches from the same start: the bf16-operand trainer's loss follows the fp32 trainer's within 1 %, and both fall"""
+    from computervision_codes_amd.spatial_cnn_train import SpatialCnnTrainer
+    cfg = dict(network="resnet18", B=8, H=64, W=96, seed=911)
+    table = shapes.spatial_cnn_shapes("resnet18")
+    sd = synth.fill_from_shapes(table, seed=cfg["seed"])
+    img, labels, tpred, tfeat = _inputs(cfg)
+    curves = []
+    for dt in (torch.float32, BF):
+        tr = SpatialCnnTrainer("resnet18", lr=0.01, weight_decay=1e-5, rates=(1.0, 1.0, 1.0), temp=4.0, operand_dtype=dt).load_state_dict(sd)
+        curves.append([tr.train_step(img.to(cuda), labels, tpred, tfeat)["loss"] for _ in range(6)])
+    f32, b16 = curves
+    assert all(abs(a - b) <= 1e-2 * abs(a) for a, b in zip(f32, b16)), (f32, b16)
+    assert f32[-1] < f32[0] and b16[-1] < b16[0]
+    # hipGraph replay of the bf16 step == eager launches
+    tr_e = SpatialCnnTrainer("resnet18", lr=0.01, operand_dtype=BF).load_state_dict(sd)
+    tr_g = SpatialCnnTrainer("resnet18", lr=0.01, operand_dtype=BF).load_state_dict(sd)
+    le = [tr_e.train_step(img.to(cuda), labels, tpred, tfeat)["loss"] for _ in range(2)]
+    lg = [tr_g.train_step(img.to(cuda), labels, tpred, tfeat, use_graph=True)["loss"] for _ in range(2)]
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(le, lg)), (le, lg)
