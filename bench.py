@@ -379,22 +379,26 @@ def e2e_script_bench(dev):
 
 
 def spatial_train_bench(dev):
-    """BASELINE configs[4] on one GPU: the student distillation step (`Spatial_cnn/run.py -t`, fp32, batch 8 of 256x448 frames as in
-    Scripts/train_fold1.sh) -- forward, hard+soft+KD losses, backward, SGD; hipGraph replay of forward+backward."""
+    """BASELINE configs[4] on one GPU: the student distillation step (`Spatial_cnn/run.py -t`, batch 8 of 256x448 frames as in
+    Scripts/train_fold1.sh, and batch 64) -- forward, hard+soft+KD losses, backward, SGD; hipGraph replay of forward+backward; fp32 and the
+    bf16-operand mode."""
     from computervision_codes_amd import shapes, synth
     from computervision_codes_amd.spatial_cnn_train import SpatialCnnTrainer
     out = {}
-    for net, B in (("resnet18", 8), ("resnet50", 8), ("resnet50", 64)):
+    for net, B, odt in (("resnet18", 8, torch.float32), ("resnet50", 8, torch.float32), ("resnet50", 64, torch.float32), ("resnet50", 8, torch.bfloat16),
+                        ("resnet50", 64, torch.bfloat16)):
         H, W = 256, 448
-        tr = SpatialCnnTrainer(net, lr=0.01, device=str(dev)).load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes(net), seed=5))
+        tr = SpatialCnnTrainer(net, lr=0.01, device=str(dev), operand_dtype=odt).load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes(net), seed=5))
         frames = synth.synthetic_frames(B, H, W, seed=1).to(dev)
         z = torch.cat([torch.from_numpy((synth.uniform01(5, i, B * k) < 0.15).reshape(B, k).astype(np.float32)) for i, k in
                        enumerate((6, 10, 15, 100))], 1).to(dev)
         tp = [synth.synthetic_features(B, k, seed=11 + i)[0].to(dev) for i, k in enumerate((6, 10, 15))]
         tf = [synth.synthetic_features(B, 1536, seed=21 + i)[0].to(dev) for i in range(3)]
         ms = _time_call(lambda: tr.train_step(frames, z, tp, tf, use_graph=True), iters=10)
-        out[f"{net}_b{B}_{H}x{W}"] = dict(ms_per_step=round(ms, 3), frames_per_s=round(B / ms * 1e3, 1), dtype="f32",
-                                          note="fwd + BCE/DistillKL/MSE + bwd + SGD, train-mode BatchNorm, 1 GPU")
+        bf = odt == torch.bfloat16
+        out[f"{net}_b{B}_{H}x{W}" + ("_bf16" if bf else "")] = dict(
+            ms_per_step=round(ms, 3), frames_per_s=round(B / ms * 1e3, 1), dtype="bf16 GEMM operands, fp32 master weights / sums" if bf else "f32",
+            note="fwd + BCE/DistillKL/MSE + bwd + SGD, train-mode BatchNorm, 1 GPU")
         del tr
     return out
 
