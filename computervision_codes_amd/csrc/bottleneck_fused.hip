@@ -317,7 +317,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
 // current tile computes, conv1 / conv2 weights resident in registers) was built and measured: bit-identical, but SLOWER -- 2.4-2.7 ms per
 // 1336-frame block against 1.47 ms here (compute alone 1.1-1.3 ms against 0.74 ms: eight waves meeting at ten barriers per tile leave the CU
 // idle where two independent workgroups fill each other's stalls; and at 256 registers every spill reload in front of a DMA or store costs a
-// vmcnt(0)).
+// vmcnt(0)).  A three-workgroups-per-CU form (40 KB of LDS: one x chunk buffer reused for t2, t1 reused as a 16 KB staging for four passes of 64
+// channels; 168 registers: residual and conv3 weights fetched a pass ahead; 18 barriers per tile) is bit-identical too and runs in exactly the
+// same 1.44 ms: occupancy is not what holds the kernel back.
 template <int CIN, bool DS>
 int launch(const BneckK& a, hipStream_t stream) {
     constexpr int NXS = CIN > 64 ? 2 : 1;
