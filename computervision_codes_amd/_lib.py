@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
         ("relu", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("tile", C.c_int32),
         ("out_row_map_len", C.c_int32), ("y_ld", C.c_int32), ("res_ld", C.c_int32), ("out_rows_per_image", C.c_int32),
         ("x_pixel_stride", C.c_int32), ("fuse_cout", C.c_int32),
-        ("fuse_w", C.c_void_p), ("fuse_bias", C.c_void_p), ("fuse_y", C.c_void_p), ("fuse_relu", C.c_int32), ("fuse_reserved", C.c_int32),
+        ("fuse_w", C.c_void_p), ("fuse_bias", C.c_void_p), ("fuse_y", C.c_void_p), ("fuse_relu", C.c_int32), ("residual_float", C.c_int32),
     ]
 
 
@@ -105,6 +105,7 @@ SIGNATURES = {
     "mt4_wgrad_conv2d_bf16": (C.c_int, [_vp, _vp, _vp] + [_i32] * 9 + [_vp]),
     "mt4_maxpool3x3s2_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_avgpool_bwd_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "mt4_cast_f32_bf16": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "mt4_refresh_weights": (C.c_int, [_vp, _i32, C.c_int64, _vp]),
     "mt4_repack_weight_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_kd_mix_bwd_f32": (C.c_int, [_vp] * 9 + [_i32, _i32, _vp]),

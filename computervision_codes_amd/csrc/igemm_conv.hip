@@ -81,6 +81,7 @@ struct ConvK {
     int map_len;
     int map_img;         // output rows per image on the y/residual side (map_len when the map is a permutation)
     int y_ld, res_ld;    // row pitch (elements) of y / residual; Cout when dense
+    int res_f32;         // bf16 operands with fp32 output only: the residual is fp32 as well (mixed-precision training GEMMs)
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, sh, sw, ph, pw, dh, dw, relu;  // relu: 0 none, 1 ReLU, 2 GELU(erf)
     int M, HoWo, CPT, SPT, taps, nsteps, n_tiles, total_tiles;
     long long x_img_bytes;  // H*W*pix_bytes
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel
     constexpr int RPI = NTH / TPR;    // rows per read-back iteration
     constexpr int ITERS = (BMP + RPI - 1) / RPI;
     constexpr int RB = (sizeof(T) == 2 && CH == 4) ? 8 : 16;  // residual bytes per output vector
+    constexpr bool MIXED = sizeof(T) == 2 && OUT_F32;          // bf16 operands, fp32 output: the residual may be fp32 (a.res_f32)
     if ((a.Cout % CH) == 0) {
         // (the K loop ended with a barrier: every wave is done reading the operand stages)
         const int rc = tid % TPR, rr = tid / TPR;
@@ -461,7 +463,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel
                     orow[it] = m;
                     if (a.res) {
                         const char* rp = a.res + ((long long)m * a.res_ld + n) * ES;
-                        if constexpr (RB == 16) {   // read once: non-temporal
+                        if (MIXED && a.res_f32) rres[it] = *(const uint4*)(a.res + ((long long)m * a.res_ld + n) * 4);
+                        else if constexpr (RB == 16) {   // read once: non-temporal
                             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                             if (a.nt_epi) { const u32x4 t = __builtin_nontemporal_load((const u32x4*)rp); rres[it] = make_uint4(t.x, t.y, t.z, t.w); }
                             else rres[it] = *(const uint4*)rp;
@@ -493,7 +496,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel
                 const long long o = orow[it] * a.y_ld + n;
                 if (a.res && a.relu == 3) {   // ReLU backward: pass the gradient where the forward activation was positive
                     const uint4 rv = rres[it];
-                    if constexpr (sizeof(T) == 2) {
+                    if (MIXED && a.res_f32) {
+                        if (!(__uint_as_float(rv.x) > 0.f)) v[0] = 0.f;
+                        if (!(__uint_as_float(rv.y) > 0.f)) v[1] = 0.f;
+                        if (!(__uint_as_float(rv.z) > 0.f)) v[2] = 0.f;
+                        if (!(__uint_as_float(rv.w) > 0.f)) v[3] = 0.f;
+                    } else if constexpr (sizeof(T) == 2) {
                         const uint32_t u[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                         for (int e = 0; e < CH / 2; ++e) {
@@ -508,7 +516,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel
                     }
                 } else if (a.res) {
                     const uint4 rv = rres[it];
-                    if constexpr (sizeof(T) == 2) {
+                    if (MIXED && a.res_f32) {
+                        v[0] += __uint_as_float(rv.x); v[1] += __uint_as_float(rv.y);
+                        v[2] += __uint_as_float(rv.z); v[3] += __uint_as_float(rv.w);
+                    } else if constexpr (sizeof(T) == 2) {
                         const uint32_t u[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                         for (int e = 0; e < CH / 2; ++e) {
@@ -601,7 +612,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel
                 float f = v[e];
                 if (a.res) {
                     float rvv;
-                    if constexpr (sizeof(T) == 2) rvv = bf16_to_f32(*(const u16*)(a.res + (ro + e) * 2));
+                    if ((sizeof(T) == 2 && OUT_F32) && a.res_f32) rvv = *(const float*)(a.res + (ro + e) * 4);
+                    else if constexpr (sizeof(T) == 2) rvv = bf16_to_f32(*(const u16*)(a.res + (ro + e) * 2));
                     else rvv = *(const float*)(a.res + (ro + e) * 4);
                     if (a.relu == 3) f = rvv > 0.f ? f : 0.f;
                     else f += rvv;
@@ -1297,9 +1309,12 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     k.y_ld = d->y_ld > 0 ? d->y_ld : d->Cout;
     k.res_ld = d->res_ld > 0 ? d->res_ld : d->Cout;
     if (k.y_ld < d->Cout || k.res_ld < d->Cout) return MT4_EINVAL;
+    if (d->residual_float && !(d->dtype == MT4_BF16 && d->out_dtype == MT4_F32 && !d->fuse_w)) return MT4_EUNSUPPORTED;
+    k.res_f32 = d->residual_float ? 1 : 0;
     {
         const int oes = d->out_dtype == MT4_BF16 ? 2 : 4;
-        if ((d->Cout * oes) % 16 == 0 && ((k.y_ld * oes) % 16 != 0 || (d->residual && (k.res_ld * es) % 16 != 0))) return MT4_EALIGN;
+        const int res_es = k.res_f32 ? 4 : es;
+        if ((d->Cout * oes) % 16 == 0 && ((k.y_ld * oes) % 16 != 0 || (d->residual && (k.res_ld * res_es) % 16 != 0))) return MT4_EALIGN;
     }
     if (d->out_row_map && d->out_row_map_len <= 0) return MT4_EINVAL;
     k.M = (int)M; k.HoWo = d->Ho * d->Wo;

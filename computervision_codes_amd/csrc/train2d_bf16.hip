@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgK a) {
 #pragma unroll
             for (int pm = 0; pm < BMT; ++pm) {
                 ry[i][pm] = make_uint4(0, 0, 0, 0);
-                if (ok) ry[i][pm] = *(const uint4*)(src + pm * 64);
+                if (ok && n0 + pm * 64 + ld_chunk * 8 < a.Cout) ry[i][pm] = *(const uint4*)(src + pm * 64);      // (channel counts need not fill the tile)
             }
         }
         // input tile for this kernel row: LDS row iy = the input row of output row ho0 + iy, IW pixels (rows of PITCH pixels), zeros outside
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgK a) {
 #pragma unroll
             for (int pn = 0; pn < BNT; ++pn) {
                 rx[i][pn] = make_uint4(0, 0, 0, 0);
-                if (ok) rx[i][pn] = *(const uint4*)(src + pn * 64);
+                if (ok && c0 + pn * 64 + ld_chunk * 8 < a.Cin) rx[i][pn] = *(const uint4*)(src + pn * 64);
             }
         }
     };
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgK a) {
                 for (int e = 0; e < 4; ++e) {
                     const int n = n0 + wm * (32 * BMT) + mi * 16 + q4 * 4 + e;
                     const int c = c0 + wn * (32 * BNT) + ni * 16 + r16;
-                    atomicAdd(a.dw + (long long)n * a.kpad + (kh * K + kw) * a.tapw + c, acc[kw][mi][ni][e]);
+                    if (n < a.Cout && c < a.Cin) atomicAdd(a.dw + (long long)n * a.kpad + (kh * K + kw) * a.tapw + c, acc[kw][mi][ni][e]);
                 }
 }
 
@@ -336,8 +336,8 @@ int launch_wgrad(WgK a, hipStream_t stream) {
     a.tiles_h = cdiv(a.Ho, TH);
     a.tiles_w = cdiv(a.Wo, 16);
     a.ntiles = a.B * a.tiles_h * a.tiles_w;
-    a.cin_tiles = a.Cin / (64 * BNT);
-    const int pairs = (a.Cout / (64 * BMT)) * a.cin_tiles * K;
+    a.cin_tiles = cdiv(a.Cin, 64 * BNT);
+    const int pairs = cdiv(a.Cout, 64 * BMT) * a.cin_tiles * K;
     // workgroups per launch: every one ends with (64 BMT)(64 BNT) K fp32 atomics, so as few as keep the CUs busy (two per CU)
     const int target = MT4_ENV_INT("MT4_WGRAD_WGS", 512);
     int nsplit = (target + pairs - 1) / pairs;
@@ -410,6 +410,13 @@ __global__ void avgpool_bwd_bf16_kernel(const float* __restrict__ df, u16* __res
     const float4 v = *(const float4*)(df + b * C + c);
     const float s = 1.0f / (float)HW;
     st4<u16>(dx + e, make_float4(v.x * s, v.y * s, v.z * s, v.w * s));
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ x, u16* __restrict__ y, long long n8) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const float4 a = *(const float4*)(x + i * 8), b = *(const float4*)(x + i * 8 + 4);
+    *(uint4*)(y + i * 8) = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
 }
 
 __global__ void repack_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, int taps, int tapw32, long long kpad32, int tapw16, long long kpad16,
@@ -546,7 +553,8 @@ extern "C" int mt4_wgrad_conv2d_bf16(const void* dy, const void* x, float* dw_pa
                                      int32_t Cout, int32_t K, int32_t stride, void* stream) {
     mt4_clear_error();
     if (!dy || !x || !dw_packed || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return MT4_EINVAL;
-    if ((K != 1 && K != 3) || (stride != 1 && stride != 2) || (Cin % 64) || (Cout % 64)) return MT4_EUNSUPPORTED;
+    if ((K != 1 && K != 3) || (stride != 1 && stride != 2)) return MT4_EUNSUPPORTED;
+    if ((Cin % 8) || (Cout % 8)) return MT4_EALIGN;
     if (Ho != (H + 2 * (K / 2) - K) / stride + 1 || Wo != (W + 2 * (K / 2) - K) / stride + 1) return MT4_EINVAL;
     if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw_packed) & 15) return MT4_EALIGN;
     WgK a;
@@ -556,7 +564,7 @@ extern "C" int mt4_wgrad_conv2d_bf16(const void* dy, const void* x, float* dw_pa
     a.tapw = (Cin + 3) / 4 * 4;
     hipStream_t s = (hipStream_t)stream;
     // wider (n, c) tiles where the channel counts allow: twice the FLOPs per staged byte
-    const bool m2 = Cout % 128 == 0, n2 = Cin % 128 == 0;
+    const bool m2 = Cout > 64, n2 = Cin > 64;
     if (K == 1 && stride == 1) {
         if (m2 && n2) return launch_wgrad<1, 1, 8, 2, 2>(a, s);
         if (m2) return launch_wgrad<1, 1, 8, 2, 1>(a, s);
@@ -588,6 +596,14 @@ extern "C" int mt4_avgpool_bwd_bf16(const float* dfeat, void* dx, int32_t B, int
     if (!dfeat || !dx || B <= 0 || HW <= 0 || C <= 0 || (C & 3)) return MT4_EINVAL;
     const long long n4 = (long long)B * HW * C / 4;
     hipLaunchKernelGGL(avgpool_bwd_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dfeat, (u16*)dx, HW, C, n4);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, void* stream) {
+    mt4_clear_error();
+    if (!x || !y_bf16 || n <= 0 || (n & 7)) return MT4_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)y_bf16) & 15) return MT4_EALIGN;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (u16*)y_bf16, (long long)(n / 8));
     return mt4_check_launch();
 }
 

@@ -122,8 +122,14 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
         assert out.is_contiguous() and out.numel() == b * out_rows_per_image * cout and out.dtype == od
     else:  # `out` is a column-slice view of a [rows, y_ld] buffer: its data_ptr is the slice start
         assert out.dtype == od and out.stride(-1) == 1
+    res_f32 = 0
     if residual is not None:
-        assert residual.dtype == x.dtype and residual.stride(-1) == 1
+        if residual.dtype == torch.float32 and x.dtype == torch.bfloat16:      # mixed-precision training GEMM: bf16 operands, fp32 output + residual
+            assert od == torch.float32 and fuse_next is None
+            res_f32 = 1
+        else:
+            assert residual.dtype == x.dtype
+        assert residual.stride(-1) == 1
         if res_ld == 0:
             assert residual.is_contiguous() and residual.numel() == b * (out_rows_per_image or ho * wo) * cout
     if bias is not None:
@@ -151,7 +157,7 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
                  out_row_map.data_ptr() if out_row_map is not None else None,
                  b, h, w_, cin, ho, wo, cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1],
                  act_code, dt_code(x.dtype), dt_code(od), tile, out_row_map.numel() if out_row_map is not None else 0, y_ld, res_ld,
-                 out_rows_per_image, pix, f_cout, f_w, f_b, f_y, f_relu, 0)
+                 out_rows_per_image, pix, f_cout, f_w, f_b, f_y, f_relu, res_f32)
     check(lib.mt4_conv_nhwc(C.byref(d), _stream()), "mt4_conv_nhwc")
     return out if fuse_next is None else (out, y2)
 
@@ -761,6 +767,15 @@ def avgpool_bwd_bf16(dfeat, b, hw, c):
     dx = torch.empty((b, hw, c), dtype=BF16, device=dfeat.device)
     check(lib.mt4_avgpool_bwd_bf16(dfeat.data_ptr(), dx.data_ptr(), b, hw, c, _stream()), "mt4_avgpool_bwd_bf16")
     return dx
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> bf16 copy (round to nearest even): the operand of a mixed-precision GEMM"""
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 8 == 0
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(lib.mt4_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "mt4_cast_f32_bf16")
+    return y
 
 
 def repack_weight_bf16(w_f32_packed, cout, cin, kh, kw, out=None):

@@ -94,7 +94,8 @@ typedef struct mt4_conv_desc {
     const float* fuse_bias;     /* [fuse_cout] or NULL */
     void* fuse_y;               /* [B][Ho][Wo][fuse_cout] bf16 */
     int32_t fuse_relu;          /* 0 / 1 */
-    int32_t fuse_reserved;
+    int32_t residual_float;       /* 1: dtype MT4_BF16 with out_dtype MT4_F32 only -- the residual (or the ReLU gate of act 3) is float32 like y: the mixed-precision
+                                   training GEMMs (bf16 operands, fp32 activations); 0 otherwise */
 } mt4_conv_desc;
 
 int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream);
@@ -296,14 +297,16 @@ int mt4_bn_backward_t(const void* dy_bf16, const void* y_post_bf16, const void* 
                       const float* gamma, double* sums_zeroed, void* dx, void* dres_bf16, float* dgamma, float* dbeta, int64_t M, int32_t C,
                       int32_t relu, void* stream);
 /* Conv2d weight gradient on bf16 MFMA: dw_packed (fp32, the layout of mt4_pack_conv_weight(MT4_F32)) += sum_pixels dy[p][n] * x[in(p, tap)][c].
- * dy [B][Ho][Wo][Cout] bf16, x [B][H][W][Cin] bf16; K = 1 or 3 (square, pad K / 2), stride 1 or 2, Cin % 64 == 0 and Cout % 64 == 0;
- * MT4_EUNSUPPORTED otherwise.  The pixel range is split over workgroups and summed with fp32 atomics (order run-dependent). */
+ * dy [B][Ho][Wo][Cout] bf16, x [B][H][W][Cin] bf16; K = 1 or 3 (square, pad K / 2), stride 1 or 2 (MT4_EUNSUPPORTED otherwise), Cin % 8 == 0 and
+ * Cout % 8 == 0 (MT4_EALIGN).  The pixel range is split over workgroups and summed with fp32 atomics (order run-dependent). */
 int mt4_wgrad_conv2d_bf16(const void* dy, const void* x, float* dw_packed, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Ho, int32_t Wo,
                           int32_t Cout, int32_t K, int32_t stride, void* stream);
 /* MaxPool2d(3,2,1) backward, bf16, gather form (no atomics; dx need not be zeroed) */
 int mt4_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 /* AdaptiveAvgPool2d(1) backward: dfeat [B][C] fp32 -> dx [B][HW][C] bf16 */
 int mt4_avgpool_bwd_bf16(const float* dfeat, void* dx, int32_t B, int32_t HW, int32_t C, void* stream);
+/* y (bf16) = x (fp32), round to nearest even; n % 8 == 0, 16-byte aligned: the operand copy of a mixed-precision GEMM */
+int mt4_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
 /* packed fp32 weight matrix (mt4_pack_conv_weight(MT4_F32) layout, e.g. the master weights or their transposed copies) -> the packed bf16
  * layout of the same geometry */
 /* One launch that rebuilds every weight matrix derived from the fp32 master weights (after an optimizer step): entry i fills dst (fp32 or bf16,

@@ -53,7 +53,7 @@ def test_ops_refuse_cpu_tensors():
 
 def test_struct_layout_matches_header():
     from computervision_codes_amd import _lib
-    # 6 pointers + 24 int32 + fuse_cout + the three fuse pointers (8-byte aligned: 25 int32 pad to 104 bytes) + fuse_relu + fuse_reserved
+    # 6 pointers + 24 int32 + fuse_cout + the three fuse pointers (8-byte aligned: 25 int32 pad to 104 bytes) + fuse_relu + residual_float
     assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 26 * 4 + 3 * 8 + 2 * 4
     assert _lib.ConvDesc.fuse_w.offset == 6 * 8 + 26 * 4 and _lib.ConvDesc.fuse_relu.offset == 6 * 8 + 26 * 4 + 24
 

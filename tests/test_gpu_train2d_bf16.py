@@ -20,7 +20,8 @@ def _rand(shape, seed, scale=1.0):
 
 @pytest.mark.parametrize("b,h,w,cin,cout,k,s", [(2, 16, 32, 64, 64, 3, 1), (3, 13, 21, 128, 64, 3, 1), (2, 9, 40, 64, 128, 1, 1), (2, 16, 32, 64, 64, 3, 2),
                                                 (3, 14, 22, 128, 128, 3, 2), (2, 14, 30, 64, 128, 1, 2), (5, 8, 14, 256, 64, 1, 1), (1, 1, 1, 64, 64, 3, 1),
-                                                (2, 9, 17, 128, 256, 1, 1), (2, 9, 17, 256, 128, 3, 1), (2, 10, 18, 128, 256, 3, 2), (2, 10, 18, 64, 256, 1, 2)])
+                                                (2, 9, 17, 128, 256, 1, 1), (2, 9, 17, 256, 128, 3, 1), (2, 10, 18, 128, 256, 3, 2), (2, 10, 18, 64, 256, 1, 2),
+                                                (3, 9, 16, 72, 200, 1, 1), (2, 8, 16, 864, 40, 1, 1), (2, 7, 9, 24, 88, 3, 1)])
 def test_wgrad_conv2d_bf16_vs_autograd(cuda, b, h, w, cin, cout, k, s):
     """`mt4_wgrad_conv2d_bf16` (bf16 MFMA, transposed LDS reads, kernel rows split over workgroups, fp32 atomics): full and ragged spatial tiles,
     both strides, 1x1 and 3x3, several channel tiles; accumulation into a non-zero buffer"""
@@ -169,3 +170,23 @@ def test_bf16_operand_training_tracks_fp32(cuda):
     le = [tr_e.train_step(img.to(cuda), labels, tpred, tfeat)["loss"] for _ in range(2)]
     lg = [tr_g.train_step(img.to(cuda), labels, tpred, tfeat, use_graph=True)["loss"] for _ in range(2)]
     assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(le, lg)), (le, lg)
+
+
+@pytest.mark.parametrize("m,k,n,act", [(300, 256, 128, None), (77, 64, 40, "relu"), (513, 384, 864, "gelu"), (200, 128, 64, "relu_gate")])
+def test_mixed_precision_linear_fp32_residual(cuda, m, k, n, act):
+    """the mixed-precision training GEMM: bf16 operands (activation copy by `mt4_cast_f32_bf16`, packed bf16 weights), fp32 output with an fp32
+    residual / ReLU gate (`mt4_conv_desc.residual_float`) -- against fp32 torch on the bf16-valued operands"""
+    from computervision_codes_amd import ops
+    x, w, b, r = _rand((m, k), 1), _rand((n, k), 2, k ** -0.5), _rand((n,), 3), _rand((m, n), 4)
+    xd = ops.cast_bf16(x.to(cuda))
+    assert torch.equal(xd.cpu(), x.to(BF))
+    wp = ops.pack_linear_weight(w.to(cuda), BF)
+    y = ops.linear(xd, wp, b.to(cuda) if act != "relu_gate" else None, act=act, residual=r.to(cuda), out_dtype=torch.float32)
+    assert y.dtype == torch.float32
+    pre = x.to(BF).float() @ w.to(BF).float().t()
+    if act == "relu_gate":
+        ref = torch.where(r > 0, pre, torch.zeros_like(pre))
+    else:
+        ref = pre + b + r
+        ref = torch.relu(ref) if act == "relu" else (F.gelu(ref) if act == "gelu" else ref)
+    assert (y.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()) + 1e-6 * (act == "gelu")
