@@ -234,20 +234,30 @@ def temporal_bench(dev, do_cpu):
 
 def mstct_train_bench(dev):
     """BASELINE configs[3]'s temporal half: one training step of the MS-TCT teacher on the reference's batch (31 windows of 256 frames,
-    Swin-L features D = 1536, `Scripts/train_fold1.sh:16`; `Temporal_mstct/run.py:147-235`): forward + BCE + backward + SGD, fp32"""
+    Swin-L features D = 1536, `Scripts/train_fold1.sh:16`; `Temporal_mstct/run.py:147-235`): forward + BCE + backward + SGD; fp32, and with
+    the nn.Linear GEMMs on bf16 operand copies (fp32 activations, accumulation and master weights)"""
     from computervision_codes_amd import shapes, synth
     from computervision_codes_amd.mstct_train import MstctTrainer
     B, T, D = 31, 256, 1536
-    tr = MstctTrainer((256, 384, 576, 864), 2, 8, 8, D, 512, "i", lr=0.01, device=str(dev)).load_state_dict(
-        synth.fill_from_shapes(shapes.mstct_shapes(D, (256, 384, 576, 864), 2, 8, 512, "i"), seed=47))
-    x = torch.randn(B, T, D, device=dev)
-    z = (torch.rand(B * T, 6, device=dev) < 0.15).float()
-    masks = tr.draw_masks_device(B, T, 1, 0)
-    ms = _time_call(lambda: tr.train_step_btd(x, z, masks=masks), iters=5)
-    ms_g = _time_call(lambda: tr.train_step_btd(x, z, masks=masks, use_graph=True), iters=5)
-    gflop = 3 * 31.2 * B     # ~3x the forward: 31.4 GFLOP per window at D = 2048 (SURVEY 8a9), 31.2 at D = 1536 (D enters the first conv only)
-    return dict(ms_per_step=round(ms, 2), ms_per_step_graph=round(ms_g, 2), windows_per_s=round(B / min(ms, ms_g) * 1e3, 1), batch=B, T=T, D=D, dtype="f32",
-                approx_tflops=round(gflop / min(ms, ms_g), 1), note="fwd + BCE(pos_weight) + bwd + SGD, dropout masks drawn outside the timed region, 1 GPU")
+    out = {}
+    for odt in (torch.float32, torch.bfloat16):
+        tr = MstctTrainer((256, 384, 576, 864), 2, 8, 8, D, 512, "i", lr=0.01, device=str(dev), operand_dtype=odt).load_state_dict(
+            synth.fill_from_shapes(shapes.mstct_shapes(D, (256, 384, 576, 864), 2, 8, 512, "i"), seed=47))
+        x = torch.randn(B, T, D, device=dev)
+        z = (torch.rand(B * T, 6, device=dev) < 0.15).float()
+        masks = tr.draw_masks_device(B, T, 1, 0)
+        ms = _time_call(lambda: tr.train_step_btd(x, z, masks=masks), iters=5)
+        ms_g = _time_call(lambda: tr.train_step_btd(x, z, masks=masks, use_graph=True), iters=5)
+        gflop = 3 * 31.2 * B     # ~3x the forward: 31.4 GFLOP per window at D = 2048 (SURVEY 8a9), 31.2 at D = 1536 (D enters the first conv only)
+        rec = dict(ms_per_step=round(ms, 2), ms_per_step_graph=round(ms_g, 2), windows_per_s=round(B / min(ms, ms_g) * 1e3, 1), batch=B, T=T, D=D,
+                   dtype="f32" if odt == torch.float32 else "bf16 GEMM operands, fp32 activations / master weights",
+                   approx_tflops=round(gflop / min(ms, ms_g), 1), note="fwd + BCE(pos_weight) + bwd + SGD, dropout masks drawn outside the timed region, 1 GPU")
+        if odt == torch.float32:
+            out.update(rec)
+        else:
+            out["bf16_operands"] = rec
+        del tr
+    return out
 
 
 def q2l_train_bench(dev, backbone="swin_L_384_22k", img=384, hidden=1536, B=16):

@@ -39,7 +39,7 @@ POS_W = {"i": [0.93487068, 0.94234964, 0.93487068, 1.18448115, 1.02368339, 0.979
 
 class _Lin:
     """nn.Linear / Conv1d parameter pair with its gradient views and the transposed copy for the data gradient"""
-    __slots__ = ("name", "cout", "cout_real", "cin", "taps", "w", "b", "gw", "gb", "wt", "kpad", "conv_shape")
+    __slots__ = ("name", "cout", "cout_real", "cin", "taps", "w", "b", "gw", "gb", "wt", "kpad", "conv_shape", "w16", "wt16")
 
 
 class _Vec:
@@ -53,8 +53,13 @@ def _r4(n: int) -> int:
 class MstctTrainer:
     def __init__(self, inter_channels: Sequence[int] = (256, 384, 576, 864), num_block: int = 2, head: int = 8, mlp_ratio: int = 8,
                  in_feat_dim: int = 1536, final_embedding_dim: int = 512, loss_type: str = "i", lr: float = 0.1, weight_decay: float = 1e-5,
-                 device: str = "cuda", process_group=None):
+                 device: str = "cuda", process_group=None, operand_dtype: torch.dtype = torch.float32):
         assert loss_type in NCLS
+        assert operand_dtype in (torch.float32, torch.bfloat16)
+        # bfloat16: the nn.Linear GEMMs (forward, data and weight gradients) read bf16 copies of their operands -- activations are cast on the
+        # way in (`mt4_cast_f32_bf16`), weights re-derived from the fp32 masters after every step -- and accumulate / store in fp32; everything
+        # between the GEMMs (LayerNorm, softmax, GELU, attention products, the k = 3 merge convolutions, the loss) stays fp32
+        self.op16 = operand_dtype == torch.bfloat16
         self.inter, self.nb, self.H, self.ratio = tuple(inter_channels), num_block, head, mlp_ratio
         self.D, self.E, self.loss_type, self.K = in_feat_dim, final_embedding_dim, loss_type, NCLS[loss_type]
         self.KP = _r4(self.K)
@@ -103,9 +108,7 @@ class MstctTrainer:
             total += _r4(int(torch.tensor(shp).prod()))
         self.P = torch.zeros(total, dtype=F32, device=self.dev)
         self.G = torch.zeros(total, dtype=F32, device=self.dev)
-        wt_total = sum(cin * ops.packed_k(_r4(cout), 1, taps, F32) for name, cout, cin, taps, _ in lin if not name.endswith("Block1.proj"))
-        self.WT = torch.zeros(wt_total, dtype=F32, device=self.dev)
-        off = wo = 0
+        off = 0
         for name, cout, cin, taps, conv_shape in lin:
             c = _Lin()
             c.name, c.cout_real, c.cout, c.cin, c.taps, c.conv_shape = name, cout, _r4(cout), cin, taps, conv_shape
@@ -120,12 +123,8 @@ class MstctTrainer:
                 w3 = torch.cat([w3, torch.zeros(c.cout - cout, cin, taps)], 0)
             c.w.copy_(ops.pack_conv_weight(w3.to(self.dev).unsqueeze(2), None, F32))
             c.b[:cout].copy_(sd[name + ".bias"].float().to(self.dev))
-            if not name.endswith("Block1.proj"):                              # the first merge conv needs no data gradient
-                kt = ops.packed_k(c.cout, 1, taps, F32)
-                c.wt = self.WT[wo:wo + cin * kt].view(cin, kt)
-                wo += cin * kt
-            else:
-                c.wt = None
+            c.wt = None if name.endswith("Block1.proj") else True          # (the first merge conv needs no data gradient; filled below)
+            c.w16 = c.wt16 = None
             self.lins[name] = c
         for name, shp in vec:
             v = _Vec()
@@ -142,6 +141,18 @@ class MstctTrainer:
         self._wsum = torch.zeros((3, E, kp), dtype=F32, device=self.dev)       # summed 1x1 mixer weights of scales 3, 2, 1
         self._bsum = torch.zeros((3, E), dtype=F32, device=self.dev)
         self._wsum_t = torch.zeros((3, E, ops.packed_k(E, 1, 1, F32)), dtype=F32, device=self.dev)
+        # every derived matrix -- the fp32 transposed (tap-flipped) weights of the data gradients and, in the bf16-operand mode, the bf16 forward /
+        # transposed copies of the eligible nn.Linear layers -- comes from ONE launch over a table after each parameter change
+        self._tab = ops.RefreshTable(self.dev)
+        for c in self.lins.values():
+            if c.wt is not None:
+                c.wt = self._tab.add(c.w, c.cout, c.cin, F32, True, [c.taps - 1 - i for i in range(c.taps)])
+            if self.op16 and c.taps == 1 and c.cin % 8 == 0 and c.cout % 8 == 0 and c.cout >= 64:
+                c.w16 = self._tab.add(c.w, c.cout, c.cin, torch.bfloat16, False, [0])
+                if c.wt is not None:
+                    c.wt16 = self._tab.add(c.w, c.cout, c.cin, torch.bfloat16, True, [0])
+        self._c16: Dict[tuple, tuple] = {}
+        self._dy16 = None
         self._refresh()
         return self
 
@@ -149,9 +160,7 @@ class MstctTrainer:
 
     def _refresh(self):
         """derived copies after a parameter change: transposed weights for the data gradients, summed mixer weights"""
-        for c in self.lins.values():
-            if c.wt is not None:
-                ops.transpose_pack_conv1d(c.w, c.cout, c.cin, c.taps, out=c.wt)
+        self._tab.run()
         for j, (_, ids) in enumerate(self._MIX):
             for n, i in enumerate(ids):
                 l = self.lins[f"Temporal_Mixer.linear{i}"]
@@ -198,14 +207,40 @@ class MstctTrainer:
                 "feat_rows": ops.dropout_mask((b * t, self.E), seed, 2 * step + 1, 0.5, self.dev)}
 
     # ------------------------------------------------------------------ building blocks
+    def _cast(self, x2d, grad=False):
+        """bf16 copy of a GEMM operand.  Forward activations: made once per step and kept with their source (the copy also serves the weight
+        gradient; holding the source keeps the allocator from handing its address to another tensor).  Gradients are short-lived: only the
+        latest one is remembered (a layer's data and weight gradient ask for the same tensor back to back)."""
+        key = (x2d.data_ptr(), tuple(x2d.shape))
+        if grad:
+            if self._dy16 is not None and self._dy16[0] == key:
+                return self._dy16[2]
+            y = ops.cast_bf16(x2d)
+            self._dy16 = (key, x2d, y)
+            return y
+        hit = self._c16.get(key)
+        if hit is None:
+            hit = self._c16[key] = (x2d, ops.cast_bf16(x2d))
+        return hit[1]
+
     def _fwd(self, x2d, c: _Lin, residual=None, act=None, out=None):
+        if c.w16 is not None:
+            x2d = x2d if x2d.is_contiguous() else x2d.contiguous()
+            return ops.linear(self._cast(x2d), c.w16, c.b, residual=residual, act=act, out=out, out_dtype=F32)
         return ops.linear(x2d, c.w, c.b, residual=residual, act=act, out=out)
 
     def _dgrad(self, dy2d, c: _Lin, residual=None):
+        if c.wt16 is not None:
+            dy2d = dy2d if dy2d.is_contiguous() else dy2d.contiguous()
+            return ops.linear(self._cast(dy2d, grad=True), c.wt16, None, residual=residual, out_dtype=F32)
         return ops.linear(dy2d, c.wt, None, residual=residual)
 
     def _wgrad(self, dy2d, x2d, c: _Lin):
-        ops.wgrad_conv1d(dy2d, x2d, c.gw, batch=1, t=dy2d.shape[0], taps=1, dil=1, pad=0)
+        m = dy2d.shape[0]
+        if c.w16 is not None and m % 16 == 0 and dy2d.is_contiguous() and x2d.is_contiguous():    # rows as a [M / 16, 16] pixel grid of one image
+            ops.wgrad_conv2d_bf16(self._cast(dy2d, grad=True).view(1, m // 16, 16, c.cout), self._cast(x2d).view(1, m // 16, 16, c.cin), c.gw, 1, 1)
+        else:
+            ops.wgrad_conv1d(dy2d, x2d, c.gw, batch=1, t=m, taps=1, dil=1, pad=0)
         ops.colsum(dy2d, c.gb)
 
     def _ln(self, x, name):
@@ -248,6 +283,8 @@ class MstctTrainer:
         b, t, d = x_btd.shape
         M, E, L = b * t, self.E, self.lins
         self.G.zero_()
+        self._c16.clear()
+        self._dy16 = None
         x = x_btd.contiguous().view(M, d)
         if mask_in is not None:
             x = ops.mul_add(x, mask_in)
@@ -451,6 +488,8 @@ def train_driver(argv=None):
     p.add_argument("--power", type=float, default=0.1)
     p.add_argument("--val_interval", type=int, default=1)
     p.add_argument("--num_clips", type=int, default=256, help="window length (the reference hard-codes 256, dataloader.py:237)")
+    p.add_argument("--operand_dtype", type=str, default="fp32", choices=["fp32", "bf16"],
+                   help="bf16: the nn.Linear GEMMs on bf16 operand copies (fp32 activations, accumulation and master weights)")
     F, _ = p.parse_known_args(argv)
     rank, world = _dist()
     lt = F.loss_type
@@ -461,7 +500,7 @@ def train_driver(argv=None):
     logfile = os.path.join(model_dir, modelname + ".log")
     latest = os.path.join(model_dir, modelname + "latest.pth")
     tr = MstctTrainer((256, 384, 576, 864), 2, 8, 8, F.input_dim, F.final_embedding_dim, lt, lr=F.initial_learning_rates[2],
-                      weight_decay=F.weight_decay)
+                      weight_decay=F.weight_decay, operand_dtype=torch.bfloat16 if F.operand_dtype == "bf16" else torch.float32)
     if os.path.exists(latest):
         tr.load_state_dict(torch.load(latest, map_location="cpu"))
     else:   # no torch.nn init here: deterministic synthetic start (the reference starts from its trunc_normal_ init)

@@ -769,6 +769,45 @@ def avgpool_bwd_bf16(dfeat, b, hw, c):
     return dx
 
 
+class RefreshTable:
+    """the derived weight matrices of a trainer (bf16 forward copies, transposed data-gradient operators, sub-pixel phase kernels), rebuilt from the
+    fp32 master weights by ONE launch (`mt4_refresh_weights`).  `add` allocates a zeroed destination and records how it is filled; `run` launches."""
+
+    def __init__(self, device):
+        self.dev, self._entries, self._blocks, self._table = device, [], 0, None
+
+    def add(self, src: torch.Tensor, cout: int, cin: int, dtype: torch.dtype, transposed: bool, tap_map, out_taps_shape=None) -> torch.Tensor:
+        """src: packed fp32 master [cout][kpad] with taps of roundup(cin, 4) elements.  Returns dst: [cout][taps x cin] (transposed False) or
+        [cin][taps x cout] (transposed True) in the packed layout of `dtype`; dst tap t is the master's tap tap_map[t].  out_taps_shape = (kh, kw) of
+        the destination kernel (default (1, len(tap_map)))"""
+        from ._lib import RefreshEntry
+        tap_map = list(tap_map)
+        kh, kw = out_taps_shape or (1, len(tap_map))
+        assert kh * kw == len(tap_map) <= 9 and src.dtype == torch.float32 and src.is_contiguous() and src.shape[0] == cout
+        rows, cols = (cin, cout) if transposed else (cout, cin)
+        dst = torch.zeros((rows, packed_k(cols, kh, kw, dtype)), dtype=dtype, device=self.dev)
+        e = RefreshEntry()
+        e.src, e.dst, e.block0 = src.data_ptr(), dst.data_ptr(), self._blocks
+        e.dst_bf16, e.transposed, e.cout, e.cin, e.ntaps_dst = int(dtype == torch.bfloat16), int(transposed), cout, cin, len(tap_map)
+        e.tapw_src, e.kpad_src = (cin + 3) // 4 * 4, src.shape[1]
+        e.tapw_dst, e.kpad_dst = ((cols + 7) // 8 * 8 if dtype == torch.bfloat16 else (cols + 3) // 4 * 4), dst.shape[1]
+        for i, t in enumerate(tap_map):
+            e.tap_map[i] = t
+        self._entries.append(e)
+        self._keep = getattr(self, "_keep", []) + [src, dst]
+        self._blocks += len(tap_map) * ((cout + 31) // 32) * ((cin + 31) // 32)
+        self._table = None
+        return dst
+
+    def run(self) -> None:
+        if not self._entries:
+            return
+        if self._table is None:
+            raw = b"".join(bytes(e) for e in self._entries)
+            self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
+        check(lib.mt4_refresh_weights(self._table.data_ptr(), len(self._entries), self._blocks, _stream()), "mt4_refresh_weights")
+
+
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     """fp32 -> bf16 copy (round to nearest even): the operand of a mixed-precision GEMM"""
     _need_cuda(x)

@@ -171,34 +171,16 @@ class SpatialCnnTrainer:
         (`mt4_refresh_weights`; a launch per matrix was ~350 launches = 1.5 ms per step).  Destinations are allocated once: captured graphs keep
         their addresses."""
         if getattr(self, "_refresh_table", None) is None:
-            import ctypes as C
-            from ._lib import RefreshEntry
             dt = torch.bfloat16 if self.op16 else F32
-            entries, block = [], 0
-
-            def add(u, dst, transposed, taps_dst, tap_map):
-                nonlocal block
-                e = RefreshEntry()
-                e.src, e.dst, e.block0 = u.w.data_ptr(), dst.data_ptr(), block
-                e.dst_bf16, e.transposed, e.cout, e.cin, e.ntaps_dst = int(dst.dtype == torch.bfloat16), int(transposed), u.cout, u.cin, taps_dst
-                e.tapw_src, e.kpad_src = (u.cin + 3) // 4 * 4, u.w.shape[1]
-                cols = u.cout if transposed else u.cin
-                e.tapw_dst, e.kpad_dst = (cols + 7) // 8 * 8 if dst.dtype == torch.bfloat16 else (cols + 3) // 4 * 4, dst.shape[1]
-                for i, t in enumerate(tap_map):
-                    e.tap_map[i] = t
-                entries.append(e)
-                block += taps_dst * ((u.cout + 31) // 32) * ((u.cin + 31) // 32)
-
+            tab = ops.RefreshTable(self.dev)
             for u in self.units.values():
                 if u.cin == 4:
                     continue   # stem: the image needs no gradient; it stays fp32
                 taps = u.k * u.k
                 if self.op16:
-                    u.w16 = torch.zeros((u.cout, ops.packed_k(u.cin, u.k, u.k, dt)), dtype=dt, device=self.dev)
-                    add(u, u.w16, False, taps, range(taps))
+                    u.w16 = tab.add(u.w, u.cout, u.cin, dt, False, range(taps), (u.k, u.k))
                 if u.stride == 1 or u.k == 1:
-                    wt = torch.zeros((u.cin, ops.packed_k(u.cout, u.k, u.k, dt)), dtype=dt, device=self.dev)
-                    add(u, wt, True, taps, [taps - 1 - t for t in range(taps)])
+                    wt = tab.add(u.w, u.cout, u.cin, dt, True, [taps - 1 - t for t in range(taps)], (u.k, u.k))
                     if self.op16:
                         u.wt16 = wt
                     else:
@@ -209,18 +191,14 @@ class SpatialCnnTrainer:
                     for ph in (0, 1):
                         for pw in (0, 1):
                             khs, kws = len(sel[ph]), len(sel[pw])
-                            dst = torch.zeros((u.cin, ops.packed_k(u.cout, khs, kws, dt)), dtype=dt, device=self.dev)
-                            add(u, dst, True, khs * kws, [sel[ph][a] * 3 + sel[pw][b] for a in range(khs) for b in range(kws)])
+                            dst = tab.add(u.w, u.cout, u.cin, dt, True, [sel[ph][a_] * 3 + sel[pw][b_] for a_ in range(khs) for b_ in range(kws)], (khs, kws))
                             ph_w[(ph, pw)] = (dst, khs, kws)
                     if self.op16:
                         u.phase_w16 = ph_w
                     else:
                         u.phase_w = ph_w
-            raw = b"".join(bytes(e) for e in entries)
-            self._refresh_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
-            self._refresh_n, self._refresh_blocks = len(entries), block
-        from ._lib import lib, check
-        check(lib.mt4_refresh_weights(self._refresh_table.data_ptr(), self._refresh_n, self._refresh_blocks, ops._stream()), "mt4_refresh_weights")
+            self._refresh_table = tab
+        self._refresh_table.run()
         # (the linear layers' data gradients transpose their small weights on the fly in _linear_bwd)
 
     def running_stats(self) -> Dict[str, torch.Tensor]:
