@@ -262,20 +262,31 @@ def mstct_train_bench(dev):
 
 def q2l_train_bench(dev, backbone="swin_L_384_22k", img=384, hidden=1536, B=16):
     """BASELINE configs[3]'s spatial half: one training step of the Swin-L + Query2Label teacher on the reference's batch (16 frames at 384 x 384,
-    `Scripts/train_fold1.sh:12`; `Spatial_transformer/run.py:150-229`): forward + BCE(pos_weight) + backward + SGD, fp32, DropPath 0.1 and the
-    transformer's dropout 0.1 on"""
+    `Scripts/train_fold1.sh:12`; `Spatial_transformer/run.py:150-229`): forward + BCE(pos_weight) + backward + SGD, DropPath 0.1 and the
+    transformer's dropout 0.1 on; fp32, and with the nn.Linear GEMMs on bf16 operand copies"""
     from computervision_codes_amd import shapes, synth
     from computervision_codes_amd.q2l_train import Q2LTrainer
-    tr = Q2LTrainer(backbone, img, hidden, "i", lr=0.01, device=str(dev)).load_state_dict(
-        synth.fill_from_shapes(shapes.q2l_param_shapes(backbone, img, hidden, "i"), seed=47))
-    frames = device_frames(B, img, img, 7, dev)
-    z = (torch.rand(B, 6, device=dev) < 0.3).float()
-    masks = tr.draw_masks_device(B, 1, 0)
-    ms = _time_call(lambda: tr.train_step(frames, z, masks=masks), iters=5)
     gflop_fwd = {"swin_L_384_22k": 207.8 + 13.6, "swin_B_384_22k": 94.2 + 7.0, "swin_T_224_1k": 9.0 + 1.3}[backbone]   # 2 x MACs: backbone + 1 decoder
-    return dict(ms_per_step=round(ms, 2), frames_per_s=round(B / ms * 1e3, 1), batch=B, img=img, backbone=backbone, dtype="f32",
-                approx_tflops=round(3 * gflop_fwd * B / ms, 1), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                note="fwd + BCE(pos_weight) + bwd + SGD, masks drawn outside the timed region, 1 GPU")
+    out = {}
+    for odt in (torch.float32, torch.bfloat16):
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        tr = Q2LTrainer(backbone, img, hidden, "i", lr=0.01, device=str(dev), operand_dtype=odt).load_state_dict(
+            synth.fill_from_shapes(shapes.q2l_param_shapes(backbone, img, hidden, "i"), seed=47))
+        frames = device_frames(B, img, img, 7, dev)
+        z = (torch.rand(B, 6, device=dev) < 0.3).float()
+        masks = tr.draw_masks_device(B, 1, 0)
+        ms = _time_call(lambda: tr.train_step(frames, z, masks=masks), iters=5)
+        rec = dict(ms_per_step=round(ms, 2), frames_per_s=round(B / ms * 1e3, 1), batch=B, img=img, backbone=backbone,
+                   dtype="f32" if odt == torch.float32 else "bf16 GEMM operands, fp32 activations / master weights",
+                   approx_tflops=round(3 * gflop_fwd * B / ms, 1), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                   note="fwd + BCE(pos_weight) + bwd + SGD, masks drawn outside the timed region, 1 GPU")
+        if odt == torch.float32:
+            out.update(rec)
+        else:
+            out["bf16_operands"] = rec
+        del tr
+    return out
 
 
 def device_frames(n, h, w, seed, dev, nbase=16):

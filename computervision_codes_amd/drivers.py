@@ -471,6 +471,8 @@ def spatial_transformer_train(argv=None) -> Dict[str, float]:
     p.add_argument("--val_interval", type=int, default=1)
     p.add_argument("--pretrain_dir", type=str, default="")
     p.add_argument("--drop_path_rate", type=float, default=0.1)          # `swin_transformer.py:488`
+    p.add_argument("--operand_dtype", type=str, default="fp32", choices=["fp32", "bf16"],
+                   help="bf16: the nn.Linear GEMMs on bf16 operand copies (fp32 activations, accumulation and master weights)")
     F, _ = p.parse_known_args(argv)
     if F.loss_type not in ("i", "v", "t"):
         raise StageNotBuilt("Spatial_transformer/run.py -t --loss_type all: the recipe trains single-task teachers (Scripts/train_fold1.sh:12, "
@@ -483,7 +485,7 @@ def spatial_transformer_train(argv=None) -> Dict[str, float]:
     ckpt, latest = os.path.join(model_dir, modelname + ".pth"), os.path.join(model_dir, modelname + "_latest.pth")
     val_interval = F.epochs - 1 if F.val_interval == -1 else F.val_interval
     tr = Q2LTrainer(F.backbone, F.img_size, F.hidden_dim, F.loss_type, lr=F.initial_learning_rates[2], weight_decay=F.weight_decay,
-                    drop_path_rate=F.drop_path_rate)
+                    drop_path_rate=F.drop_path_rate, operand_dtype=torch.bfloat16 if F.operand_dtype == "bf16" else torch.float32)
     table = shapes.q2l_param_shapes(F.backbone, F.img_size, F.hidden_dim, F.loss_type)
     sd = synth.fill_from_shapes(table, seed=F.seed)          # deterministic synthetic start when no pretrained file is on disk
     # `build_backbone` (`backbone.py:188-196`): the upstream Swin checkpoint ../Pretrain/<file> ('model' entry, `head.*` dropped) into the backbone

@@ -42,7 +42,7 @@ def _r4(n: int) -> int:
 
 class _Lin:
     """a GEMM weight (packed) + bias with gradient views; `wt` = transposed packed copy for the data gradient"""
-    __slots__ = ("name", "wkey", "bkey", "cout", "cin", "w", "b", "gw", "gb", "wt", "shape")
+    __slots__ = ("name", "wkey", "bkey", "cout", "cin", "w", "b", "gw", "gb", "wt", "shape", "w16", "wt16")
 
 
 class _Vec:
@@ -53,8 +53,9 @@ class FlatParams:
     """all trained tensors in ONE flat parameter buffer P and ONE flat gradient buffer G (packed GEMM layouts), plus the derived transposed
     copies; state-dict in / out in the reference's key names and shapes"""
 
-    def __init__(self, device):
-        self.dev = device
+    def __init__(self, device, op16: bool = False):
+        self.dev, self.op16 = device, op16
+        self.tab = ops.RefreshTable(device)          # every derived matrix (transposed fp32, bf16 copies) from one launch per refresh
         self._lin: List[tuple] = []
         self._vec: List[tuple] = []
         self.L: Dict[str, _Lin] = {}
@@ -86,7 +87,7 @@ class FlatParams:
             l.w.copy_(ops.pack_linear_weight(w.reshape(cout, cin).to(self.dev), F32))
             if bkey:
                 l.b.copy_(sd[bkey].float().to(self.dev))
-            l.wt = torch.zeros((cin, ops.packed_k(cout, 1, 1, F32)), dtype=F32, device=self.dev) if need_dgrad else None
+            self._derive(l, need_dgrad)
             self.L[name] = l
         for key, shape in self._vec:
             v = _Vec()
@@ -100,21 +101,28 @@ class FlatParams:
         self.refresh()
         return self
 
+    def _derive(self, l: _Lin, need_dgrad: bool):
+        """the matrices the kernels read besides the master weight: the transposed copy for the data gradient (fp32) and, in the bf16-operand
+        mode, bf16 copies of both for the GEMMs whose channel counts allow it"""
+        l.wt = self.tab.add(l.w, l.cout, l.cin, F32, True, [0]) if need_dgrad else None
+        l.w16 = l.wt16 = None
+        if self.op16 and l.cin % 8 == 0 and l.cout % 8 == 0 and l.cout >= 64:
+            l.w16 = self.tab.add(l.w, l.cout, l.cin, torch.bfloat16, False, [0])
+            if need_dgrad:
+                l.wt16 = self.tab.add(l.w, l.cout, l.cin, torch.bfloat16, True, [0])
+
     def rows(self, name: str, lo: int, hi: int) -> _Lin:
         """a row slice of a packed weight (nn.MultiheadAttention's in_proj split into q / k / v) with its own transposed copy"""
         src = self.L[name]
         l = _Lin()
         l.name, l.cout, l.cin = f"{name}[{lo}:{hi}]", hi - lo, src.cin
         l.w, l.gw, l.b, l.gb = src.w[lo:hi], src.gw[lo:hi], src.b[lo:hi], src.gb[lo:hi]
-        l.wt = torch.zeros((src.cin, ops.packed_k(hi - lo, 1, 1, F32)), dtype=F32, device=self.dev)
+        self._derive(l, True)
         self._slices.append(l)
-        ops.transpose_pack_conv1d(l.w, l.cout, l.cin, 1, out=l.wt)
         return l
 
     def refresh(self):
-        for l in list(self.L.values()) + self._slices:
-            if l.wt is not None:
-                ops.transpose_pack_conv1d(l.w, l.cout, l.cin, 1, out=l.wt)
+        self.tab.run()
 
     def _export(self, which: str) -> Dict[str, torch.Tensor]:
         out = {}
@@ -130,13 +138,20 @@ class FlatParams:
 
 class Q2LTrainer:
     def __init__(self, backbone: str = "swin_L_384_22k", img_size: int = 384, hidden_dim: int = 1536, loss_type: str = "i", lr: float = 0.01,
-                 weight_decay: float = 1e-5, drop_path_rate: float = 0.1, device: str = "cuda", process_group=None):
+                 weight_decay: float = 1e-5, drop_path_rate: float = 0.1, device: str = "cuda", process_group=None,
+                 operand_dtype: torch.dtype = torch.float32):
         if loss_type not in NCLS:
             raise NotImplementedError("the teacher recipe trains single-task heads: loss_type i | v | t (Scripts/train_fold1.sh:12-14)")
         self.backbone, self.S, self.d, self.task, self.K = backbone, int(img_size), int(hidden_dim), loss_type, NCLS[loss_type]
         self.cfg = SWIN_CFG[backbone]
         assert self.d == self.cfg["embed_dim"] * 8, "hidden_dim is the backbone's final width (backbone.py:188-201)"
         self.lr, self.wd, self.dev, self.pg = lr, weight_decay, torch.device(device), process_group
+        assert operand_dtype in (torch.float32, torch.bfloat16)
+        # bfloat16: the nn.Linear / patch-embedding GEMMs (forward, data and weight gradients) read bf16 copies of their operands; activations,
+        # accumulation, everything between the GEMMs and the master weights stay fp32 (as in `MstctTrainer`)
+        self.op16 = operand_dtype == torch.bfloat16
+        self._c16: Dict[tuple, tuple] = {}
+        self._dy16 = None
         self.exchange = True
         self._table = q2l_param_shapes(backbone, self.S, self.d, loss_type)
         nblk = sum(self.cfg["depths"])
@@ -146,7 +161,7 @@ class Q2LTrainer:
     # ------------------------------------------------------------------ parameters
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         assert all(k in sd for k, _ in self._table), "state dict incomplete"
-        fp, pre, C0, d = FlatParams(self.dev), "backbone.0.", self.cfg["embed_dim"], self.d
+        fp, pre, C0, d = FlatParams(self.dev, self.op16), "backbone.0.", self.cfg["embed_dim"], self.d
         fp.lin("pe", pre + "patch_embed.proj.weight", pre + "patch_embed.proj.bias", C0, 48, need_dgrad=False)
         fp.vec(pre + "patch_embed.norm.weight", (C0,)); fp.vec(pre + "patch_embed.norm.bias", (C0,))
         self.stages = []
@@ -191,6 +206,7 @@ class Q2LTrainer:
         fp.build(sd)
         self.fp, self.P, self.G = fp, fp.P, fp.G
         self.att = {tag: tuple(fp.rows(tag + ".in", i * d, (i + 1) * d) for i in range(3)) for tag, *_ in layers}
+        fp.refresh()                                   # (the q / k / v row slices joined the table after build())
         self.layer_prefix = {tag: lp for tag, lp, _, _ in layers}
         self.layer_norms = {tag: norms for tag, _, _, norms in layers}
         hh = self.S // 32
@@ -235,16 +251,46 @@ class Q2LTrainer:
         return {"droppath": dp, "tx": tx}
 
     # ------------------------------------------------------------------ building blocks
+    def _cast(self, x2d, grad=False):
+        """bf16 copy of a GEMM operand: forward activations once per step, kept with their source (the copy also serves the weight gradient, and
+        holding the source keeps the allocator from reusing its address); of the short-lived gradients only the latest is remembered"""
+        key = (x2d.data_ptr(), tuple(x2d.shape))
+        if grad:
+            if self._dy16 is not None and self._dy16[0] == key:
+                return self._dy16[2]
+            y = ops.cast_bf16(x2d)
+            self._dy16 = (key, x2d, y)
+            return y
+        hit = self._c16.get(key)
+        if hit is None:
+            hit = self._c16[key] = (x2d, ops.cast_bf16(x2d))
+        return hit[1]
+
     def _fwd(self, x, l: _Lin, residual=None, act=None, out_row_map=None):
+        if l.w16 is not None:
+            x = x if x.is_contiguous() else x.contiguous()
+            return ops.linear(self._cast(x), l.w16, l.b, residual=residual, act=act, out_row_map=out_row_map, out_dtype=F32)
         return ops.linear(x, l.w, l.b, residual=residual, act=act, out_row_map=out_row_map)
 
     def _bwd(self, dy, x, l: _Lin, need_dx=True, residual=None, gate=None):
         """parameter gradients of y = x W^T + b from dy; returns dx (+ residual; gate: ReLU of the layer below, `act=relu_gate`)"""
-        ops.wgrad_conv1d(dy, x, l.gw, batch=1, t=dy.shape[0], taps=1, dil=1, pad=0, accumulate=True)
+        m = dy.shape[0]
+        mixed = l.w16 is not None and m % 16 == 0
+        if mixed:
+            dy = dy if dy.is_contiguous() else dy.contiguous()
+            x = x if x.is_contiguous() else x.contiguous()
+            dy16 = self._cast(dy, grad=True)
+            ops.wgrad_conv2d_bf16(dy16.view(1, m // 16, 16, l.cout), self._cast(x).view(1, m // 16, 16, l.cin), l.gw, 1, 1)   # (adds to gw)
+        else:
+            ops.wgrad_conv1d(dy, x, l.gw, batch=1, t=m, taps=1, dil=1, pad=0, accumulate=True)
         if l.gb is not None:
             ops.colsum(dy, l.gb, accumulate=True)
         if not need_dx:
             return None
+        if mixed and l.wt16 is not None:
+            if gate is not None:
+                return ops.linear(dy16, l.wt16, None, residual=gate, act="relu_gate", out_dtype=F32)
+            return ops.linear(dy16, l.wt16, None, residual=residual, out_dtype=F32)
         if gate is not None:
             return ops.linear(dy, l.wt, None, residual=gate, act="relu_gate")
         return ops.linear(dy, l.wt, None, residual=residual)
@@ -382,6 +428,8 @@ class Q2LTrainer:
         tm = lambda k: tx.get(k)
         pre = "backbone.0."
         self.G.zero_()
+        self._c16.clear()
+        self._dy16 = None
         # ---- backbone forward
         rows = ops.patchify(img, 4, F32, IMAGENET_MEAN, IMAGENET_STD)
         pe = self._fwd(rows, fp.L["pe"])

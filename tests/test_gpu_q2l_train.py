@@ -166,3 +166,26 @@ def test_q2l_device_draw_is_the_counter_generator(cuda):
     assert tuple(m["tx"]["dec1.ffn"].shape) == dict(specs)["dec1.ffn"] == (3 * 6, 8192)
     frac = float((m["tx"]["enc.ffn"] == 0).float().mean())
     assert 0.08 < frac < 0.12
+
+
+def test_q2l_bf16_operand_step_vs_reference_fixture(cuda):
+    """`Q2LTrainer(operand_dtype=torch.bfloat16)`: the nn.Linear / patch-embedding GEMMs (forward, data and weight gradients, the ReLU-gated data
+    gradient of the FFN included) on bf16 copies of their operands, fp32 activations / accumulation / master weights.  DECLARED tolerance against
+    the fp32 fixture of the reference step: loss 3e-3, every gradient norm 3 % (floor 1e-6 of the largest); with DropPath / dropout draws the step
+    follows the fp32 trainer on the same draws"""
+    z, cfg = load_golden("q2l_train_swinT_t")
+    tr, sd, table = _trainer(cfg, operand_dtype=torch.bfloat16)
+    assert tr.fp.L["backbone.0.layers.2.blocks.3.fc1"].w16 is not None and tr.fp.L["pe"].w16 is not None and tr.att["enc"][1].wt16 is not None
+    img, y = _inputs(cfg)
+    loss = tr.train_step(img.to(cuda), y, apply_update=False)
+    assert abs(loss - float(z["loss"])) < 3e-3 * max(1.0, abs(float(z["loss"]))), (loss, float(z["loss"]))
+    grads = tr.grads()
+    floor = 1e-6 * float(z["grad_norms"].max())
+    rel = [abs(float(grads[k].norm()) - ref) / max(ref, floor) for (k, _), ref in zip(table, z["grad_norms"])]
+    assert max(rel) < 3e-2, max(rel)
+    masks = tr.draw_masks(cfg["B"], torch.Generator().manual_seed(9))
+    curves = []
+    for dt in (torch.float32, torch.bfloat16):
+        t2, _, _ = _trainer(dict(cfg, lr=2e-3), operand_dtype=dt)
+        curves.append([t2.train_step(img.to(cuda), y, masks=masks) for _ in range(4)])
+    assert all(abs(a - b) <= 1e-2 * abs(a) for a, b in zip(*curves)), curves
