@@ -101,7 +101,7 @@ SIGNATURES = {
     "mt4_mse_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, _vp]),
     "mt4_bn_stats_t": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, C.c_float, C.c_float, _vp]),
     "mt4_bn_apply_t": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _vp]),
-    "mt4_bn_backward_t": (C.c_int, [_vp, _vp, _vp, _i32] + [_vp] * 8 + [C.c_int64, _i32, _i32, _vp]),
+    "mt4_bn_backward_t": (C.c_int, [_vp, _vp, _vp, _i32] + [_vp] * 9 + [C.c_int64, _i32, _i32, _vp]),
     "mt4_wgrad_conv2d_bf16": (C.c_int, [_vp, _vp, _vp] + [_i32] * 9 + [_vp]),
     "mt4_maxpool3x3s2_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_avgpool_bwd_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),

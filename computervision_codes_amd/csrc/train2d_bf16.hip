@@ -90,18 +90,29 @@ __global__ void bn_apply_t_kernel(const TZ* __restrict__ x, const float* __restr
     st4<u16>(y + i * 4, o);
 }
 
+// relu: 0 none; 1 the ReLU gate is read from the stored output y; 2 it is recomputed from x -- (x - mean) * invstd * gamma + beta > 0, the
+// forward's own fp32 expression -- for units without a residual input: y need not be read (2 of the 6 / 8 bytes per element these HBM-bound
+// kernels move)
 template <typename TZ>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_t_kernel(const u16* __restrict__ dy, const u16* __restrict__ y, const TZ* __restrict__ x,
-                                                              const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ sums,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, double* __restrict__ sums,
                                                               long long M, int C, int relu) {
     const int c0 = blockIdx.x * 64, c = c0 + (threadIdx.x & 15) * 4;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (c < C) {
         const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
+        float4 ga = make_float4(0, 0, 0, 0), be = ga;
+        if (relu == 2) { ga = *(const float4*)(gamma + c); be = *(const float4*)(beta + c); }
         for (long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4); m < M; m += (long long)gridDim.y * 16) {
             float4 g = ld4<u16>(dy + m * C + c);
             const float4 xv = ld4<TZ>(x + m * C + c);
-            if (relu) {
+            if (relu == 2) {
+                if (!((xv.x - mu.x) * is.x * ga.x + be.x > 0.f)) g.x = 0.f;
+                if (!((xv.y - mu.y) * is.y * ga.y + be.y > 0.f)) g.y = 0.f;
+                if (!((xv.z - mu.z) * is.z * ga.z + be.z > 0.f)) g.z = 0.f;
+                if (!((xv.w - mu.w) * is.w * ga.w + be.w > 0.f)) g.w = 0.f;
+            } else if (relu) {
                 const float4 yv = ld4<u16>(y + m * C + c);
                 if (!(yv.x > 0.f)) g.x = 0.f;
                 if (!(yv.y > 0.f)) g.y = 0.f;
@@ -119,14 +130,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_t_kernel(const u16* __restr
 // dx has the type of x (the convolution output: bf16, or fp32 for the stem); dres = the gated gradient, bf16
 template <typename TZ>
 __global__ void bn_bwd_apply_t_kernel(const u16* __restrict__ dy, const u16* __restrict__ y, const TZ* __restrict__ x, const float* __restrict__ mean,
-                                      const float* __restrict__ invstd, const float* __restrict__ gamma, const double* __restrict__ sums, TZ* __restrict__ dx,
-                                      u16* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta, long long M, int C, int relu) {
+                                      const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const double* __restrict__ sums, TZ* __restrict__ dx, u16* __restrict__ dres, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, long long M, int C, int relu) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < C) { dbeta[i] = (float)sums[i]; dgamma[i] = (float)sums[C + i]; }
     if (i >= M * C / 4) return;
     const int c = (int)((i * 4) % C);
     float4 g = ld4<u16>(dy + i * 4);
-    if (relu) {
+    if (relu == 2) {
+        const float4 xg = ld4<TZ>(x + i * 4), mg = *(const float4*)(mean + c), ig = *(const float4*)(invstd + c), gg = *(const float4*)(gamma + c),
+                     bg = *(const float4*)(beta + c);
+        if (!((xg.x - mg.x) * ig.x * gg.x + bg.x > 0.f)) g.x = 0.f;
+        if (!((xg.y - mg.y) * ig.y * gg.y + bg.y > 0.f)) g.y = 0.f;
+        if (!((xg.z - mg.z) * ig.z * gg.z + bg.z > 0.f)) g.z = 0.f;
+        if (!((xg.w - mg.w) * ig.w * gg.w + bg.w > 0.f)) g.w = 0.f;
+    } else if (relu) {
         const float4 yv = ld4<u16>(y + i * 4);
         if (!(yv.x > 0.f)) g.x = 0.f;
         if (!(yv.y > 0.f)) g.y = 0.f;
@@ -524,11 +543,11 @@ extern "C" int mt4_bn_apply_t(const void* x, int32_t x_dtype, const float* mean,
 }
 
 extern "C" int mt4_bn_backward_t(const void* dy_bf16, const void* y_post_bf16, const void* x, int32_t x_dtype, const float* mean, const float* invstd,
-                                 const float* gamma, double* sums_zeroed, void* dx, void* dres_bf16, float* dgamma, float* dbeta, int64_t M, int32_t C,
-                                 int32_t relu, void* stream) {
+                                 const float* gamma, const float* beta, double* sums_zeroed, void* dx, void* dres_bf16, float* dgamma, float* dbeta,
+                                 int64_t M, int32_t C, int32_t relu, void* stream) {
     mt4_clear_error();
     if (!dy_bf16 || !x || !mean || !invstd || !gamma || !sums_zeroed || !dx || !dgamma || !dbeta || M <= 0 || C <= 0) return MT4_EINVAL;
-    if (relu && !y_post_bf16) return MT4_EINVAL;
+    if (relu < 0 || relu > 2 || (relu == 1 && !y_post_bf16) || (relu == 2 && !beta)) return MT4_EINVAL;
     if (C % 4) return MT4_EALIGN;
     if (x_dtype != MT4_BF16 && x_dtype != MT4_F32) return MT4_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -538,12 +557,12 @@ extern "C" int mt4_bn_backward_t(const void* dy_bf16, const void* y_post_bf16, c
     const dim3 g2((unsigned)((n + 255) / 256));
     const u16 *dy = (const u16*)dy_bf16, *yp = (const u16*)y_post_bf16;
     if (x_dtype == MT4_BF16) {
-        hipLaunchKernelGGL(bn_bwd_reduce_t_kernel<u16>, g1, dim3(256), 0, s, dy, yp, (const u16*)x, mean, invstd, sums_zeroed, (long long)M, C, relu);
-        hipLaunchKernelGGL(bn_bwd_apply_t_kernel<u16>, g2, dim3(256), 0, s, dy, yp, (const u16*)x, mean, invstd, gamma, sums_zeroed, (u16*)dx, (u16*)dres_bf16,
-                           dgamma, dbeta, (long long)M, C, relu);
+        hipLaunchKernelGGL(bn_bwd_reduce_t_kernel<u16>, g1, dim3(256), 0, s, dy, yp, (const u16*)x, mean, invstd, gamma, beta, sums_zeroed, (long long)M, C, relu);
+        hipLaunchKernelGGL(bn_bwd_apply_t_kernel<u16>, g2, dim3(256), 0, s, dy, yp, (const u16*)x, mean, invstd, gamma, beta, sums_zeroed, (u16*)dx,
+                           (u16*)dres_bf16, dgamma, dbeta, (long long)M, C, relu);
     } else {
-        hipLaunchKernelGGL(bn_bwd_reduce_t_kernel<float>, g1, dim3(256), 0, s, dy, yp, (const float*)x, mean, invstd, sums_zeroed, (long long)M, C, relu);
-        hipLaunchKernelGGL(bn_bwd_apply_t_kernel<float>, g2, dim3(256), 0, s, dy, yp, (const float*)x, mean, invstd, gamma, sums_zeroed, (float*)dx,
+        hipLaunchKernelGGL(bn_bwd_reduce_t_kernel<float>, g1, dim3(256), 0, s, dy, yp, (const float*)x, mean, invstd, gamma, beta, sums_zeroed, (long long)M, C, relu);
+        hipLaunchKernelGGL(bn_bwd_apply_t_kernel<float>, g2, dim3(256), 0, s, dy, yp, (const float*)x, mean, invstd, gamma, beta, sums_zeroed, (float*)dx,
                            (u16*)dres_bf16, dgamma, dbeta, (long long)M, C, relu);
     }
     return mt4_check_launch();

@@ -731,16 +731,19 @@ def bn_apply_t(x2d, mean, invstd, gamma, beta, residual=None, relu=True):
     return y
 
 
-def bn_backward_t(dy, y_post, x2d, mean, invstd, gamma, dgamma, dbeta, relu=True, want_dres=False, sums=None):
-    """dy / y_post bf16; x2d (the convolution output) bf16 or fp32 -> dx of that type; dres bf16"""
+def bn_backward_t(dy, y_post, x2d, mean, invstd, gamma, dgamma, dbeta, relu=True, want_dres=False, sums=None, beta=None):
+    """dy / y_post bf16; x2d (the convolution output) bf16 or fp32 -> dx of that type; dres bf16.  With `beta` and relu the ReLU gate is recomputed
+    from x2d instead of read from y_post (units without a residual input)"""
     m, c = x2d.shape
     assert sums is not None and sums.dtype == torch.float64 and sums.numel() == 2 * c
     assert dy.dtype == BF16 and dy.is_contiguous() and x2d.is_contiguous() and (y_post is None or (y_post.dtype == BF16 and y_post.is_contiguous()))
     dx = torch.empty_like(x2d)
     dres = torch.empty((m, c), dtype=BF16, device=x2d.device) if want_dres else None
-    check(lib.mt4_bn_backward_t(dy.data_ptr(), y_post.data_ptr() if y_post is not None else None, x2d.data_ptr(), dt_code(x2d.dtype), mean.data_ptr(),
-                                invstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(), dx.data_ptr(), dres.data_ptr() if want_dres else None,
-                                dgamma.data_ptr(), dbeta.data_ptr(), m, c, 1 if relu else 0, _stream()), "mt4_bn_backward_t")
+    code = 0 if not relu else (2 if beta is not None else 1)
+    check(lib.mt4_bn_backward_t(dy.data_ptr(), y_post.data_ptr() if (y_post is not None and code == 1) else None, x2d.data_ptr(), dt_code(x2d.dtype),
+                                mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr() if beta is not None else None, sums.data_ptr(),
+                                dx.data_ptr(), dres.data_ptr() if want_dres else None, dgamma.data_ptr(), dbeta.data_ptr(), m, c, code, _stream()),
+          "mt4_bn_backward_t")
     return dx, dres
 
 

@@ -263,7 +263,7 @@ class SpatialCnnTrainer:
             mean, invstd = ops.bn_stats(z2, u.rmean, u.rvar, sums=u.sums_f)
             a = ops.bn_apply(z2, mean, invstd, u.gamma, u.beta, residual.view(-1, c) if residual is not None else None, relu).view(b, ho, wo, c)
         if saved is not None:
-            saved.append((u, x, z, mean, invstd, a, relu))
+            saved.append((u, x, z, mean, invstd, a, relu, residual is not None))
         return a
 
     def _dgrad(self, u: _Unit, dz, x_shape, residual=None):
@@ -295,11 +295,14 @@ class SpatialCnnTrainer:
         return self._row_maps[key]
 
     def _bwd_unit(self, rec, dy, residual_for_dx=None, want_dres=False, need_dx=True):
-        u, x, z, mean, invstd, a, relu = rec
+        u, x, z, mean, invstd, a, relu, has_res = rec
         c = z.shape[-1]
-        bnb = ops.bn_backward_t if self.op16 else ops.bn_backward
-        dz, dres = bnb(dy.reshape(-1, c), a.view(-1, c) if relu else None, z.view(-1, c), mean, invstd, u.gamma, u.ggamma, u.gbeta,
-                       relu=relu, want_dres=want_dres, sums=u.sums_b)
+        if self.op16:   # (units without a residual input recompute their ReLU gate from z: the stored activation is not read)
+            dz, dres = ops.bn_backward_t(dy.reshape(-1, c), a.view(-1, c) if relu else None, z.view(-1, c), mean, invstd, u.gamma, u.ggamma, u.gbeta,
+                                         relu=relu, want_dres=want_dres, sums=u.sums_b, beta=u.beta if (relu and not has_res) else None)
+        else:
+            dz, dres = ops.bn_backward(dy.reshape(-1, c), a.view(-1, c) if relu else None, z.view(-1, c), mean, invstd, u.gamma, u.ggamma, u.gbeta,
+                                       relu=relu, want_dres=want_dres, sums=u.sums_b)
         dz = dz.view(z.shape)
         if self.op16 and u.cin != 4:
             ops.wgrad_conv2d_bf16(dz, x, u.gw, u.k, u.stride)                                         # (adds to G, zeroed once per step)
@@ -423,7 +426,7 @@ class SpatialCnnTrainer:
         self._arena.zero_()
         self.G.zero_()
         saved: List[tuple] = []
-        self.last_saved = saved          # (unit, input, conv output, mean, invstd, post-activation, relu) per conv+BN, forward order
+        self.last_saved = saved          # (unit, input, conv output, mean, invstd, post-activation, relu, has residual) per conv+BN, forward order
         pre = "basemodel.basemodel."
         U = self.units
         a0 = self._fwd_unit(U[pre + "conv1"], xp, saved=saved)
@@ -517,7 +520,7 @@ class SpatialCnnTrainer:
 
     def relu_outputs(self) -> Dict[str, torch.Tensor]:
         """post-ReLU activations of the last step by BatchNorm name, NCHW on the host (tests: ReLU-gate comparison)"""
-        return {u.bn: a.permute(0, 3, 1, 2).cpu() for (u, _, _, _, _, a, relu) in self.last_saved if relu}
+        return {u.bn: a.permute(0, 3, 1, 2).cpu() for (u, _, _, _, _, a, relu, _) in self.last_saved if relu}
 
     def apply_update(self):
         if self._pending:                                   # buckets were reduced during the backward

@@ -292,10 +292,12 @@ int mt4_bn_stats_t(const void* x, int32_t x_dtype, double* sums_zeroed, float* m
 /* y (bf16) = act( (x - mean) * invstd * gamma + beta [+ residual (bf16)] ) */
 int mt4_bn_apply_t(const void* x, int32_t x_dtype, const float* mean, const float* invstd, const float* gamma, const float* beta,
                    const void* residual_bf16, void* y_bf16, int64_t M, int32_t C, int32_t relu, void* stream);
-/* as mt4_bn_backward_f32 with dy / y_post / dres in bf16 and dx in the type of x */
+/* as mt4_bn_backward_f32 with dy / y_post / dres in bf16 and dx in the type of x.  relu: 0 none; 1 the ReLU gate is read from y_post; 2 it is
+ * recomputed from x ((x - mean) * invstd * gamma + beta > 0, the forward's own expression; units WITHOUT a residual input only): y_post may be
+ * NULL and is not read */
 int mt4_bn_backward_t(const void* dy_bf16, const void* y_post_bf16, const void* x, int32_t x_dtype, const float* mean, const float* invstd,
-                      const float* gamma, double* sums_zeroed, void* dx, void* dres_bf16, float* dgamma, float* dbeta, int64_t M, int32_t C,
-                      int32_t relu, void* stream);
+                      const float* gamma, const float* beta, double* sums_zeroed, void* dx, void* dres_bf16, float* dgamma, float* dbeta, int64_t M,
+                      int32_t C, int32_t relu, void* stream);
 /* Conv2d weight gradient on bf16 MFMA: dw_packed (fp32, the layout of mt4_pack_conv_weight(MT4_F32)) += sum_pixels dy[p][n] * x[in(p, tap)][c].
  * dy [B][Ho][Wo][Cout] bf16, x [B][H][W][Cin] bf16; K = 1 or 3 (square, pad K / 2), stride 1 or 2 (MT4_EUNSUPPORTED otherwise), Cin % 8 == 0 and
  * Cout % 8 == 0 (MT4_EALIGN).  The pixel range is split over workgroups and summed with fp32 atomics (order run-dependent). */

@@ -83,6 +83,11 @@ def test_batchnorm_bf16_fwd_bwd(cuda, m, c, relu, res, xf32):
     assert (db.cpu() - bt.grad).abs().max().item() <= 2e-3 * max(1.0, bt.grad.abs().max().item())
     if res:
         assert (dres.float().cpu() - rt.grad).abs().max().item() <= 2 ** -8 * max(1.0, rt.grad.abs().max().item())
+    if relu and not res:   # the gate recomputed from x == the gate read from the stored output
+        dg2, db2 = torch.zeros(c, device=cuda), torch.zeros(c, device=cuda)
+        sums2 = torch.zeros(2 * c, dtype=torch.float64, device=cuda)
+        dx2, _ = ops.bn_backward_t(dy.to(cuda), None, x.to(cuda), mean, invstd, g.to(cuda), dg2, db2, relu=True, sums=sums2, beta=bta.to(cuda))
+        assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
 def test_pool_backward_and_repack_bf16(cuda):
