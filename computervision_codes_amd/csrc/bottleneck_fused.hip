@@ -141,14 +141,18 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
         if (kc + 2 < KC) { if (kc & 1) load_chunk(kc + 2, stg1); else load_chunk(kc + 2, stg0); }
         __syncthreads();
         const char* sb = xs + (kc & 1) * XS_BYTES + r16 * ROW_B;
+        // all 20 fragments of the chunk go in flight before the first MFMA (left alone, hipcc pairs each read with its MFMA and every MFMA
+        // waits out an LDS round trip); the empty asm keeps the reads above it
+        uint4 fx[2][10];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            uint4 fx[10];
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 10; ++i) fx[i] = *(const uint4*)(sb + i * 16 * ROW_B + (kk ? sw1 : sw0));
+            for (int i = 0; i < 10; ++i) fx[kk][i] = *(const uint4*)(sb + i * 16 * ROW_B + (kk ? sw1 : sw0));
+        asm volatile("" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 10; ++i) acc1[i] = mfma_bf16(wf1[kc * 2 + kk], fx[i], acc1[i]);
-        }
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 10; ++i) acc1[i] = mfma_bf16(wf1[kc * 2 + kk], fx[kk][i], acc1[i]);
     }
     // weights of conv2 and the residual pixels go in flight now; they are consumed after the t1 hand-off
     uint4 wf2[18];
@@ -160,6 +164,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
     // From here on the tile is an 8 x 16 grid: pixel tile ty = output row ty, lane r16 = column tx (columns 14, 15 are never stored; they
     // read the two slack rows behind t1).  Every LDS row index is then 16 * (row of tiles) + r16 + shift, so the XOR swizzle depends on the
     // lane only and each fragment address is a per-lane constant plus an immediate.
+    // (The residual pixels are requested here, after phase 1: asked for together with the x chunks -- the same cache lines -- the block took
+    // 1.53 ms instead of 1.47.)
     const int wcol = w0 + r16;
     const bool col_ok = r16 < TW && wcol < a.W;
     const unsigned roff = (unsigned)(wcol * 512 + (wave * 16 + q * 4) * 2);   // this lane's bytes in an image row; channel tile 4 i + wave: + 128 i
@@ -205,16 +211,20 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
         for (int kk = 0; kk < 2; ++kk) toff[kw][kk] = (r16 + kw) * ROW_B + (((kk * 4 + q) ^ ((r16 + kw) & 7)) << 4);
 #pragma unroll
     for (int hr = 0; hr < 10; ++hr) {
+        uint4 fr[3][2];                                    // the six fragments of a halo row in flight together
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
+        for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const uint4 fx = *(const uint4*)(t1 + hr * (16 * ROW_B) + toff[kw][kk]);
+            for (int kk = 0; kk < 2; ++kk) fr[kw][kk] = *(const uint4*)(t1 + hr * (16 * ROW_B) + toff[kw][kk]);
+        asm volatile("" ::: "memory");
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const int ty = hr - kh;
-                    if (ty >= 0 && ty < 8) acc2[ty] = mfma_bf16(wf2[(kh * 3 + kw) * 2 + kk], fx, acc2[ty]);
-                }
+        for (int kh = 0; kh < 3; ++kh) {                   // per accumulator the K order stays (kh, kw) ascending, kk inner
+            const int ty = hr - kh;
+            if (ty >= 0 && ty < 8) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) acc2[ty] = mfma_bf16(wf2[(kh * 3 + kw) * 2 + kk], fr[kw][kk], acc2[ty]);
             }
         }
     }
@@ -298,14 +308,17 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
             const int w = w0 + st_tx;
             const int rd_off = st_tx * 256 + ((st_chunk ^ st_tx) << 4);
             if (st_tx < TW && w < a.W) {
+                uint4 v[8];
+#pragma unroll
+                for (int ty = 0; ty < 8; ++ty) v[ty] = *(const uint4*)(ys + ty * (16 * 256) + rd_off);
+                asm volatile("" ::: "memory");
 #pragma unroll
                 for (int ty = 0; ty < 8; ++ty) {
                     if (h0 + ty < a.H) {
                         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                        const uint4 v = *(const uint4*)(ys + ty * (16 * 256) + rd_off);
                         char* yp = yimg + (unsigned)((h0 + ty) * a.W * 512) + (unsigned)(w * 512 + pass * 256 + st_chunk * 16);
-                        if (a.nt) __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, (u32x4*)yp);
-                        else *(uint4*)yp = v;
+                        if (a.nt) __builtin_nontemporal_store((u32x4){v[ty].x, v[ty].y, v[ty].z, v[ty].w}, (u32x4*)yp);
+                        else *(uint4*)yp = v[ty];
                     }
                 }
             }
