@@ -135,6 +135,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
         for (int i = 0; i < 10; ++i) acc1[i] = b4;
     }
     const int sw0 = (q ^ (r16 & 7)) << 4, sw1 = ((4 + q) ^ (r16 & 7)) << 4;   // fragment chunk of kk = 0 / 1 in rows 16 i + r16
+    // identity blocks: the residual of output channels 64 i + 16 wave + 4 q .. + 3 (channel tile 4 i + wave of pass i / 2) IS x chunk i at the
+    // tile's own pixels -- picked out of the LDS copy of the chunk while it is there (row (j + 1) * 16 + r16 + 1 of the halo tile) instead of
+    // read from memory a second time (the re-read had left the XCD's L2 by phase 3 and came back over the fabric: 2.1 GB per block)
+    uint2 res[DS ? 1 : 4][DS ? 1 : 8];
+    const int res_off = (r16 + 1) * ROW_B + (((2 * wave + (q >> 1)) ^ ((r16 + 1) & 7)) << 4) + (q & 1) * 8;
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
         if (kc & 1) store_chunk(1, stg1); else store_chunk(0, stg0);
@@ -148,6 +153,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 10; ++i) fx[kk][i] = *(const uint4*)(sb + i * 16 * ROW_B + (kk ? sw1 : sw0));
+        if constexpr (!DS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) res[kc][j] = *(const uint2*)(xs + (kc & 1) * XS_BYTES + (j + 1) * (16 * ROW_B) + res_off);
+        }
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -164,22 +173,6 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
     // From here on the tile is an 8 x 16 grid: pixel tile ty = output row ty, lane r16 = column tx (columns 14, 15 are never stored; they
     // read the two slack rows behind t1).  Every LDS row index is then 16 * (row of tiles) + r16 + shift, so the XOR swizzle depends on the
     // lane only and each fragment address is a per-lane constant plus an immediate.
-    // (The residual pixels are requested here, after phase 1: asked for together with the x chunks -- the same cache lines -- the block took
-    // 1.53 ms instead of 1.47.)
-    const int wcol = w0 + r16;
-    const bool col_ok = r16 < TW && wcol < a.W;
-    const unsigned roff = (unsigned)(wcol * 512 + (wave * 16 + q * 4) * 2);   // this lane's bytes in an image row; channel tile 4 i + wave: + 128 i
-    uint2 res[DS ? 1 : 4][DS ? 1 : 8];
-    if constexpr (!DS) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                res[i][j] = make_uint2(0, 0);
-                if (col_ok && h0 + j < a.H)
-                    res[i][j] = *(const uint2*)(ximg + (unsigned)((h0 + j) * a.W * 512) + (roff + i * 128));
-            }
-    }
     const int cb1 = (ch1 + q * 4) * 2;                    // byte offset of this lane's 4 channels in a 128-byte row
     {   // t1 rows: relu, zero outside the image, 4 channels = 8 bytes per lane and pixel tile
         const int wr_off = r16 * ROW_B + (((cb1 >> 4) ^ (r16 & 7)) << 4) + (cb1 & 8);
