@@ -16,7 +16,8 @@
 //            of t1 for all 160 halo pixels; out-of-image halo pixels are written as zeros.
 //   phase 2: conv2 from t1 (tap (kh, kw) of pixel (ty, tx) = t1 row (ty + kh) * 16 + tx + kw); wave w: 16 channels x 7 pixel tiles.
 //   phase 3: conv3 in two passes of 128 output channels; wave w owns channel tiles w, w + 4, w + 8, w + 12; residual added in the
-//            accumulator layout (8-byte loads issued before phase 2), result staged in LDS and stored as 16-byte vectors, 256 B per pixel.
+//            accumulator layout (identity blocks: picked out of the LDS copy of x chunk i during phase 1 -- no second read), result staged in
+//            LDS and stored as 16-byte vectors, 256 B per pixel.
 // K order and MFMA chain (bias-initialised fp32 accumulator; K-steps of 64 channels ascending, 3x3: tap-major; two 32-wide MFMAs per step;
 // t1 / t2 / the downsample branch rounded to bf16 exactly where the layer-by-layer path stores them) are those of the stand-alone launches:
 // the result is bit-identical to conv1 -> conv2 -> conv3 through mt4_conv_nhwc.
@@ -319,13 +320,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
     }
 }
 
-// A persistent form of this kernel (one workgroup of 8 waves per CU walking tiles, the next tile's whole x halo fetched by LDS-DMA while the
-// current tile computes, conv1 / conv2 weights resident in registers) was built and measured: bit-identical, but SLOWER -- 2.4-2.7 ms per
-// 1336-frame block against 1.47 ms here (compute alone 1.1-1.3 ms against 0.74 ms: eight waves meeting at ten barriers per tile leave the CU
-// idle where two independent workgroups fill each other's stalls; and at 256 registers every spill reload in front of a DMA or store costs a
-// vmcnt(0)).  A three-workgroups-per-CU form (40 KB of LDS: one x chunk buffer reused for t2, t1 reused as a 16 KB staging for four passes of 64
-// channels; 168 registers: residual and conv3 weights fetched a pass ahead; 18 barriers per tile) is bit-identical too and runs in exactly the
-// same 1.44 ms: occupancy is not what holds the kernel back.
+// Forms of this kernel that were built, are bit-identical, and lost (1336 frames per block, identity blocks): a persistent one (one workgroup of
+// 8 waves per CU walking tiles, the next tile's whole x halo fetched by LDS-DMA while the current tile computes, conv1 / conv2 weights resident in
+// registers) 2.4-2.7 ms -- eight waves meeting at ten barriers per tile leave the CU idle where two independent workgroups fill each other's
+// stalls, and at 256 registers every spill reload in front of a DMA or store costs a vmcnt(0); three workgroups per CU (40 KB of LDS: one x chunk
+// buffer reused for t2, t1 reused as a 16 KB staging for four passes of 64 channels; 168 registers; 18 barriers per tile) 1.44 ms, exactly the
+// two-workgroup time of that moment: the bound was the residual's second trip over the fabric (see phase 1), not occupancy.
 template <int CIN, bool DS>
 int launch(const BneckK& a, hipStream_t stream) {
     constexpr int NXS = CIN > 64 ? 2 : 1;
