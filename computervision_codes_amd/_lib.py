@@ -112,7 +112,9 @@ SIGNATURES = {
     "mt4_tcn_conv": (C.c_int, [C.POINTER(TcnDesc), _vp]),
     "mt4_tcn_dilated_residual_layer": (C.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
     "mt4_tcn_stage": (C.c_int, [_vp] * 5 + [C.POINTER(_vp)] * 4 + [_i32] * 5 + [_vp]),
-    "mt4_bottleneck_fused_bf16": (C.c_int, [_vp] * 10 + [_i32] * 5 + [_vp]),
+    "mt4_bottleneck_packed_bytes": (C.c_int64, [_i32, _i32]),
+    "mt4_bottleneck_pack_bf16": (C.c_int, [_vp] * 4 + [_i32, _vp, _vp]),
+    "mt4_bottleneck_fused_bf16": (C.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
     "mt4_fpn_topdown": (C.c_int, [_vp, _vp, _i32, C.c_int64, _i32, _vp]),
     "mt4_bgemm_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                 C.c_float, _i32, _vp]),

@@ -11,7 +11,9 @@
 // A workgroup (4 waves) owns an 8 x 14 pixel tile of one frame: 112 output pixels = 7 MFMA pixel tiles, halo 10 x 16 = 160 pixels = 10 pixel
 // tiles (one per halo row).  As in igemm_conv.hip the weight tile is the MFMA A operand and the pixel tile the B operand, so an accumulator
 // lane owns 4 consecutive channels of one pixel.  Weight fragments come straight from global memory (L2-resident: 136 KB for the block) into
-// registers, issued a phase ahead; pixel fragments from LDS rows of 64 channels (128 B, 16-byte chunks XOR-swizzled with row & 7).
+// registers, issued a phase ahead, from a FRAGMENT-ORDERED copy of the packed weights (mt4_bottleneck_pack_bf16: a wave's load of one
+// fragment is 1 KB contiguous = 8 full cache lines; read from the row-major packed layout it was 16 half lines, and with 136 KB of weights
+// per tile those were most of the kernel's L2 requests); pixel fragments from LDS rows of 64 channels (128 B, 16-byte chunks XOR-swizzled with row & 7).
 //   phase 1: x halo tile in K-chunks of 64 channels, global -> registers -> LDS, two chunks in flight; wave w computes channels 16w..16w+15
 //            of t1 for all 160 halo pixels; out-of-image halo pixels are written as zeros.
 //   phase 2: conv2 from t1 (tap (kh, kw) of pixel (ty, tx) = t1 row (ty + kh) * 16 + tx + kw); wave w: 16 channels x 7 pixel tiles.
@@ -37,10 +39,9 @@ constexpr int YS_BYTES = NPX * 256;          // one pass of the output staging: 
 struct BneckK {
     const char* x;
     char* y;
-    const char *w1, *w2, *w3, *wds;
+    const char *w1, *w2, *w3, *wds;             // fragment-ordered weights (mt4_bottleneck_pack_bf16): [channel tile][K step of 32][lane] x 16 B
     const float *b1, *b2, *b3, *bds;
     int B, H, W, tiles_h, tiles_w;
-    int w1_row, w2_row, w3_row, wds_row;     // bytes per packed weight row
     int nt;                                  // non-temporal output stores
 };
 
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
     const int ch1 = wave * 16;                       // this wave's 16 channels of t1 / t2
     uint4 wf1[KC * 2];
     {
-        const char* wr = a.w1 + (long long)(ch1 + r16) * a.w1_row + q * 16;
+        const char* wr = a.w1 + (wave * (KC * 2) * 64 + lane) * 16;       // channel tile `wave`, K step s: 64 lanes x 16 B contiguous
 #pragma unroll
-        for (int s = 0; s < KC * 2; ++s) wf1[s] = *(const uint4*)(wr + s * 64);
+        for (int s = 0; s < KC * 2; ++s) wf1[s] = *(const uint4*)(wr + s * 1024);
     }
     f32x4 acc1[10];
     {
@@ -167,9 +168,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
     // weights of conv2 and the residual pixels go in flight now; they are consumed after the t1 hand-off
     uint4 wf2[18];
     {
-        const char* wr = a.w2 + (long long)(ch1 + r16) * a.w2_row + q * 16;
+        const char* wr = a.w2 + (wave * 18 * 64 + lane) * 16;
 #pragma unroll
-        for (int s = 0; s < 18; ++s) wf2[s] = *(const uint4*)(wr + s * 64);
+        for (int s = 0; s < 18; ++s) wf2[s] = *(const uint4*)(wr + s * 1024);
     }
     // From here on the tile is an 8 x 16 grid: pixel tile ty = output row ty, lane r16 = column tx (columns 14, 15 are never stored; they
     // read the two slack rows behind t1).  Every LDS row index is then 16 * (row of tiles) + r16 + shift, so the XOR swizzle depends on the
@@ -225,9 +226,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
     uint4 wf3[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const char* wr = a.w3 + (long long)((4 * i + wave) * 16 + r16) * a.w3_row + q * 16;
+        const char* wr = a.w3 + ((4 * i + wave) * 2 * 64 + lane) * 16;
         wf3[i][0] = *(const uint4*)wr;
-        wf3[i][1] = *(const uint4*)(wr + 64);
+        wf3[i][1] = *(const uint4*)(wr + 1024);
     }
     {
         const int wr_off = r16 * ROW_B + (((cb1 >> 4) ^ (r16 & 7)) << 4) + (cb1 & 8);
@@ -267,9 +268,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
             if constexpr (DS) {
                 uint4 wfd[2];                              // (loaded here: preloading all four tiles' fragments spills)
                 {
-                    const char* wd = a.wds + (long long)(ct * 16 + r16) * a.wds_row + q * 16;
+                    const char* wd = a.wds + (ct * 2 * 64 + lane) * 16;
                     wfd[0] = *(const uint4*)wd;
-                    wfd[1] = *(const uint4*)(wd + 64);
+                    wfd[1] = *(const uint4*)(wd + 1024);
                 }
                 const f32x4 bd4 = bias4(a.bds, ct * 16 + q * 4);
 #pragma unroll
@@ -340,28 +341,63 @@ int launch(const BneckK& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int mt4_bottleneck_fused_bf16(const void* x, void* y, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3,
-                                         const float* b3, const void* wds, const float* bds, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t mid,
-                                         void* stream) {
+// fragment-ordered copy of the block's packed weights: for each matrix, [channel tile of 16][K step of 32][lane (r16, q)] x 16 bytes =
+// W[tile * 16 + r16][step * 32 + q * 8 .. + 8]
+__global__ void bneck_pack_kernel(const u16* __restrict__ w, uint4* __restrict__ out, int ctiles, int ksteps, int row_elems) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ctiles * ksteps * 64) return;
+    const int lane = i & 63, fs = i >> 6;
+    const int step = fs % ksteps, tile = fs / ksteps;
+    out[i] = *(const uint4*)(w + (long long)(tile * 16 + (lane & 15)) * row_elems + step * 32 + (lane >> 4) * 8);
+}
+
+static inline long long bneck_frag_bytes(int Cin, bool ds) { return ((long long)4 * (Cin / 32) + 4 * 18 + 16 * 2 + (ds ? 16 * (Cin / 32) : 0)) * 1024; }
+
+extern "C" int64_t mt4_bottleneck_packed_bytes(int32_t Cin, int32_t has_downsample) {
+    if (!((has_downsample && Cin == 64) || (!has_downsample && Cin == 256))) return MT4_EUNSUPPORTED;
+    return bneck_frag_bytes(Cin, has_downsample != 0);
+}
+
+extern "C" int mt4_bottleneck_pack_bf16(const void* w1, const void* w2, const void* w3, const void* wds, int32_t Cin, void* out, void* stream) {
     mt4_clear_error();
-    if (!x || !y || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || B <= 0 || H <= 0 || W <= 0) return MT4_EINVAL;
-    if ((wds == nullptr) != (bds == nullptr)) return MT4_EINVAL;
-    if (mid != 64 || !((wds && Cin == 64) || (!wds && Cin == 256))) return MT4_EUNSUPPORTED;
-    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)w3 | (uintptr_t)wds | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)b3 |
-         (uintptr_t)bds) & 15)
-        return MT4_EALIGN;
+    if (!w1 || !w2 || !w3 || !out) return MT4_EINVAL;
+    if (!((wds && Cin == 64) || (!wds && Cin == 256))) return MT4_EUNSUPPORTED;
+    if (((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)w3 | (uintptr_t)wds | (uintptr_t)out) & 15) return MT4_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int k1 = Cin / 32;
+    char* o = (char*)out;
+    const int r1 = (int)mt4_conv_packed_k(Cin, 1, 1, MT4_BF16), r2 = (int)mt4_conv_packed_k(64, 3, 3, MT4_BF16), r3 = (int)mt4_conv_packed_k(64, 1, 1, MT4_BF16);
+    auto go = [&](const void* w, int ctiles, int ksteps, int row_elems) {
+        const int n = ctiles * ksteps * 64;
+        hipLaunchKernelGGL(bneck_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const u16*)w, (uint4*)o, ctiles, ksteps, row_elems);
+        o += (long long)n * 16;
+    };
+    go(w1, 4, k1, r1);
+    go(w2, 4, 18, r2);
+    go(w3, 16, 2, r3);
+    if (wds) go(wds, 16, k1, r1);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_bottleneck_fused_bf16(const void* x, void* y, const void* w_frag, const float* b1, const float* b2, const float* b3, const float* bds,
+                                         int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t mid, void* stream) {
+    mt4_clear_error();
+    if (!x || !y || !w_frag || !b1 || !b2 || !b3 || B <= 0 || H <= 0 || W <= 0) return MT4_EINVAL;
+    const bool ds = bds != nullptr;
+    if (mid != 64 || !((ds && Cin == 64) || (!ds && Cin == 256))) return MT4_EUNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w_frag | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)b3 | (uintptr_t)bds) & 15) return MT4_EALIGN;
     if ((long long)H * W * 512 > 0x7fffffffLL) return MT4_EUNSUPPORTED;    // per-image byte offsets are 32-bit
     BneckK a;
     a.x = (const char*)x; a.y = (char*)y;
-    a.w1 = (const char*)w1; a.w2 = (const char*)w2; a.w3 = (const char*)w3; a.wds = (const char*)wds;
+    const int k1 = Cin / 32;
+    a.w1 = (const char*)w_frag;
+    a.w2 = a.w1 + (long long)4 * k1 * 1024;
+    a.w3 = a.w2 + (long long)4 * 18 * 1024;
+    a.wds = ds ? a.w3 + (long long)16 * 2 * 1024 : nullptr;
     a.b1 = b1; a.b2 = b2; a.b3 = b3; a.bds = bds;
     a.B = B; a.H = H; a.W = W;
     a.tiles_h = cdiv(H, TH); a.tiles_w = cdiv(W, TW);
-    a.w1_row = (int)mt4_conv_packed_k(Cin, 1, 1, MT4_BF16) * 2;
-    a.w2_row = (int)mt4_conv_packed_k(64, 3, 3, MT4_BF16) * 2;
-    a.w3_row = (int)mt4_conv_packed_k(64, 1, 1, MT4_BF16) * 2;
-    a.wds_row = a.w1_row;
     a.nt = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
     if ((long long)B * a.tiles_h * a.tiles_w > 0x7fffffffLL) return MT4_EUNSUPPORTED;
-    return wds ? launch<64, true>(a, (hipStream_t)stream) : launch<256, false>(a, (hipStream_t)stream);
+    return ds ? launch<64, true>(a, (hipStream_t)stream) : launch<256, false>(a, (hipStream_t)stream);
 }

@@ -389,22 +389,34 @@ def linear_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -
     return y
 
 
-def bottleneck_fused(x: torch.Tensor, conv1, conv2, conv3, ds=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """one stride-1 ResNet Bottleneck of 64 mid channels in one launch (`mt4_bottleneck_fused_bf16`): x [B,H,W,Cin] bf16 NHWC; conv1 / conv2 /
-    conv3 / ds = (packed weight with the BatchNorm scale folded in, float32 bias); ds None = identity residual (Cin 256), else Cin 64"""
+def bottleneck_pack(conv1, conv2, conv3, ds=None):
+    """the weights of one 64-mid-channel Bottleneck in the fragment order `mt4_bottleneck_fused_bf16` reads (once per model load).  conv1 / conv2 /
+    conv3 / ds = (packed bf16 weight with the BatchNorm scale folded in, float32 bias); returns (w_frag, b1, b2, b3, bds | None, cin)"""
     (w1, b1), (w2, b2), (w3, b3) = conv1, conv2, conv3
     wd, bd = ds if ds is not None else (None, None)
-    _need_cuda(x, w1, b1, w2, b2, w3, b3, wd, bd, out)
-    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
-    b, h, w, cin = x.shape
+    _need_cuda(w1, b1, w2, b2, w3, b3, wd, bd)
+    cin = 64 if ds is not None else 256
     assert w1.dtype == w2.dtype == w3.dtype == torch.bfloat16 and tuple(w1.shape) == (64, packed_k(cin, 1, 1, torch.bfloat16)) and \
         tuple(w2.shape) == (64, packed_k(64, 3, 3, torch.bfloat16)) and tuple(w3.shape) == (256, packed_k(64, 1, 1, torch.bfloat16))
     assert wd is None or tuple(wd.shape) == (256, packed_k(cin, 1, 1, torch.bfloat16))
+    nbytes = int(lib.mt4_bottleneck_packed_bytes(cin, 1 if ds is not None else 0))
+    frag = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+    check(lib.mt4_bottleneck_pack_bf16(w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), wd.data_ptr() if wd is not None else None, cin, frag.data_ptr(),
+                                       _stream()), "mt4_bottleneck_pack_bf16")
+    return frag, b1.contiguous(), b2.contiguous(), b3.contiguous(), (bd.contiguous() if bd is not None else None), cin
+
+
+def bottleneck_fused(x: torch.Tensor, packed, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """one stride-1 ResNet Bottleneck of 64 mid channels in one launch (`mt4_bottleneck_fused_bf16`): x [B,H,W,Cin] bf16 NHWC, packed =
+    `bottleneck_pack(...)`"""
+    frag, b1, b2, b3, bd, cin = packed
+    _need_cuda(x, frag, out)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4 and x.shape[3] == cin
+    b, h, w, _ = x.shape
     y = torch.empty((b, h, w, 256), dtype=torch.bfloat16, device=x.device) if out is None else out
     assert y.is_contiguous() and tuple(y.shape) == (b, h, w, 256) and y.dtype == torch.bfloat16
-    check(lib.mt4_bottleneck_fused_bf16(x.data_ptr(), y.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
-                                        b3.data_ptr(), wd.data_ptr() if wd is not None else None, bd.data_ptr() if bd is not None else None,
-                                        b, h, w, cin, 64, _stream()), "mt4_bottleneck_fused_bf16")
+    check(lib.mt4_bottleneck_fused_bf16(x.data_ptr(), y.data_ptr(), frag.data_ptr(), b1.data_ptr(), b2.data_ptr(), b3.data_ptr(),
+                                        bd.data_ptr() if bd is not None else None, b, h, w, cin, 64, _stream()), "mt4_bottleneck_fused_bf16")
     return y
 
 

@@ -118,6 +118,8 @@ class VideoNas:
                     p[f"{q}conv{ci}"] = self._fold(f"{q}conv{ci}", f"{q}bn{ci}")
                 if (q + "downsample.0.weight") in self._sd:
                     p[q + "ds"] = self._fold(q + "downsample.0", q + "downsample.1")
+                if bottleneck and li == 1 and self.dtype == torch.bfloat16:   # the block's weights in the fused kernel's fragment order
+                    p[q + "fused"] = ops.bottleneck_pack(p[q + "conv1"], p[q + "conv2"], p[q + "conv3"], p.get(q + "ds"))
         ws, bs, self._head_slices, o = [], [], {}, 0
         for task, k in _HEADS:
             if self.loss_type in (task, "all"):
@@ -158,9 +160,9 @@ class VideoNas:
                 q = f"{pre}layer{li}.{bi}."
                 s = 2 if (bi == 0 and li > 1) else 1
                 o_buf = out if (li == last and bi == n - 1) else None
-                if (bottleneck and li == 1 and self.fuse_bottleneck and self.dtype == torch.bfloat16 and pending is None):
+                if (bottleneck and li == 1 and self.fuse_bottleneck and self.dtype == torch.bfloat16 and pending is None and (q + "fused") in self._p):
                     # conv1 -> conv2 -> conv3 (+ downsample) of a 64-channel stride-1 block in one launch, intermediates in LDS (bit-identical)
-                    x = ops.bottleneck_fused(x, self._p[q + "conv1"], self._p[q + "conv2"], self._p[q + "conv3"], self._p.get(q + "ds"), out=o_buf)
+                    x = ops.bottleneck_fused(x, self._p[q + "fused"], out=o_buf)
                     continue
                 idt = self._conv(x, q + "ds", 1, stride=s, relu=False) if (q + "ds") in self._p else x
                 if bottleneck:  # resnet.py:101-121 (stride on the 3x3)

@@ -105,14 +105,18 @@ int mt4_conv_tile_count(void);
  * conv3 1x1 + bn3 + residual + ReLU (Spatial_transformer/models/resnet.py:101-121; what Spatial_cnn/network.py:25-31 runs through
  * torchvision's Bottleneck) with the 64-channel intermediates held in LDS: x is read from HBM once (plus the 1-pixel halo ring of each
  * 8 x 14 pixel tile) and y written once, instead of 8.5 GB per 1336 frames through three mt4_conv_nhwc launches (+ the downsample launch).
- *   x [B][H][W][Cin] bf16, y [B][H][W][256] bf16, weights packed by mt4_pack_conv_weight with the BatchNorm scale folded in
- *   (w1 [64][Cin], w2 [64][9*64], w3 [256][64], wds [256][Cin] or NULL), biases float32.
- *   wds == NULL: identity residual, Cin == 256 (layer1.1, layer1.2); wds != NULL: Cin == 64, residual = bf16(wds . x + bds) (layer1.0).
+ *   x [B][H][W][Cin] bf16, y [B][H][W][256] bf16, biases float32 (bds != NULL selects the downsample block).
+ *   Cin == 256: identity residual (layer1.1, layer1.2); Cin == 64 with bds: residual = bf16(wds . x + bds) (layer1.0).
+ *   w_frag: the block's weights in fragment order, made once per model load by mt4_bottleneck_pack_bf16 from the matrices packed by
+ *   mt4_pack_conv_weight with the BatchNorm scale folded in (w1 [64][Cin], w2 [64][9*64], w3 [256][64], wds [256][Cin] or NULL):
+ *   [channel tile of 16][K step of 32][lane] x 16 bytes, so that a wave's load of one MFMA fragment is 1 KB contiguous;
+ *   mt4_bottleneck_packed_bytes gives the buffer size.
  * Bit-identical to the launch sequence through mt4_conv_nhwc (same K order, bias-initialised fp32 accumulators, bf16 rounding of the
  * intermediates where that path stores them).  mid != 64 or another Cin: MT4_EUNSUPPORTED.  H*W*512 < 2 GiB. */
-int mt4_bottleneck_fused_bf16(const void* x, void* y, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3,
-                              const float* b3, const void* wds, const float* bds, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t mid,
-                              void* stream);
+int64_t mt4_bottleneck_packed_bytes(int32_t Cin, int32_t has_downsample);
+int mt4_bottleneck_pack_bf16(const void* w1, const void* w2, const void* w3, const void* wds, int32_t Cin, void* out, void* stream);
+int mt4_bottleneck_fused_bf16(const void* x, void* y, const void* w_frag, const float* b1, const float* b2, const float* b3, const float* bds,
+                              int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t mid, void* stream);
 /* elements per packed weight row for a given geometry (Kpad above) */
 int64_t mt4_conv_packed_k(int32_t Cin, int32_t KH, int32_t KW, int32_t dtype);
 

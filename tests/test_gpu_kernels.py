@@ -291,6 +291,6 @@ def test_bottleneck_fused_bit_identical_to_three_launches(cuda, b, h, w, ds):
     o = ops.conv_nhwc(x, c1[0], c1[1], kh=1, kw=1, relu=True)
     o = ops.conv_nhwc(o, c2[0], c2[1], kh=3, kw=3, pad=(1, 1), relu=True)
     ref = ops.conv_nhwc(o, c3[0], c3[1], kh=1, kw=1, residual=idt, relu=True)
-    y = ops.bottleneck_fused(x, c1, c2, c3, cd)
+    y = ops.bottleneck_fused(x, ops.bottleneck_pack(c1, c2, c3, cd))
     assert float(ref.float().abs().max()) > 0.5
     assert torch.equal(y.view(torch.int16), ref.view(torch.int16)), float((y.float() - ref.float()).abs().max())

@@ -22,6 +22,7 @@ for ds in (False, True):
         o = ops.conv_nhwc(o, c2[0], c2[1], kh=3, kw=3, pad=(1, 1), relu=True)
         return ops.conv_nhwc(o, c3[0], c3[1], kh=1, kw=1, residual=idt, relu=True, out=y)
     t_u = bench._time_call(unfused, iters=10)
-    t_f = bench._time_call(lambda: ops.bottleneck_fused(x, c1, c2, c3, cd, out=y), iters=10)
+    pk = ops.bottleneck_pack(c1, c2, c3, cd)
+    t_f = bench._time_call(lambda: ops.bottleneck_fused(x, pk, out=y), iters=10)
     gb = B * 3136 * (cin + 256) * 2 / 1e9
     print(f"ds={int(ds)} Cin={cin}: unfused {t_u:.3f} ms | fused {t_f:.3f} ms = {gb / t_f:.2f} TB/s of x-once + y-once ({gb:.2f} GB)", flush=True)
