@@ -58,34 +58,26 @@ def conv_flops_per_frame(model, h, w):
 
 
 def time_conv_kernels(model, frames, iters=3):
-    """Average duration of the conv launches of one step (implicit-GEMM kernels and the fused layer1 Bottlenecks), measured with HIP events
+    """Average duration of the conv launches of one step (implicit-GEMM kernels, the fused layer1 Bottlenecks, the stem + max-pool launch), measured with HIP events
     recorded on the stream the kernels are launched on (torch's current stream), one event pair per launch."""
     from computervision_codes_amd import ops
     pairs = []
-    orig = ops.conv_nhwc
+    names = ("conv_nhwc", "bottleneck_fused", "stem_maxpool")
+    origs = {n: getattr(ops, n) for n in names}
 
-    def timed(*a, **k):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        y = orig(*a, **k)
-        e1.record()
-        pairs.append((e0, e1))
-        return y
+    def wrap(fn):
+        def timed(*a, **k):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = fn(*a, **k)
+            e1.record()
+            pairs.append((e0, e1))
+            return y
+        return timed
 
-    orig_b = ops.bottleneck_fused
-
-    def timed_b(*a, **k):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        y = orig_b(*a, **k)
-        e1.record()
-        pairs.append((e0, e1))
-        return y
-
-    ops.conv_nhwc = timed
-    ops.bottleneck_fused = timed_b
+    for n in names:
+        setattr(ops, n, wrap(origs[n]))
     try:
         per_iter = []
         for _ in range(iters):
@@ -94,8 +86,8 @@ def time_conv_kernels(model, frames, iters=3):
             torch.cuda.synchronize()
             per_iter.append([a.elapsed_time(b) for a, b in pairs])
     finally:
-        ops.conv_nhwc = orig
-        ops.bottleneck_fused = orig_b
+        for n in names:
+            setattr(ops, n, origs[n])
     n = len(per_iter[0])
     per_launch_ms = [min(it[i] for it in per_iter) for i in range(n)]
     return per_launch_ms
@@ -633,7 +625,7 @@ def main():
                 mfma_util = rec["mfma_util"] if rec else None
             except Exception:
                 mfma_util = None
-        roofline = dict(bound="mfma", kernel="conv launches of one step (igemm_conv_kernel, conv3x3_patch_kernel, stem_patch_kernel, bottleneck64_fused_kernel)", achieved=round(achieved, 2),
+        roofline = dict(bound="mfma", kernel="conv launches of one step (igemm_conv_kernel, conv3x3_patch_kernel, stem_pool_kernel, bottleneck64_fused_kernel)", achieved=round(achieved, 2),
                         peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic, mfma_util_pmc=mfma_util,
                         launches_per_step=len(per_launch), conv_ms_per_step=round(conv_ms, 4),
                         gflop_per_frame=round(flops_frame / 1e9, 3), traffic_unit="HBM bytes per step (all conv launches)",

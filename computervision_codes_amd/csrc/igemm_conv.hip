@@ -1008,6 +1008,166 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stem + max-pool in one launch
+// relu(stem conv) -> MaxPool2d(3, 2, 1) (`Spatial_transformer/models/resnet.py:145-157`, conv1 / bn1 / relu / maxpool) on the space-to-depth
+// frame without the 112 x 112 x 64 map ever reaching memory (2.1 GB written and read back per 1336 frames at 224 x 224).  A workgroup owns
+// two pooled rows of one frame: conv rows 2 P0 - 1 .. 2 P0 + 3 (five; the first is shared with the tile above and computed by both),
+// whose eight space-to-depth rows are staged once together with the weight matrix exactly as in stem_patch_kernel; the five conv rows
+// (ReLU, rounded to bf16: what the stand-alone launch stores) meet in LDS over the dead operands and every thread then takes the maximum of
+// up to nine 16-byte channel vectors per pooled pixel (values >= 0: an unsigned 16-bit maximum IS the bf16 maximum).  K order and MFMA
+// chain are stem_patch_kernel's: bit-identical to stem -> mt4_maxpool3x3s2_nhwc.
+struct StemPoolK {
+    const char* x;          // [B][Hs][Ws][16] bf16
+    const char* w;          // packed [Cout <= 64][KH * 64] bf16
+    const float* bias;
+    char* y;                // [B][Hp][Wp][64] bf16
+    unsigned x_bytes, w_bytes;
+    int w_row_bytes, Cout, KH;
+    int Hs, Ws, Ho, Wo, Hp, Wp;
+    int tiles_per_img;      // pairs of pooled rows
+    int pra;                // staged pixels (multiple of 32)
+};
+
+__global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
+    constexpr int MT = 9, NT = 2, BN = 64, NTH = 512, PPP = NTH * 16 / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int r16 = lane & 15, q = lane >> 4;
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x;
+        const int q8 = nb >> 3, r8 = nb & 7;
+        const int xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+    }
+    const int img = bid / a.tiles_per_img;
+    const int P0 = (bid - img * a.tiles_per_img) * 2;
+    const int c0 = 2 * P0 - 1;                     // first conv row of the tile (-1 for the top tile: computed from zeros / the frame above, never pooled)
+    const int tpr = a.Wo >> 4;                     // 16-pixel tiles per conv row
+    const int ntile = 5 * tpr;
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = wave_n * 32 + i * 16 + q * 4;
+        f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (a.bias && n < a.Cout) { const float4 t = *(const float4*)(a.bias + n); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = b4;
+    }
+    const int p0 = __builtin_amdgcn_readfirstlane((img * a.Hs + c0) * a.Ws);   // frame pixel of LDS pixel 0
+    int base[MT];                                  // wave-uniform part of the LDS pixel of tile j (scalar registers); + lane_px per lane
+    const int lane_px = r16 + (q >> 1);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int t = min(wave_m + 4 * j, ntile - 1);
+        const int row = t / tpr;
+        base[j] = __builtin_amdgcn_readfirstlane(row * a.Ws + (t - row * tpr) * 16);
+    }
+    const v4u rsx = make_srd(a.x, a.x_bytes);
+    const v4u rsw = make_srd(a.w, a.w_bytes);
+    constexpr unsigned OOB = 0x80000000u;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int patch_bytes = a.pra * 32;
+    {
+        const int npp = (a.pra + PPP - 1) / PPP;
+        for (int piece = 0; piece < npp; ++piece) {
+            if (piece * PPP + wave_u * 32 < a.pra) {
+                const int t = piece * PPP + (tid >> 1);
+                const int h = (tid & 1) ^ ((t >> 3) & 1);
+                // (pixels in front of the buffer -- the top tile of frame 0 -- wrap to offsets beyond it: range-checked, zeros)
+                const unsigned v[1] = {(unsigned)((p0 + t) * 32 + h * 16)};
+                lds_dma16_group<1, 0>(rsx, v, 0u, lds_base + piece * (PPP * 32) + wave_u * 1024);
+            }
+        }
+        const int ld_row = tid >> 3, ld_chunk = tid & 7;
+        const int gch = ld_chunk ^ (ld_row & 7);
+        const unsigned woff[1] = {ld_row < a.Cout ? (unsigned)(ld_row * a.w_row_bytes + gch * 16) : OOB};
+        for (int kh = 0; kh < a.KH; ++kh)
+            lds_dma16_group<1, 0>(rsw, woff, (unsigned)__builtin_amdgcn_readfirstlane(kh * 128), lds_base + patch_bytes + kh * (BN * 128) + wave_u * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int rd_w = (wave_n * 32 + r16) * 128;
+#pragma unroll 1
+    for (int kh = 0; kh < a.KH; ++kh) {
+        const char* wb = smem + patch_bytes + kh * (BN * 128);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int sww = ((kk * 4 + q) ^ (r16 & 7)) << 4;
+            uint4 fw[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) fw[i] = *(const uint4*)(wb + rd_w + i * 16 * 128 + sww);
+#pragma unroll
+            for (int j0 = 0; j0 < MT; j0 += 5) {          // two batches of pixel fragments (all nine in flight: over the 128-register budget)
+                uint4 fx[5];
+#pragma unroll
+                for (int j = j0; j < MT && j < j0 + 5; ++j) {
+                    const int pix = lane_px + (base[j] + kh * a.Ws + kk * 2);
+                    fx[j - j0] = *(const uint4*)(smem + pix * 32 + (((q & 1) ^ ((pix >> 3) & 1)) << 4));
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = j0; j < MT && j < j0 + 5; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[i]), __builtin_bit_cast(bf16x8_t, fx[j - j0]),
+                                                                            acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();   // the conv rows go over the operands
+
+    // conv tile: pixel (row, col) at (row * Wo + col) * 128 B, 16-byte chunks XOR-swizzled with col & 7
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int t = wave_m + 4 * j;
+        if (t < ntile) {
+            const int row = __builtin_amdgcn_readfirstlane(t / tpr);
+            const int col = __builtin_amdgcn_readfirstlane((t - row * tpr) * 16) + r16;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int cb = (wave_n * 32 + i * 16 + q * 4) * 2;
+                uint2 o = make_uint2(pack_bf16x2(fmaxf(acc[i][j][0], 0.f), fmaxf(acc[i][j][1], 0.f)),
+                                     pack_bf16x2(fmaxf(acc[i][j][2], 0.f), fmaxf(acc[i][j][3], 0.f)));
+                *(uint2*)(smem + (row * a.Wo + col) * 128 + (((cb >> 4) ^ (col & 7)) << 4) + (cb & 8)) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int nvec = 2 * a.Wp * 8;
+    for (int v = tid; v < nvec; v += NTH) {
+        const int c8 = v & 7;
+        const int pp = v >> 3;
+        const int pr = pp >= a.Wp ? 1 : 0;
+        const int pc = pp - pr * a.Wp;
+        const int P = P0 + pr;
+        if (P >= a.Hp || c8 * 8 >= a.Cout) continue;
+        uint4 best = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int jr = 2 * pr + kh;
+            if ((unsigned)(c0 + jr) >= (unsigned)a.Ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int cc = 2 * pc - 1 + kw;
+                if ((unsigned)cc >= (unsigned)a.Wo) continue;
+                const uint4 t = *(const uint4*)(smem + (jr * a.Wo + cc) * 128 + ((c8 ^ (cc & 7)) << 4));
+                asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.x) : "v"(t.x));
+                asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.y) : "v"(t.y));
+                asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.z) : "v"(t.z));
+                asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.w) : "v"(t.w));
+            }
+        }
+        *(uint4*)(a.y + (((long long)img * a.Hp + P) * a.Wp + pc) * (a.Cout * 2) + c8 * 16) = best;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 namespace {
 
@@ -1447,6 +1607,38 @@ extern "C" int mt4_pack_conv_weight(const float* w_oihw, const float* scale, voi
     else
         hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(grid), dim3(256), 0, s, w_oihw, scale, (float*)w_packed, Cout,
                            Cin, KH, KW, cpt * E, Kpad);
+    return mt4_check_launch();
+}
+
+// relu(stem conv on the space-to-depth frame) -> 3x3 / 2 max-pool, pad 1, one launch (stem_pool_kernel).  x_s2d [B][Hs][Ws][16] bf16
+// (mt4_preprocess_u8_s2d), w_packed [Cout][KH * 64] bf16 (the 4 x 1 kernel over runs of 4 pixels), y [B][Hp][Wp][Cout] bf16 with
+// Ho = Hs - KH + 1, Wo = Ws - 3, Hp = (Ho - 1) / 2 + 1, Wp = (Wo - 1) / 2 + 1.  Conv rows of up to 112 pixels in whole 16-pixel tiles
+// (224 x 224 frames); wider frames: MT4_EUNSUPPORTED (the caller runs mt4_conv_nhwc + mt4_maxpool3x3s2_nhwc).
+extern "C" int mt4_stem_maxpool_bf16(const void* x_s2d, const void* w_packed, const float* bias, void* y, int32_t B, int32_t Hs, int32_t Ws,
+                                     int32_t Cout, int32_t KH, void* stream) {
+    mt4_clear_error();
+    if (!x_s2d || !w_packed || !y || B <= 0 || Hs <= 0 || Ws <= 3 || KH <= 0 || KH > Hs) return MT4_EINVAL;
+    if (((uintptr_t)x_s2d | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)bias) & 15) return MT4_EALIGN;
+    const int Ho = Hs - KH + 1, Wo = Ws - 3;
+    if (KH > 8 || Cout != 64 || (Wo & 15) || Wo > 112) return MT4_EUNSUPPORTED;
+    const long long xb = (long long)B * Hs * Ws * 32;
+    if (xb >= 0x70000000LL) return MT4_EUNSUPPORTED;
+    StemPoolK k{};
+    k.x = (const char*)x_s2d; k.w = (const char*)w_packed; k.bias = bias; k.y = (char*)y;
+    k.x_bytes = (unsigned)xb;
+    k.w_row_bytes = KH * 128;
+    k.w_bytes = (unsigned)(Cout * k.w_row_bytes);
+    k.Cout = Cout; k.KH = KH; k.Hs = Hs; k.Ws = Ws; k.Ho = Ho; k.Wo = Wo;
+    k.Hp = (Ho - 1) / 2 + 1; k.Wp = (Wo - 1) / 2 + 1;
+    k.tiles_per_img = cdiv(k.Hp, 2);
+    k.pra = ((4 + KH) * Ws + 31) / 32 * 32;      // five conv rows: 4 + KH frame rows
+    int lds = k.pra * 32 + KH * 64 * 128;
+    if (lds < 5 * Wo * 128) lds = 5 * Wo * 128;
+    if (lds > 80 * 1024) return MT4_EUNSUPPORTED;
+    if ((long long)B * k.tiles_per_img > 0x7fffffffLL) return MT4_EUNSUPPORTED;
+    auto fn = stem_pool_kernel;
+    if (lds > 65536) MT4_RAISE_LDS(fn);
+    hipLaunchKernelGGL(fn, dim3((unsigned)(B * k.tiles_per_img)), dim3(512), lds, (hipStream_t)stream, k);
     return mt4_check_launch();
 }
 

@@ -86,6 +86,14 @@ extern "C" int mt4_pad_nchw_f32(const float* x, void* out, int32_t B, int32_t H,
 // kernel row is 4 pixels x 16 channels = ONE contiguous 128-byte run: it goes through the LDS-DMA path of mt4_conv_nhwc (x_pixel_stride).
 __global__ void stem_input_s2d_kernel(const uint8_t* __restrict__ in, u16* __restrict__ out, int B, int H, int W, int Hs, int Ws, float m0,
                                       float m1, float m2, float s0, float s1, float s2) {
+    // the 3 x 256 possible bf16 values, once per block (two fp32 divisions per value: per element they cost more than the kernel's memory time)
+    __shared__ u16 lut[3][256];
+    for (int i = threadIdx.x; i < 768; i += blockDim.x) {
+        const int c = i >> 8;
+        const float m = c == 0 ? m0 : c == 1 ? m1 : m2, sd = c == 0 ? s0 : c == 1 ? s1 : s2;
+        lut[c][i & 255] = f32_to_bf16(((float)(i & 255) / 255.0f - m) / sd);
+    }
+    __syncthreads();
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one space-to-depth pixel (32 bytes) per thread
     const long long total = (long long)B * Hs * Ws;
     if (idx >= total) return;
@@ -93,9 +101,9 @@ __global__ void stem_input_s2d_kernel(const uint8_t* __restrict__ in, u16* __res
     const long long t = idx / Ws;
     const int ys = (int)(t % Hs);
     const int b = (int)(t / Hs);
-    float v[16];
+    unsigned v[12];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = 0.f;
+    for (int e = 0; e < 12; ++e) v[e] = 0u;
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -103,14 +111,14 @@ __global__ void stem_input_s2d_kernel(const uint8_t* __restrict__ in, u16* __res
             const int h = 2 * ys + dy - 3, w = 2 * xs + dx - 3;
             if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
                 const uint8_t* p = in + (((long long)b * H + h) * W + w) * 3;
-                v[(dy * 2 + dx) * 3 + 0] = ((float)p[0] / 255.0f - m0) / s0;
-                v[(dy * 2 + dx) * 3 + 1] = ((float)p[1] / 255.0f - m1) / s1;
-                v[(dy * 2 + dx) * 3 + 2] = ((float)p[2] / 255.0f - m2) / s2;
+                v[(dy * 2 + dx) * 3 + 0] = lut[0][p[0]];
+                v[(dy * 2 + dx) * 3 + 1] = lut[1][p[1]];
+                v[(dy * 2 + dx) * 3 + 2] = lut[2][p[2]];
             }
         }
     uint4* o = (uint4*)(out + idx * 16);
-    o[0] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-    o[1] = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), 0u, 0u);
+    o[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    o[1] = make_uint4(v[8] | (v[9] << 16), v[10] | (v[11] << 16), 0u, 0u);
 }
 
 extern "C" int mt4_preprocess_u8_s2d(const uint8_t* frames, void* out, int32_t B, int32_t H, int32_t W, const float mean[3],
@@ -206,12 +214,50 @@ __global__ void global_avgpool_kernel(const T* __restrict__ x, float* __restrict
     y[(long long)b * C + c] = s / (float)HW;
 }
 
+// bf16, C % 8 == 0: thread = 8 channels (16-byte loads, 7 pixels in flight), the same i = 0 .. HW-1 summation order per channel
+__global__ void global_avgpool_bf16x8_kernel(const uint4* __restrict__ x, float* __restrict__ y, int HW, int CV, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long long b = idx / CV;
+    const int cv = (int)(idx - b * CV);
+    const uint4* p = x + b * HW * CV + cv;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    auto add = [&](const uint4 v) {
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s[2 * e] += __uint_as_float(u[e] << 16);
+            s[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u);
+        }
+    };
+    int i = 0;
+    for (; i + 7 <= HW; i += 7) {
+        uint4 v[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[k] = p[(long long)(i + k) * CV];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) add(v[k]);
+    }
+    for (; i < HW; ++i) add(p[(long long)i * CV]);
+    float4* o = (float4*)(y + idx * 8);
+    const float n = (float)HW;
+    o[0] = make_float4(s[0] / n, s[1] / n, s[2] / n, s[3] / n);
+    o[1] = make_float4(s[4] / n, s[5] / n, s[6] / n, s[7] / n);
+}
+
 extern "C" int mt4_global_avgpool_nhwc(const void* x, float* y, int32_t B, int32_t HW, int32_t C, int32_t dtype, void* stream) {
     mt4_clear_error();
     if (!x || !y || B <= 0 || HW <= 0 || C <= 0) return MT4_EINVAL;
     if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
     if (B > 65535) return MT4_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == MT4_BF16 && (C & 7) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+        const long long total = (long long)B * (C / 8);
+        hipLaunchKernelGGL(global_avgpool_bf16x8_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, (const uint4*)x, y, HW, C / 8, total);
+        return mt4_check_launch();
+    }
     dim3 grid(cdiv(C, 256), B);
     if (dtype == MT4_BF16) hipLaunchKernelGGL(global_avgpool_kernel<u16>, grid, dim3(256), 0, s, (const u16*)x, y, HW, C);
     else hipLaunchKernelGGL(global_avgpool_kernel<float>, grid, dim3(256), 0, s, (const float*)x, y, HW, C);

@@ -369,6 +369,26 @@ def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def stem_maxpool_supported(h: int, w: int) -> bool:
+    """frame sizes `stem_maxpool` takes: even, conv rows (w / 2 pixels) in whole 16-pixel tiles of at most 112"""
+    return h % 2 == 0 and w % 32 == 0 and w // 2 <= 112
+
+
+def stem_maxpool(xs: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """conv1 / bn1 / relu / maxpool of the ResNet stem in one launch (`mt4_stem_maxpool_bf16`): xs = `preprocess_u8_s2d(...)` [B,Hs,Ws,16]
+    bf16, w_packed = `stem_s2d_weight(...)` -> [B,Hp,Wp,64] bf16, bit-identical to the stem conv followed by `maxpool3x3s2`"""
+    _need_cuda(xs, w_packed, bias)
+    assert xs.dtype == torch.bfloat16 and xs.is_contiguous() and xs.dim() == 4 and xs.shape[3] == 16
+    assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous() and w_packed.shape[1] % 64 == 0 and bias.dtype == torch.float32
+    b, hs, ws, _ = xs.shape
+    cout, kh = w_packed.shape[0], w_packed.shape[1] // 64
+    ho, wo = hs - kh + 1, ws - 3
+    y = torch.empty((b, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1, cout), dtype=torch.bfloat16, device=xs.device)
+    check(lib.mt4_stem_maxpool_bf16(xs.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, hs, ws, cout, kh, _stream()),
+          "mt4_stem_maxpool_bf16")
+    return y
+
+
 def global_avgpool(x: torch.Tensor) -> torch.Tensor:
     _need_cuda(x)
     assert x.is_contiguous()

@@ -46,6 +46,7 @@ class VideoNas:
         # not pay for that.  Off by default; kept for the A/B and as the starting point of a smaller-tile variant.
         self.fuse_next_conv = False
         import os
+        self.fuse_stem_pool = not os.environ.get("MT4_NO_STEM_POOL_FUSE")   # stem conv + max-pool in one launch (bf16 uint8-frame path)
         self.fuse_bottleneck = not os.environ.get("MT4_NO_BNECK_FUSE")   # layer1 Bottlenecks in one launch each (bf16 ResNet-50)
 
     def train(self, mode: bool = True):
@@ -281,6 +282,8 @@ class VideoNas:
         _, h, w, _ = frames_u8.shape
         if "stem_s2d" in self._p and h % 2 == 0 and w % 2 == 0:
             xs = ops.preprocess_u8_s2d(frames_u8, IMAGENET_MEAN, IMAGENET_STD)
+            if self.fuse_stem_pool and ops.stem_maxpool_supported(h, w):   # conv1 / bn1 / relu / maxpool in one launch (bit-identical)
+                return ops.global_avgpool(self._layers(ops.stem_maxpool(xs, self._p["stem_s2d"], self._p["stem"][1]), 1, 4))
             y = ops.conv_nhwc(xs, self._p["stem_s2d"], self._p["stem"][1], kh=4, kw=1, relu=True, run_pixels=4, out_hw=(h // 2, w // 2))
             return ops.global_avgpool(self._layers(ops.maxpool3x3s2(y), 1, 4))
         return self.trunk_from_padded(ops.preprocess_u8(frames_u8, IMAGENET_MEAN, IMAGENET_STD, self.dtype), h, w)

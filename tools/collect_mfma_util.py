@@ -8,7 +8,7 @@ per dispatch summed over the 8 XCDs (value / launch duration = 18.3-19.4 cycles 
 duration in shader-clock cycles is value / 8.  utilisation = busy / (1024 SIMDs x cycles)."""
 import collections, csv, glob, json, os, sys
 
-CONV_KERNELS = ("igemm_conv_kernel", "conv3x3_patch_kernel", "stem_patch_kernel", "bottleneck64_fused_kernel")   # every conv launch of a step
+CONV_KERNELS = ("igemm_conv_kernel", "conv3x3_patch_kernel", "stem_patch_kernel", "stem_pool_kernel", "bottleneck64_fused_kernel")   # every conv launch of a step
 
 N_SIMD = 256 * 4
 N_XCD = 8

@@ -5,7 +5,7 @@ Per MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH
 (16 B/lane) coalesced stream -- doubled here; WRITE_SIZE is exact for 16-B-per-lane stores."""
 import collections, csv, glob, json, os, sys
 
-CONV_KERNELS = ("igemm_conv_kernel", "conv3x3_patch_kernel", "stem_patch_kernel", "bottleneck64_fused_kernel")   # everything mt4_conv_nhwc launches
+CONV_KERNELS = ("igemm_conv_kernel", "conv3x3_patch_kernel", "stem_patch_kernel", "stem_pool_kernel", "bottleneck64_fused_kernel")   # everything mt4_conv_nhwc launches
 
 def per_dispatch(d, counter):
     f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)   # (the newest pass)
