@@ -637,7 +637,8 @@ def main():
             rows = []
             for g, ms in zip(groups, per_launch):
                 fl = sum(2 * a.batch * plan[i]["Ho"] * plan[i]["Wo"] * plan[i]["Cout"] * plan[i]["Cin"] * plan[i]["kh"] * plan[i]["kw"] for i in g)
-                rec = dict(plan[g[0]]) if len(g) == 1 else dict(name=plan[g[0]]["name"].rsplit(".", 1)[0] + " (one launch)", fused=[plan[i]["name"] for i in g])
+                gname = plan[g[0]]["name"] + " + downsample" if len(g) == 2 else plan[g[0]]["name"].rsplit(".", 1)[0]
+                rec = dict(plan[g[0]]) if len(g) == 1 else dict(name=gname + " (one launch)", fused=[plan[i]["name"] for i in g])
                 rows.append(dict(rec, ms=round(ms, 4), tflops=round(fl / (ms * 1e-3) / 1e12, 1)))
             os.makedirs(os.path.dirname(os.path.abspath(a.per_layer)), exist_ok=True)
             json.dump(rows, open(a.per_layer, "w"), indent=1)

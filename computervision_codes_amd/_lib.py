@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("out_row_map_len", C.c_int32), ("y_ld", C.c_int32), ("res_ld", C.c_int32), ("out_rows_per_image", C.c_int32),
         ("x_pixel_stride", C.c_int32), ("fuse_cout", C.c_int32),
         ("fuse_w", C.c_void_p), ("fuse_bias", C.c_void_p), ("fuse_y", C.c_void_p), ("fuse_relu", C.c_int32), ("residual_float", C.c_int32),
+        ("x2", C.c_void_p), ("x2_H", C.c_int32), ("x2_W", C.c_int32), ("x2_C", C.c_int32), ("x2_stride", C.c_int32),
     ]
 
 

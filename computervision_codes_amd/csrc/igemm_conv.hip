@@ -94,6 +94,12 @@ struct ConvK {
                             // same-box A/B on the ResNet-50 bench: +2.6 % frames/s).  MT4_NO_NT=1 switches it off
     // FUSE: the 1x1 conv that FOLLOWS this launch's output (the next bottleneck's conv1, resnet.py:101-103) runs in this launch's
     // epilogue on the tile's bf16 result while it is still in LDS: y2 = relu(f_w . y + f_bias), [M][f_cout]
+    // DUAL: a second K source behind the first (a 1x1 conv, stride 1): the block input x2 [B][H2][W2][C2] gathered at stride x2_s (the
+    // downsample branch of a strided Bottleneck, resnet.py:116-119): y = act([W | W2] . [x ; x2(s*ho, s*wo)] + bias) in ONE accumulator chain
+    const char* x2;
+    long long x2_img_bytes, x2_total_bytes;
+    int x2_W, x2_s, x2_pix_bytes, x2_HoWo, x2_Wo;
+    int nsteps1;            // K-steps of the first source
     const char* f_w;        // packed [f_cout][Cout] bf16 (mt4_pack_conv_weight, 1x1)
     const float* f_bias;
     char* f_y;
@@ -104,8 +110,9 @@ struct ConvK {
 // tile through its own operand stages and the partial tiles are added in LDS in the fixed order g = 0, 1, ... before the epilogue
 // (deterministic, independent of the batch).  For launches with few tiles and a long K (a TCN layer over one short video: 128 workgroups,
 // 48 K-steps) the K loop -- one barrier and one DMA round trip per step -- is the launch's critical path; this cuts it KS-fold.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool FAST, bool OUT_F32, int KS = 1, bool FUSE = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool FAST, bool OUT_F32, int KS = 1, bool FUSE = false, bool DUAL = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel(const ConvK a) {
+    static_assert(!DUAL || (FAST && sizeof(T) == 2 && KS == 1 && !FUSE), "the second K source exists on the bf16 LDS-DMA path");
     static_assert(!FUSE || (sizeof(T) == 2 && !OUT_F32 && KS == 1 && BN == 256 && BM == 256 && WAVES_M * WAVES_N == 16),
                   "the fused following 1x1 conv exists for the bf16 256x256 tile of 16 waves");
     constexpr int ES = (int)sizeof(T);
@@ -270,8 +277,35 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel
             const int n = n0 + ld_row + RPP * i;
             woff[i] = n < a.Cout ? (unsigned)(n * a.w_row_bytes + gch * 16) : OOB;
         }
+        // DUAL: per staged row the offset of the block-input pixel (s * ho, s * wo) from the image of the tile's first pixel
+        unsigned xoff2[DUAL ? NLD_X : 1];
+        v4u rsx2 = rsx;
+        if constexpr (DUAL) {
+            const long long org2 = (long long)(m0 / a.x2_HoWo) * a.x2_img_bytes;
+            const long long left2 = a.x2_total_bytes - org2;
+            rsx2 = make_srd(a.x2 + org2, (unsigned)(left2 < 0x7fffffffLL ? left2 : 0x7fffffffLL));
+#pragma unroll
+            for (int i = 0; i < NLD_X; ++i) {
+                const int m = m0 + ld_row + RPP * i;
+                const int mm = m < a.M ? m : 0;
+                const int b = mm / a.x2_HoWo;
+                const int rem = mm - b * a.x2_HoWo;
+                const int ho = rem / a.x2_Wo;
+                const int wo = rem - ho * a.x2_Wo;
+                const long long base2 = (long long)b * a.x2_img_bytes + (long long)(ho * a.x2_s * a.x2_W + wo * a.x2_s) * a.x2_pix_bytes;
+                xoff2[i] = m < a.M ? (unsigned)((int)(base2 - org2) + gch * 16) : OOB;
+            }
+        }
         int f_kh = 0, f_kw = 0, f_cs = 0;
         auto issue = [&](int step, int stage) {
+            if constexpr (DUAL) {
+                if (step >= a.nsteps1) {     // (wave-uniform) K-steps of the second source: weight K-step = step (the first source is a 1x1 conv)
+                    const unsigned dst2 = lds_base + stage * STAGE_BYTES + wave_u * 1024;
+                    lds_dma16_group<NLD_X, RPP * 128>(rsx2, xoff2, (unsigned)__builtin_amdgcn_readfirstlane((step - a.nsteps1) * 128), dst2);
+                    lds_dma16_group<NLD_W, RPP * 128>(rsw, woff, (unsigned)__builtin_amdgcn_readfirstlane(step * 128), dst2 + BM * 128);
+                    return;
+                }
+            }
             const int delta = (f_kh * a.dh * a.W + f_kw * a.dw) * a.pix_bytes + f_cs * 128;   // wave-uniform
             const unsigned bits = (hmask >> f_kh) & (wmask >> f_kw);   // bit 8*i: row i valid for this tap
             // K walk order: taps fastest, the 128-byte channel slice slowest (the packed weights are tap-major, so the weight K-step
@@ -1257,6 +1291,20 @@ int launch_fused_next1x1(const ConvK& k, hipStream_t s) {
     return mt4_check_launch();
 }
 
+// tile 17 (bf16 256 x 256, 16 waves) with the second K source (ConvK::x2)
+int launch_dual(const ConvK& k, hipStream_t s) {
+    constexpr int BM = 256, BN = 256, stage = (BM + BN) * 128;
+    ConvK kk = k;
+    kk.n_tiles = cdiv(k.Cout, BN);
+    kk.total_tiles = cdiv(k.M, BM) * kk.n_tiles;
+    kk.nt_epi = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
+    if ((long long)k.M * k.Cout * 2 < (long long)MT4_ENV_INT("MT4_NT_MIN_MB", 200) * 1000000LL) kk.nt_epi = 0;
+    auto fn = igemm_conv_kernel<u16, BM, BN, 4, 4, 2, true, false, 1, false, true>;
+    MT4_RAISE_LDS(fn);
+    hipLaunchKernelGGL(fn, dim3(kk.total_tiles), dim3(1024), 2 * stage, s, kk);
+    return mt4_check_launch();
+}
+
 template <typename T, bool OUT_F32>
 int launch_dtype(const ConvK& k, int tile, bool fast, hipStream_t s) {
     switch (tile) {
@@ -1515,6 +1563,29 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
         k.f_w = (const char*)d->fuse_w; k.f_bias = d->fuse_bias; k.f_y = (char*)d->fuse_y; k.f_cout = d->fuse_cout; k.f_relu = d->fuse_relu ? 1 : 0;
         k.f_w_row_bytes = d->Cout * 2;     // packed [fuse_cout][Cout] bf16: 256 channels = 4 K-steps of 128 bytes, no padding
         return launch_fused_next1x1(k, (hipStream_t)stream);
+    }
+    if (d->x2) {
+        // second K source: y = act([W | W2] . [x ; x2 gathered at stride x2_stride] + bias); w rows hold both K ranges back to back
+        if (d->x2_H <= 0 || d->x2_W <= 0 || d->x2_C <= 0 || d->x2_stride <= 0) return MT4_EINVAL;
+        if (!(fast && d->dtype == MT4_BF16 && d->out_dtype == MT4_BF16 && d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 &&
+              d->pad_h == 0 && d->pad_w == 0 && !d->out_row_map && !d->residual && d->relu <= 1 && d->tile == 0 && pix == d->Cin * es &&
+              (d->x2_C * 2) % 128 == 0 && (d->Cout % 8) == 0 && (k.y_ld * 2) % 16 == 0))
+            return MT4_EUNSUPPORTED;
+        if ((long long)(d->Ho - 1) * d->x2_stride >= d->x2_H || (long long)(d->Wo - 1) * d->x2_stride >= d->x2_W) return MT4_EINVAL;
+        if ((uintptr_t)d->x2 & 15) return MT4_EALIGN;
+        k.x2 = (const char*)d->x2;
+        k.x2_pix_bytes = d->x2_C * 2;
+        k.x2_img_bytes = (long long)d->x2_H * d->x2_W * k.x2_pix_bytes;
+        k.x2_total_bytes = (long long)d->B * k.x2_img_bytes;
+        k.x2_W = d->x2_W; k.x2_s = d->x2_stride; k.x2_HoWo = d->Ho * d->Wo; k.x2_Wo = d->Wo;
+        if (((long long)(256 / k.x2_HoWo) + 2) * k.x2_img_bytes >= 0x70000000LL) return MT4_EUNSUPPORTED;
+        k.nsteps1 = k.nsteps;
+        k.nsteps += d->x2_C * 2 / 128;
+        k.w_row_bytes = k.nsteps * 128;
+        const long long wb2 = (long long)d->Cout * k.w_row_bytes;
+        if (wb2 >= 0x7fffffffLL) return MT4_EUNSUPPORTED;
+        k.w_bytes = (unsigned)wb2;
+        return launch_dual(k, (hipStream_t)stream);
     }
     int tile = d->tile;
     if (tile < -1 || tile > kNumTiles) return MT4_EINVAL;

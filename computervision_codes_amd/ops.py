@@ -94,10 +94,12 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
               residual: Optional[torch.Tensor] = None, relu: bool = False, out_dtype: Optional[torch.dtype] = None,
               out: Optional[torch.Tensor] = None, tile: int = 0, act: Optional[str] = None,
               out_row_map: Optional[torch.Tensor] = None, y_ld: int = 0, res_ld: int = 0, out_hw: Optional[Tuple[int, int]] = None,
-              out_rows_per_image: int = 0, run_pixels: int = 1, fuse_next=None):
+              out_rows_per_image: int = 0, run_pixels: int = 1, fuse_next=None, second=None):
     """y = act(conv(x, w) + bias [+ residual]); x [B,H,W,Cin] contiguous channels-last storage.
     fuse_next = (w2_packed [C2][Cout], bias2 [C2], relu2): the following 1x1 conv runs in this launch's epilogue (bf16, Cout == 256);
     returns (y, y2) then, y2 [B,Ho,Wo,C2] = act2(conv1x1(y, w2) + bias2), bit-identical to the stand-alone launch.
+    second = (x2 [B,H2,W2,C2], stride): a second K source behind x, gathered at x2[b, s*ho, s*wo] -- conv3 + the downsample branch of a strided
+    Bottleneck in one accumulator chain; `w_packed` = torch.cat([w3_packed, wds_packed], 1), `bias` = b3 + bds (bf16 1x1 launches).
     run_pixels > 1: a tap reads a contiguous run of that many pixels (Cin_eff = run_pixels * x.shape[-1]; kw must be 1, no padding,
     pass out_hw): the space-to-depth stem."""
     _need_cuda(x, w_packed, bias, residual)
@@ -134,7 +136,15 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
             assert residual.is_contiguous() and residual.numel() == b * (out_rows_per_image or ho * wo) * cout
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == cout
-    assert w_packed.dtype == x.dtype and w_packed.shape[1] == packed_k(cin, kh, kw, x.dtype)
+    x2p, x2h, x2w, x2c, x2s = None, 0, 0, 0, 0
+    if second is not None:
+        x2, x2s = second
+        _need_cuda(x2)
+        assert x2.dtype == x.dtype == torch.bfloat16 and x2.is_contiguous() and x2.dim() == 4 and x2.shape[0] == b and kh == kw == 1
+        x2p, (_, x2h, x2w, x2c) = x2.data_ptr(), x2.shape
+        assert w_packed.dtype == x.dtype and w_packed.shape[1] == packed_k(cin, 1, 1, x.dtype) + packed_k(x2c, 1, 1, x.dtype)
+    else:
+        assert w_packed.dtype == x.dtype and w_packed.shape[1] == packed_k(cin, kh, kw, x.dtype)
     act_code = {None: 1 if relu else 0, "none": 0, "relu": 1, "gelu": 2, "relu_gate": 3}[act]
     if out_row_map is not None:
         assert out_row_map.dtype == torch.int32 and out_row_map.is_cuda and out_row_map.is_contiguous()
@@ -157,7 +167,7 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
                  out_row_map.data_ptr() if out_row_map is not None else None,
                  b, h, w_, cin, ho, wo, cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1],
                  act_code, dt_code(x.dtype), dt_code(od), tile, out_row_map.numel() if out_row_map is not None else 0, y_ld, res_ld,
-                 out_rows_per_image, pix, f_cout, f_w, f_b, f_y, f_relu, res_f32)
+                 out_rows_per_image, pix, f_cout, f_w, f_b, f_y, f_relu, res_f32, x2p, x2h, x2w, x2c, x2s)
     check(lib.mt4_conv_nhwc(C.byref(d), _stream()), "mt4_conv_nhwc")
     return out if fuse_next is None else (out, y2)
 

@@ -47,6 +47,7 @@ class VideoNas:
         self.fuse_next_conv = False
         import os
         self.fuse_stem_pool = not os.environ.get("MT4_NO_STEM_POOL_FUSE")   # stem conv + max-pool in one launch (bf16 uint8-frame path)
+        self.fuse_downsample = not os.environ.get("MT4_NO_DS_FUSE")   # strided Bottlenecks: conv3 + downsample branch as one GEMM (bf16)
         self.fuse_bottleneck = not os.environ.get("MT4_NO_BNECK_FUSE")   # layer1 Bottlenecks in one launch each (bf16 ResNet-50)
 
     def train(self, mode: bool = True):
@@ -121,6 +122,9 @@ class VideoNas:
                     p[q + "ds"] = self._fold(q + "downsample.0", q + "downsample.1")
                 if bottleneck and li == 1 and self.dtype == torch.bfloat16:   # the block's weights in the fused kernel's fragment order
                     p[q + "fused"] = ops.bottleneck_pack(p[q + "conv1"], p[q + "conv2"], p[q + "conv3"], p.get(q + "ds"))
+                if bottleneck and li > 1 and (q + "ds") in p and self.dtype == torch.bfloat16:   # conv3 and the downsample branch as ONE GEMM: K ranges back to back
+                    (w3, b3), (wd, bd) = p[q + "conv3"], p[q + "ds"]
+                    p[q + "conv3ds"] = (torch.cat([w3, wd], 1).contiguous(), (b3 + bd).contiguous())
         ws, bs, self._head_slices, o = [], [], {}, 0
         for task, k in _HEADS:
             if self.loss_type in (task, "all"):
@@ -164,6 +168,13 @@ class VideoNas:
                 if (bottleneck and li == 1 and self.fuse_bottleneck and self.dtype == torch.bfloat16 and pending is None and (q + "fused") in self._p):
                     # conv1 -> conv2 -> conv3 (+ downsample) of a 64-channel stride-1 block in one launch, intermediates in LDS (bit-identical)
                     x = ops.bottleneck_fused(x, self._p[q + "fused"], out=o_buf)
+                    continue
+                if bottleneck and (q + "conv3ds") in self._p and self.fuse_downsample:
+                    # conv3 and the downsample branch in ONE accumulator chain (K = planes + Cin): no identity map written and read back
+                    o = self._conv(pending if pending is not None else self._conv(x, q + "conv1", 1), q + "conv2", 3, stride=s, pad=1)
+                    pending = None
+                    wcat, bcat = self._p[q + "conv3ds"]
+                    x = ops.conv_nhwc(o, wcat, bcat, kh=1, kw=1, relu=True, out=o_buf, second=(x, s))
                     continue
                 idt = self._conv(x, q + "ds", 1, stride=s, relu=False) if (q + "ds") in self._p else x
                 if bottleneck:  # resnet.py:101-121 (stride on the 3x3)
@@ -225,9 +236,14 @@ class VideoNas:
         the bf16 ResNet-50, which run as one `mt4_bottleneck_fused_bf16` launch each"""
         plan = self.conv_plan(h, w)
         fused = self.network == "resnet50" and self.fuse_bottleneck and self.dtype == torch.bfloat16
+        ds_fused = self.network == "resnet50" and self.fuse_downsample and self.dtype == torch.bfloat16
         groups, i = [], 0
         while i < len(plan):
             name = plan[i]["name"]
+            if ds_fused and name.endswith(".ds") and not name.startswith("layer1."):   # plan order ds, conv1, conv2, conv3 -> launches conv1, conv2, conv3 + ds
+                groups += [[i + 1], [i + 2], [i + 3, i]]
+                i += 4
+                continue
             if fused and name.startswith("layer1."):
                 blk = name.split(".")[1]
                 j = i

@@ -96,6 +96,16 @@ typedef struct mt4_conv_desc {
     int32_t fuse_relu;          /* 0 / 1 */
     int32_t residual_float;       /* 1: dtype MT4_BF16 with out_dtype MT4_F32 only -- the residual (or the ReLU gate of act 3) is float32 like y: the mixed-precision
                                    training GEMMs (bf16 operands, fp32 activations); 0 otherwise */
+    /* Optional second K source: the downsample branch of a strided Bottleneck (resnet.py:116-119: identity = bn(conv1x1 stride s (x_block)))
+       accumulated in the SAME launch as conv3 + bn3, instead of a launch of its own whose map is written and read back as `residual`:
+           y[b][ho][wo] = act( [w | w2] . [ x[b][ho][wo] ; x2[b][s * ho][s * wo] ] + bias ),   bias = b3 + b_downsample
+       `w` rows hold both K ranges back to back ([Cout][Cin + x2_C], each a whole number of 128-byte K-steps).  This conv must be a 1x1 /
+       stride 1 / pad 0 bf16 -> bf16 launch without residual or out_row_map, tile 0; MT4_EUNSUPPORTED otherwise.  One fp32 accumulator chain:
+       the branch is NOT rounded to bf16 before the add (the two-launch form rounds it), so results differ from that form by bf16 rounding of
+       the identity, towards the reference's fp32 arithmetic. */
+    const void* x2;             /* [B][x2_H][x2_W][x2_C] bf16 or NULL */
+    int32_t x2_H, x2_W, x2_C;
+    int32_t x2_stride;          /* s */
 } mt4_conv_desc;
 
 int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream);

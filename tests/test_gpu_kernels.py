@@ -315,3 +315,27 @@ def test_stem_maxpool_fused_bit_identical_to_two_launches(cuda, b, h, w):
     y = ops.stem_maxpool(xs, wp, bias)
     assert y.shape == ref.shape and float(ref.float().abs().max()) > 0.5
     assert torch.equal(y.view(torch.int16), ref.view(torch.int16)), float((y.float() - ref.float()).abs().max())
+
+
+@pytest.mark.parametrize("b,h2,w2,mid,c2,cout,s", [(3, 28, 28, 128, 256, 512, 2), (2, 27, 13, 256, 512, 1024, 2), (5, 7, 7, 64, 128, 256, 1), (1, 56, 56, 128, 256, 512, 2)])
+def test_conv_with_second_k_source_is_conv3_plus_downsample(cuda, b, h2, w2, mid, c2, cout, s):
+    """`mt4_conv_desc.x2`: conv3 + bn3 and the downsample branch of a strided Bottleneck (`resnet.py:112-119`) as one GEMM over K = planes + Cin.
+    Against fp32 torch on the same bf16 operands (one rounding at the end), and within bf16 rounding of the identity of the two-launch form"""
+    from computervision_codes_amd import ops
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(5 + h2)
+    ho, wo = (h2 - 1) // s + 1, (w2 - 1) // s + 1
+    t2 = torch.randn((b, ho, wo, mid), generator=g).to(bf)
+    xb = torch.randn((b, h2, w2, c2), generator=g).to(bf)
+    w3 = (torch.randn((cout, mid, 1, 1), generator=g) * mid ** -0.5)
+    wd = (torch.randn((cout, c2, 1, 1), generator=g) * c2 ** -0.5)
+    b3, bd = torch.randn(cout, generator=g) * 0.3, torch.randn(cout, generator=g) * 0.3
+    w3p, wdp = ops.pack_conv_weight(w3.to(cuda), None, bf), ops.pack_conv_weight(wd.to(cuda), None, bf)
+    y = ops.conv_nhwc(t2.to(cuda), torch.cat([w3p, wdp], 1).contiguous(), (b3 + bd).to(cuda), kh=1, kw=1, relu=True, second=(xb.to(cuda), s))
+    ref = torch.relu(t2.float() @ w3.view(cout, mid).to(bf).float().T + xb[:, ::s, ::s].float() @ wd.view(cout, c2).to(bf).float().T + (b3 + bd))
+    assert y.shape == ref.shape
+    err = (y.float().cpu() - ref).abs()
+    assert float((err / (ref.abs() + 1.0)).max()) < 2 ** -8            # half a bf16 ulp of the result + accumulation order
+    idt = ops.conv_nhwc(xb.to(cuda), wdp, bd.to(cuda), kh=1, kw=1, stride=(s, s), relu=False)
+    two = ops.conv_nhwc(t2.to(cuda), w3p, b3.to(cuda), kh=1, kw=1, residual=idt, relu=True)
+    assert float(((y.float() - two.float()).abs() / (two.float().abs() + 1.0)).max()) < 2 ** -6
