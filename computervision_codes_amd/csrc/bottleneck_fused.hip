@@ -43,6 +43,13 @@ struct BneckK {
     const float *b1, *b2, *b3, *bds;
     int B, H, W, tiles_h, tiles_w;
     int nt;                                  // non-temporal output stores
+    // NEXT: the 1x1 conv that follows the block (conv1 + bn1 + relu of the strided Bottleneck behind it, 256 -> 128 channels) runs on the tile's
+    // result while it is in LDS: y2 [B][H][W][128]; y itself is then stored at the even pixels only, [B][H2][W2][256] (all its other reader,
+    // the stride-2 downsample branch, takes)
+    char* y2;
+    const char* wn;                          // fragment-ordered [8 channel tiles][8 K steps][lane] x 16 B
+    const float* bn;
+    int H2, W2;
 };
 
 __device__ __forceinline__ f32x4 bias4(const float* b, int n) {
@@ -63,8 +70,9 @@ __device__ __forceinline__ f32x4 mfma_bf16(uint4 wfrag, uint4 xfrag, f32x4 acc) 
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfrag), __builtin_bit_cast(bf16x8_t, xfrag), acc, 0, 0, 0);
 }
 
-template <int CIN, bool DS>
+template <int CIN, bool DS, bool NEXT = false>
 __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK a) {
+    static_assert(!NEXT || !DS, "the following conv rides behind an identity block");
     constexpr int KC = CIN / 64;
     constexpr int NXS = KC > 1 ? 2 : 1;
     static_assert(DS ? CIN == 64 : CIN == 256, "layer1.0 (64 channels in, downsample branch) or layer1.1+ (256 in, identity)");
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
     const int th = trem / a.tiles_w;
     const int h0 = th * TH, w0 = (trem - th * a.tiles_w) * TW;
     const char* const ximg = a.x + (long long)img * a.H * a.W * (CIN * 2);
-    char* const yimg = a.y + (long long)img * a.H * a.W * 512;
+    char* const yimg = NEXT ? a.y + (long long)img * a.H2 * a.W2 * 512 : a.y + (long long)img * a.H * a.W * 512;
 
     // ---------------------------------------------------------------- phase 1: t1 = relu(W1 . x + b1) on the halo tile
     // staging: thread (row tid >> 3, chunk tid & 7) moves 16 bytes of halo pixels row, row + 32, ... (5 passes per K-chunk)
@@ -248,9 +256,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
         fx3[j][1] = *(const uint4*)(t2 + j * (16 * ROW_B) + r16 * ROW_B + sw1);
     }
     const int st_tx = tid >> 4, st_chunk = tid & 15;       // read-back: column st_tx of every row, 16 chunks of 16 bytes per pixel
+    uint4 wfn[NEXT ? 2 : 1][NEXT ? 8 : 1];             // NEXT: this wave's fragments of the following conv (channel tiles 2 wave, 2 wave + 1)
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        if (pass) __syncthreads();                       // the previous pass has been read back
+        char* const ysp = NEXT ? xs + pass * YS_BYTES : ys;   // NEXT keeps both passes (the whole 256-channel tile) for phase 4
+        if (pass && !NEXT) __syncthreads();              // the previous pass has been read back
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
             const int i = pass * 2 + ii;
@@ -295,17 +305,36 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const uint2 o = relu_pack4(acc3[j]);
-                *(uint2*)(ys + j * (16 * 256) + wr_off) = o;
+                *(uint2*)(ysp + j * (16 * 256) + wr_off) = o;
+            }
+        }
+        if constexpr (NEXT) {
+            if (pass == 1) {     // in flight across the barrier and the read-back
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) wfn[c][ks] = *(const uint4*)(a.wn + (((2 * wave + c) * 8 + ks) * 64 + lane) * 16);
             }
         }
         __syncthreads();
         {
             const int w = w0 + st_tx;
             const int rd_off = st_tx * 256 + ((st_chunk ^ st_tx) << 4);
-            if (st_tx < TW && w < a.W) {
+            if constexpr (NEXT) {
+                if (st_tx < TW && w < a.W && !(st_tx & 1)) {      // even pixels only (h0, w0 are even)
+                    const uint4 v0 = *(const uint4*)(ysp + rd_off), v1 = *(const uint4*)(ysp + 2 * (16 * 256) + rd_off);
+                    const uint4 v2 = *(const uint4*)(ysp + 4 * (16 * 256) + rd_off), v3 = *(const uint4*)(ysp + 6 * (16 * 256) + rd_off);
+                    char* const yp = yimg + (unsigned)(((h0 >> 1) * a.W2 + (w >> 1)) * 512 + pass * 256 + st_chunk * 16);
+                    const int rows = a.H - h0;                     // (> 0)
+                    *(uint4*)yp = v0;
+                    if (rows > 2) *(uint4*)(yp + a.W2 * 512) = v1;
+                    if (rows > 4) *(uint4*)(yp + 2 * a.W2 * 512) = v2;
+                    if (rows > 6) *(uint4*)(yp + 3 * a.W2 * 512) = v3;
+                }
+            } else if (st_tx < TW && w < a.W) {
                 uint4 v[8];
 #pragma unroll
-                for (int ty = 0; ty < 8; ++ty) v[ty] = *(const uint4*)(ys + ty * (16 * 256) + rd_off);
+                for (int ty = 0; ty < 8; ++ty) v[ty] = *(const uint4*)(ysp + ty * (16 * 256) + rd_off);
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int ty = 0; ty < 8; ++ty) {
@@ -319,6 +348,56 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
             }
         }
     }
+    if constexpr (NEXT) {
+        // ------------------------------------------------------------ phase 4: y2 = relu(Wn . y + bn), 256 -> 128 channels, on the tile in LDS
+        // wave w: channel tiles 2 w, 2 w + 1 for the 8 pixel tiles; K steps of 32 channels ascending = the stand-alone launch's chain
+        f32x4 acc4[2][8];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const f32x4 b4 = bias4(a.bn, (2 * wave + c) * 16 + q * 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc4[c][j] = b4;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            uint4 fy[8];
+            const char* yb = xs + (ks >> 2) * YS_BYTES + r16 * 256 + ((((ks & 3) * 4 + q) ^ r16) << 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fy[j] = *(const uint4*)(yb + j * (16 * 256));
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc4[c][j] = mfma_bf16(wfn[c][ks], fy[j], acc4[c][j]);
+        }
+        __syncthreads();                                 // every wave has read the tile (and pass 1 has been read back)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int cbyte = ((2 * wave + c) * 16 + q * 4) * 2;
+            const int wr_off = r16 * 256 + (((cbyte >> 4) ^ r16) << 4) + (cbyte & 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *(uint2*)(xs + j * (16 * 256) + wr_off) = relu_pack4(acc4[c][j]);
+        }
+        __syncthreads();
+        const int w = w0 + st_tx;
+        if (st_tx < TW && w < a.W) {
+            const int rd_off = st_tx * 256 + ((st_chunk ^ st_tx) << 4);
+            char* const y2img = a.y2 + (long long)img * a.H * a.W * 256;
+            uint4 v[8];
+#pragma unroll
+            for (int ty = 0; ty < 8; ++ty) v[ty] = *(const uint4*)(xs + ty * (16 * 256) + rd_off);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int ty = 0; ty < 8; ++ty) {
+                if (h0 + ty < a.H) {
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    char* yp = y2img + (unsigned)(((h0 + ty) * a.W + w) * 256 + st_chunk * 16);
+                    if (a.nt) __builtin_nontemporal_store((u32x4){v[ty].x, v[ty].y, v[ty].z, v[ty].w}, (u32x4*)yp);
+                    else *(uint4*)yp = v[ty];
+                }
+            }
+        }
+    }
 }
 
 // Forms of this kernel that were built, are bit-identical, and lost (1336 frames per block, identity blocks): a persistent one (one workgroup of
@@ -327,12 +406,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
 // stalls, and at 256 registers every spill reload in front of a DMA or store costs a vmcnt(0); three workgroups per CU (40 KB of LDS: one x chunk
 // buffer reused for t2, t1 reused as a 16 KB staging for four passes of 64 channels; 168 registers; 18 barriers per tile) 1.44 ms, exactly the
 // two-workgroup time of that moment: the bound was the residual's second trip over the fabric (see phase 1), not occupancy.
-template <int CIN, bool DS>
+template <int CIN, bool DS, bool NEXT = false>
 int launch(const BneckK& a, hipStream_t stream) {
     constexpr int NXS = CIN > 64 ? 2 : 1;
     constexpr int LDS = NXS * XS_BYTES + T2_BYTES + (DS ? YS_BYTES : T1_BYTES);
     static_assert(LDS <= 80 * 1024, "two workgroups per CU");
-    auto fn = bottleneck64_fused_kernel<CIN, DS>;
+    static_assert(!NEXT || LDS >= 2 * YS_BYTES, "both output passes stay in LDS");
+    auto fn = bottleneck64_fused_kernel<CIN, DS, NEXT>;
     MT4_RAISE_LDS(fn);
     const long long nblk = (long long)a.B * a.tiles_h * a.tiles_w;
     hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(256), LDS, stream, a);
@@ -400,4 +480,44 @@ extern "C" int mt4_bottleneck_fused_bf16(const void* x, void* y, const void* w_f
     a.nt = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
     if ((long long)B * a.tiles_h * a.tiles_w > 0x7fffffffLL) return MT4_EUNSUPPORTED;
     return ds ? launch<64, true>(a, (hipStream_t)stream) : launch<256, false>(a, (hipStream_t)stream);
+}
+
+// the 1x1 conv behind a fused identity block (conv1 of the strided Bottleneck that follows layer1: 256 -> 128 channels) in fragment order
+extern "C" int64_t mt4_bottleneck_next_packed_bytes(void) { return (int64_t)8 * 8 * 1024; }
+
+extern "C" int mt4_bottleneck_pack_next_bf16(const void* w1_next, void* out, void* stream) {
+    mt4_clear_error();
+    if (!w1_next || !out) return MT4_EINVAL;
+    if (((uintptr_t)w1_next | (uintptr_t)out) & 15) return MT4_EALIGN;
+    const int n = 8 * 8 * 64;
+    hipLaunchKernelGGL(bneck_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const u16*)w1_next, (uint4*)out, 8, 8,
+                       (int)mt4_conv_packed_k(256, 1, 1, MT4_BF16));
+    return mt4_check_launch();
+}
+
+// mt4_bottleneck_fused_bf16 for an identity block (Cin = 256) that is followed by a strided Bottleneck: also runs that block's conv1 + bn1 +
+// relu (w_next: mt4_bottleneck_pack_next_bf16, 256 -> 128 channels) on the result while it is in LDS.  y_even [B][(H + 1) / 2][(W + 1) / 2][256]
+// receives the block's output at the even pixels (what the stride-2 downsample branch reads), t_next [B][H][W][128] the following conv's
+// output; both bit-identical to the separate launches.
+extern "C" int mt4_bottleneck_fused_next_bf16(const void* x, void* y_even, void* t_next, const void* w_frag, const float* b1, const float* b2,
+                                              const float* b3, const void* w_next, const float* b_next, int32_t B, int32_t H, int32_t W, void* stream) {
+    mt4_clear_error();
+    if (!x || !y_even || !t_next || !w_frag || !b1 || !b2 || !b3 || !w_next || !b_next || B <= 0 || H <= 0 || W <= 0) return MT4_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)y_even | (uintptr_t)t_next | (uintptr_t)w_frag | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)b3 | (uintptr_t)w_next |
+         (uintptr_t)b_next) & 15)
+        return MT4_EALIGN;
+    if ((long long)H * W * 512 > 0x7fffffffLL) return MT4_EUNSUPPORTED;
+    BneckK a{};
+    a.x = (const char*)x; a.y = (char*)y_even; a.y2 = (char*)t_next;
+    a.w1 = (const char*)w_frag;
+    a.w2 = a.w1 + (long long)4 * 8 * 1024;
+    a.w3 = a.w2 + (long long)4 * 18 * 1024;
+    a.wds = nullptr;
+    a.b1 = b1; a.b2 = b2; a.b3 = b3; a.bds = nullptr;
+    a.wn = (const char*)w_next; a.bn = b_next;
+    a.B = B; a.H = H; a.W = W; a.H2 = (H + 1) / 2; a.W2 = (W + 1) / 2;
+    a.tiles_h = cdiv(H, TH); a.tiles_w = cdiv(W, TW);
+    a.nt = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
+    if ((long long)B * a.tiles_h * a.tiles_w > 0x7fffffffLL) return MT4_EUNSUPPORTED;
+    return launch<256, false, true>(a, (hipStream_t)stream);
 }

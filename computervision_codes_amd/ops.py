@@ -450,6 +450,33 @@ def bottleneck_fused(x: torch.Tensor, packed, out: Optional[torch.Tensor] = None
     return y
 
 
+def bottleneck_pack_next(conv1_next):
+    """conv1 (+ folded bn1) of the strided Bottleneck behind layer1, (packed bf16 [128, 256], bias), in the fragment order of
+    `bottleneck_fused_next`"""
+    w, b = conv1_next
+    _need_cuda(w, b)
+    assert w.dtype == torch.bfloat16 and tuple(w.shape) == (128, packed_k(256, 1, 1, torch.bfloat16)) and b.numel() == 128
+    frag = torch.empty(int(lib.mt4_bottleneck_next_packed_bytes()), dtype=torch.uint8, device=w.device)
+    check(lib.mt4_bottleneck_pack_next_bf16(w.data_ptr(), frag.data_ptr(), _stream()), "mt4_bottleneck_pack_next_bf16")
+    return frag, b.contiguous()
+
+
+def bottleneck_fused_next(x: torch.Tensor, packed, packed_next):
+    """`bottleneck_fused` for the last identity block of layer1 plus the following block's conv1 + bn1 + relu on the result while it is in LDS
+    (`mt4_bottleneck_fused_next_bf16`): returns (y at the even pixels [B,(H+1)//2,(W+1)//2,256], conv1 output [B,H,W,128]), bit-identical to the
+    separate launches"""
+    frag, b1, b2, b3, bd, cin = packed
+    fn, bn = packed_next
+    _need_cuda(x, frag, fn)
+    assert bd is None and cin == 256 and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4 and x.shape[3] == 256
+    b, h, w, _ = x.shape
+    y_even = torch.empty((b, (h + 1) // 2, (w + 1) // 2, 256), dtype=torch.bfloat16, device=x.device)
+    t = torch.empty((b, h, w, 128), dtype=torch.bfloat16, device=x.device)
+    check(lib.mt4_bottleneck_fused_next_bf16(x.data_ptr(), y_even.data_ptr(), t.data_ptr(), frag.data_ptr(), b1.data_ptr(), b2.data_ptr(), b3.data_ptr(),
+                                             fn.data_ptr(), bn.data_ptr(), b, h, w, _stream()), "mt4_bottleneck_fused_next_bf16")
+    return y_even, t
+
+
 # ----------------------------------------------------------------------------------------- transformer-stage pieces
 def linear(x2d: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, act: Optional[str] = None,
            residual: Optional[torch.Tensor] = None, out_row_map: Optional[torch.Tensor] = None,

@@ -47,6 +47,7 @@ class VideoNas:
         self.fuse_next_conv = False
         import os
         self.fuse_stem_pool = not os.environ.get("MT4_NO_STEM_POOL_FUSE")   # stem conv + max-pool in one launch (bf16 uint8-frame path)
+        self.fuse_next_block = not os.environ.get("MT4_NO_NEXT_FUSE")   # layer2.0's conv1 behind the last layer1 block, in its launch
         self.fuse_downsample = not os.environ.get("MT4_NO_DS_FUSE")   # strided Bottlenecks: conv3 + downsample branch as one GEMM (bf16)
         self.fuse_bottleneck = not os.environ.get("MT4_NO_BNECK_FUSE")   # layer1 Bottlenecks in one launch each (bf16 ResNet-50)
 
@@ -125,6 +126,8 @@ class VideoNas:
                 if bottleneck and li > 1 and (q + "ds") in p and self.dtype == torch.bfloat16:   # conv3 and the downsample branch as ONE GEMM: K ranges back to back
                     (w3, b3), (wd, bd) = p[q + "conv3"], p[q + "ds"]
                     p[q + "conv3ds"] = (torch.cat([w3, wd], 1).contiguous(), (b3 + bd).contiguous())
+                    if li == 2:      # its conv1 rides behind the last layer1 block (ops.bottleneck_fused_next)
+                        p[q + "conv1next"] = ops.bottleneck_pack_next(p[q + "conv1"])
         ws, bs, self._head_slices, o = [], [], {}, 0
         for task, k in _HEADS:
             if self.loss_type in (task, "all"):
@@ -159,6 +162,7 @@ class VideoNas:
         pre = "basemodel.basemodel."
         bottleneck = self.network == "resnet50"
         pending = None          # conv1 output of the block about to run, when the previous block's conv3 launch produced it
+        x_is_even = False       # x holds the previous block's output at the even pixels only (ops.bottleneck_fused_next)
         for li in range(first, last + 1):
             n = _DEPTHS[self.network][li - 1]
             for bi in range(n):
@@ -167,14 +171,22 @@ class VideoNas:
                 o_buf = out if (li == last and bi == n - 1) else None
                 if (bottleneck and li == 1 and self.fuse_bottleneck and self.dtype == torch.bfloat16 and pending is None and (q + "fused") in self._p):
                     # conv1 -> conv2 -> conv3 (+ downsample) of a 64-channel stride-1 block in one launch, intermediates in LDS (bit-identical)
-                    x = ops.bottleneck_fused(x, self._p[q + "fused"], out=o_buf)
+                    nq = f"{pre}layer2.0.conv1next"
+                    if bi == n - 1 and li < last and self.fuse_downsample and self.fuse_next_block and nq in self._p:
+                        # ... and the next block's conv1 on the result while it is in LDS; the map itself is kept at the even pixels only
+                        # (its other reader is the stride-2 downsample branch)
+                        x, pending = ops.bottleneck_fused_next(x, self._p[q + "fused"], self._p[nq])
+                        x_is_even = True
+                    else:
+                        x = ops.bottleneck_fused(x, self._p[q + "fused"], out=o_buf)
                     continue
                 if bottleneck and (q + "conv3ds") in self._p and self.fuse_downsample:
                     # conv3 and the downsample branch in ONE accumulator chain (K = planes + Cin): no identity map written and read back
                     o = self._conv(pending if pending is not None else self._conv(x, q + "conv1", 1), q + "conv2", 3, stride=s, pad=1)
                     pending = None
                     wcat, bcat = self._p[q + "conv3ds"]
-                    x = ops.conv_nhwc(o, wcat, bcat, kh=1, kw=1, relu=True, out=o_buf, second=(x, s))
+                    x = ops.conv_nhwc(o, wcat, bcat, kh=1, kw=1, relu=True, out=o_buf, second=(x, 1 if x_is_even else s))
+                    x_is_even = False
                     continue
                 idt = self._conv(x, q + "ds", 1, stride=s, relu=False) if (q + "ds") in self._p else x
                 if bottleneck:  # resnet.py:101-121 (stride on the 3x3)
@@ -237,11 +249,16 @@ class VideoNas:
         plan = self.conv_plan(h, w)
         fused = self.network == "resnet50" and self.fuse_bottleneck and self.dtype == torch.bfloat16
         ds_fused = self.network == "resnet50" and self.fuse_downsample and self.dtype == torch.bfloat16
+        next_fused = fused and ds_fused and self.fuse_next_block
         groups, i = [], 0
         while i < len(plan):
             name = plan[i]["name"]
             if ds_fused and name.endswith(".ds") and not name.startswith("layer1."):   # plan order ds, conv1, conv2, conv3 -> launches conv1, conv2, conv3 + ds
-                groups += [[i + 1], [i + 2], [i + 3, i]]
+                if next_fused and name.startswith("layer2."):
+                    groups[-1].append(i + 1)          # layer2.0.conv1 ran in the launch of the last layer1 block
+                else:
+                    groups.append([i + 1])
+                groups += [[i + 2], [i + 3, i]]
                 i += 4
                 continue
             if fused and name.startswith("layer1."):

@@ -339,3 +339,25 @@ def test_conv_with_second_k_source_is_conv3_plus_downsample(cuda, b, h2, w2, mid
     idt = ops.conv_nhwc(xb.to(cuda), wdp, bd.to(cuda), kh=1, kw=1, stride=(s, s), relu=False)
     two = ops.conv_nhwc(t2.to(cuda), w3p, b3.to(cuda), kh=1, kw=1, residual=idt, relu=True)
     assert float(((y.float() - two.float()).abs() / (two.float().abs() + 1.0)).max()) < 2 ** -6
+
+
+@pytest.mark.parametrize("b,h,w", [(3, 56, 56), (2, 16, 24), (1, 9, 15), (2, 8, 14), (1, 1, 1)])
+def test_bottleneck_fused_next_bit_identical(cuda, b, h, w):
+    """`mt4_bottleneck_fused_next_bf16`: the last identity block of layer1 + the following block's conv1 in one launch; the block's output at the
+    even pixels and the conv1 output equal the separate launches bit for bit (full, ragged and odd-sized frames)"""
+    from computervision_codes_amd import ops
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(3 + h)
+    x = torch.randn((b, h, w, 256), generator=g).to(cuda).to(bf)
+
+    def mk(cout, ci, k, s):
+        wt = (torch.randn((cout, ci, k, k), generator=g) * s).to(cuda)
+        return ops.pack_conv_weight(wt, None, bf), (torch.randn(cout, generator=g) * 0.3).to(cuda)
+    c1, c2, c3, cn = mk(64, 256, 1, 1 / 16), mk(64, 64, 3, 1 / 24), mk(256, 64, 1, 1 / 8), mk(128, 256, 1, 1 / 16)
+    packed = ops.bottleneck_pack(c1, c2, c3, None)
+    ref_y = ops.bottleneck_fused(x, packed)
+    ref_t = ops.conv_nhwc(ref_y, cn[0], cn[1], kh=1, kw=1, relu=True)
+    y_even, t = ops.bottleneck_fused_next(x, packed, ops.bottleneck_pack_next(cn))
+    assert float(ref_t.float().abs().max()) > 0.5
+    assert torch.equal(y_even.view(torch.int16), ref_y[:, ::2, ::2].contiguous().view(torch.int16))
+    assert torch.equal(t.view(torch.int16), ref_t.view(torch.int16)), float((t.float() - ref_t.float()).abs().max())
