@@ -62,7 +62,7 @@ def time_conv_kernels(model, frames, iters=3):
     recorded on the stream the kernels are launched on (torch's current stream), one event pair per launch."""
     from computervision_codes_amd import ops
     pairs = []
-    names = ("conv_nhwc", "bottleneck_fused", "bottleneck_fused_next", "stem_maxpool")
+    names = ("conv_nhwc", "conv3x3_expand", "bottleneck_fused", "bottleneck_fused_next", "stem_maxpool")
     origs = {n: getattr(ops, n) for n in names}
 
     def wrap(fn):
@@ -637,7 +637,11 @@ def main():
             rows = []
             for g, ms in zip(groups, per_launch):
                 fl = sum(2 * a.batch * plan[i]["Ho"] * plan[i]["Wo"] * plan[i]["Cout"] * plan[i]["Cin"] * plan[i]["kh"] * plan[i]["kw"] for i in g)
-                gname = plan[g[0]]["name"] + " + downsample" if len(g) == 2 else plan[g[0]]["name"].rsplit(".", 1)[0] + (" + " + plan[g[-1]]["name"] if plan[g[-1]]["name"].split(".")[0] != plan[g[0]]["name"].split(".")[0] else "")
+                blk = lambda nm: nm.rsplit(".", 1)[0]
+                if len(g) == 2:
+                    gname = plan[g[0]]["name"] + " + " + ("downsample" if plan[g[1]]["name"].endswith(".ds") else plan[g[1]]["name"].rsplit(".", 1)[1])
+                else:
+                    gname = blk(plan[g[0]]["name"]) + (" + " + plan[g[-1]]["name"] if blk(plan[g[-1]]["name"]) != blk(plan[g[0]]["name"]) else "")
                 rec = dict(plan[g[0]]) if len(g) == 1 else dict(name=gname + " (one launch)", fused=[plan[i]["name"] for i in g])
                 rows.append(dict(rec, ms=round(ms, 4), tflops=round(fl / (ms * 1e-3) / 1e12, 1)))
             os.makedirs(os.path.dirname(os.path.abspath(a.per_layer)), exist_ok=True)

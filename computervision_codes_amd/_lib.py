@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
         ("out_row_map_len", C.c_int32), ("y_ld", C.c_int32), ("res_ld", C.c_int32), ("out_rows_per_image", C.c_int32),
         ("x_pixel_stride", C.c_int32), ("fuse_cout", C.c_int32),
         ("fuse_w", C.c_void_p), ("fuse_bias", C.c_void_p), ("fuse_y", C.c_void_p), ("fuse_relu", C.c_int32), ("residual_float", C.c_int32),
-        ("x2", C.c_void_p), ("x2_H", C.c_int32), ("x2_W", C.c_int32), ("x2_C", C.c_int32), ("x2_stride", C.c_int32),
+        ("x2", C.c_void_p), ("x2_H", C.c_int32), ("x2_W", C.c_int32), ("x2_C", C.c_int32), ("x2_stride", C.c_int32), ("fuse_expand", C.c_int32),
     ]
 
 
@@ -117,6 +117,7 @@ SIGNATURES = {
     "mt4_bottleneck_packed_bytes": (C.c_int64, [_i32, _i32]),
     "mt4_bottleneck_pack_bf16": (C.c_int, [_vp] * 4 + [_i32, _vp, _vp]),
     "mt4_bottleneck_fused_bf16": (C.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
+    "mt4_pack_fragments_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "mt4_bottleneck_next_packed_bytes": (C.c_int64, []),
     "mt4_bottleneck_pack_next_bf16": (C.c_int, [_vp, _vp, _vp]),
     "mt4_bottleneck_fused_next_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
@@ -158,6 +159,9 @@ def _load() -> C.CDLL:
 
 
 lib = _load()
+
+
+MT4_EUNSUPPORTED = -4   # include/mt4hip.h
 
 
 def check(code: int, what: str = "") -> None:

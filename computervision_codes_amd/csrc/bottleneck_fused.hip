@@ -20,6 +20,8 @@
 //   phase 3: conv3 in two passes of 128 output channels; wave w owns channel tiles w, w + 4, w + 8, w + 12; residual added in the
 //            accumulator layout (identity blocks: picked out of the LDS copy of x chunk i during phase 1 -- no second read), result staged in
 //            LDS and stored as 16-byte vectors, 256 B per pixel.
+//   phase 4 (NEXT, mt4_bottleneck_fused_next_bf16): the 1x1 conv of the block that follows layer1 (256 -> 128 channels) on the tile while both
+//            passes are in LDS; the block's own map is then stored at the even pixels only (its remaining reader is the stride-2 branch).
 // K order and MFMA chain (bias-initialised fp32 accumulator; K-steps of 64 channels ascending, 3x3: tap-major; two 32-wide MFMAs per step;
 // t1 / t2 / the downsample branch rounded to bf16 exactly where the layer-by-layer path stores them) are those of the stand-alone launches:
 // the result is bit-identical to conv1 -> conv2 -> conv3 through mt4_conv_nhwc.
@@ -147,7 +149,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
     const int sw0 = (q ^ (r16 & 7)) << 4, sw1 = ((4 + q) ^ (r16 & 7)) << 4;   // fragment chunk of kk = 0 / 1 in rows 16 i + r16
     // identity blocks: the residual of output channels 64 i + 16 wave + 4 q .. + 3 (channel tile 4 i + wave of pass i / 2) IS x chunk i at the
     // tile's own pixels -- picked out of the LDS copy of the chunk while it is there (row (j + 1) * 16 + r16 + 1 of the halo tile) instead of
-    // read from memory a second time (the re-read had left the XCD's L2 by phase 3 and came back over the fabric: 2.1 GB per block)
+    // read from memory a second time (8-byte loads in the accumulator layout: 66 M sector requests to the L2 per block against 23 M for all the x
+    // chunks -- the request count, not the bytes, was the cost: FETCH_SIZE is the same with and without the re-read)
     uint2 res[DS ? 1 : 4][DS ? 1 : 8];
     const int res_off = (r16 + 1) * ROW_B + (((2 * wave + (q >> 1)) ^ ((r16 + 1) & 7)) << 4) + (q & 1) * 8;
 #pragma unroll
@@ -405,7 +408,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
 // registers) 2.4-2.7 ms -- eight waves meeting at ten barriers per tile leave the CU idle where two independent workgroups fill each other's
 // stalls, and at 256 registers every spill reload in front of a DMA or store costs a vmcnt(0); three workgroups per CU (40 KB of LDS: one x chunk
 // buffer reused for t2, t1 reused as a 16 KB staging for four passes of 64 channels; 168 registers; 18 barriers per tile) 1.44 ms, exactly the
-// two-workgroup time of that moment: the bound was the residual's second trip over the fabric (see phase 1), not occupancy.
+// two-workgroup time of that moment: the bound was the number of L2 requests (the residual's 8-byte re-read, see phase 1, and the weight
+// fragments' 64-byte pieces, see the header), not occupancy.
 template <int CIN, bool DS, bool NEXT = false>
 int launch(const BneckK& a, hipStream_t stream) {
     constexpr int NXS = CIN > 64 ? 2 : 1;
@@ -520,4 +524,18 @@ extern "C" int mt4_bottleneck_fused_next_bf16(const void* x, void* y_even, void*
     a.nt = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
     if ((long long)B * a.tiles_h * a.tiles_w > 0x7fffffffLL) return MT4_EUNSUPPORTED;
     return launch<256, false, true>(a, (hipStream_t)stream);
+}
+
+// a packed bf16 matrix [rows][row_elems] (mt4_pack_conv_weight) in MFMA fragment order: [rows / 16][row_elems / 32][lane] x 16 bytes
+// (mt4_conv_desc.fuse_expand reads the expansion weights this way)
+extern "C" int mt4_pack_fragments_bf16(const void* w_packed, int32_t rows, int32_t row_elems, void* out, void* stream) {
+    mt4_clear_error();
+    if (!w_packed || !out || rows <= 0 || row_elems <= 0) return MT4_EINVAL;
+    if ((rows % 16) || (row_elems % 32)) return MT4_EUNSUPPORTED;
+    if (((uintptr_t)w_packed | (uintptr_t)out) & 15) return MT4_EALIGN;
+    const long long n = (long long)(rows / 16) * (row_elems / 32) * 64;
+    if (n > 0x7fffffffLL) return MT4_EUNSUPPORTED;
+    hipLaunchKernelGGL(bneck_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u16*)w_packed, (uint4*)out, rows / 16,
+                       row_elems / 32, row_elems);
+    return mt4_check_launch();
 }

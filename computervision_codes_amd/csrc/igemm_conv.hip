@@ -672,8 +672,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel
 // Same K walk (slice outer, taps inner) and the same MFMA chain as the generic kernel: results are bit-identical.
 // Weight K-steps (BN rows x 128 B) run through a ring of WS stages, issued WS-1 steps ahead: a K-step of the narrow tiles is shorter
 // than the L2 -> LDS latency, so one step of prefetch distance leaves every step waiting for its weights.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int WS>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_patch_kernel(const ConvK a, const int pra, const int npatch) {
+// EXPAND (BN == 128 = every channel of the layer): the Bottleneck's conv3 + bn3 + add + ReLU (resnet.py:112-119) follows in the same launch.
+// The tile's ReLU'd bf16 result -- what the stand-alone launch stores -- stays in LDS as the pixel operand of a second GEMM over K = 128 against
+// the fragment-ordered expansion weights (a.f_w, 128-channel chunks of a.f_cout outputs); each chunk goes through the fp32 staging with the
+// block's residual (a.res, pitch f_cout) and is stored to a.f_y.  a.y is not written: the 128-channel map never reaches memory.  Same K order
+// and bias-initialised accumulators as the stand-alone 1x1 launch: bit-identical.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WS, bool EXPAND = false>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 : 1) void conv3x3_patch_kernel(const ConvK a, const int pra, const int npatch) {
+    static_assert(!EXPAND || BN == 128, "the expansion needs a pixel's whole channel vector in the tile");
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int NTH = NW * 64;
     constexpr int RPP = NTH / 8;
@@ -844,6 +850,122 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_patch_kernel(c
     const int rc = tid % TPR, rr = tid / TPR;
     const int n = n0 + rc * 8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (EXPAND) {
+        // t2 tile as the pixel operand: two planes (64 channels = 128 B per pixel each), 16-byte chunks XOR-swizzled with row & 7
+        char* const t2p = smem;
+        char* const stg = smem + 2 * BM * 128;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int row = wave_m * WM + j * 16 + r16;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int ch = wave_n * WN + i * 16 + q * 4;
+                const int cb = (ch & 63) * 2;
+                f32x4 v = acc[i][j];
+                if (a.relu == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *(uint2*)(t2p + (ch >> 6) * (BM * 128) + row * 128 + (((cb >> 4) ^ (row & 7)) << 4) + (cb & 8)) =
+                    make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+        }
+        __syncthreads();
+        // per 128-channel output chunk: two staging passes of BM / 2 pixels.  The residual rows of the NEXT pass are requested before this pass's
+        // LDS hand-off (issued just in time, every pass waited out an HBM round trip -- 8 per tile), the weight fragments of the next chunk right
+        // behind this chunk's MFMAs; the pixel fragments are re-read from LDS per K step (kept in registers they would leave no room for either)
+        const int nchunk = a.f_cout >> 7;
+        auto load_res = [&](int c, int p, u32x4 (&r)[ITERS]) {
+            const int n2 = c * 128 + rc * 8;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int lrow = rr + it * RPI;
+                const int m = m0 + (lrow / WMP) * WM + p * WMP + (lrow % WMP);
+                r[it] = (u32x4){0u, 0u, 0u, 0u};
+                if (a.res && lrow < BMP && m < a.M) {
+                    const u32x4* rp = (const u32x4*)(a.res + ((long long)m * a.f_cout + n2) * 2);
+                    r[it] = a.nt_epi ? __builtin_nontemporal_load(rp) : *rp;
+                }
+            }
+        };
+        uint4 fa[NT][4];      // fragment-ordered weights: [channel tile][K step of 32][lane] x 16 B
+        auto load_w = [&](int c) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fa[i][ks] = *(const uint4*)(a.f_w + ((long long)(((c * 8 + wave_n * NT + i) * 4 + ks) * 64 + lane)) * 16);
+        };
+        static_assert(PASSES == 2, "the residual prefetch alternates between two register sets");
+        u32x4 r0[ITERS], r1[ITERS];      // residual rows of pass 0 / pass 1
+        load_res(0, 0, r0);
+        load_w(0);
+#pragma unroll 1
+        for (int c = 0; c < nchunk; ++c) {
+            f32x4 acc2[NT][MT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const float4 t = *(const float4*)(a.f_bias + c * 128 + wave_n * WN + i * 16 + q * 4);
+#pragma unroll
+                for (int j = 0; j < MT; ++j) acc2[i][j] = (f32x4){t.x, t.y, t.z, t.w};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 fb[MT];
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int prow = wave_m * WM + j * 16 + r16;
+                    fb[j] = *(const uint4*)(t2p + (ks >> 1) * (BM * 128) + prow * 128 + ((((ks & 1) * 4 + q) ^ (prow & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+                        acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i][ks]), __builtin_bit_cast(bf16x8_t, fb[j]),
+                                                                             acc2[i][j], 0, 0, 0);
+            }
+            if (c + 1 < nchunk) load_w(c + 1);
+            const int n2 = c * 128 + rc * 8;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                if (p == 0) load_res(c, 1, r1);
+                else if (c + 1 < nchunk) load_res(c + 1, 0, r0);
+                if (c || p) __syncthreads();          // the previous pass has been read back
+#pragma unroll
+                for (int jj = 0; jj < MTP; ++jj) {
+                    const int lrow = wave_m * WMP + jj * 16 + r16;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) *(f32x4*)(stg + lrow * ROWB + (wave_n * WN + i * 16 + q * 4) * 4) = acc2[i][p * MTP + jj];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int lrow = rr + it * RPI;
+                    const int m = m0 + (lrow / WMP) * WM + p * WMP + (lrow % WMP);
+                    if (lrow >= BMP || m >= a.M) continue;
+                    float v[8];
+                    *(float4*)&v[0] = *(const float4*)(stg + lrow * ROWB + rc * 32);
+                    *(float4*)&v[4] = *(const float4*)(stg + lrow * ROWB + rc * 32 + 16);
+                    if (a.res) {
+                        const u32x4 rv = p ? r1[it] : r0[it];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += __uint_as_float(rv[e] << 16);
+                            v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u);
+                        }
+                    }
+                    if (a.f_relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    const u32x4 ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                    char* yp = a.f_y + ((long long)m * a.f_cout + n2) * 2;
+                    if (a.nt_epi) __builtin_nontemporal_store(ov, (u32x4*)yp);
+                    else *(uint4*)yp = make_uint4(ov.x, ov.y, ov.z, ov.w);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         // residual rows of the pass (the second conv of a BasicBlock) go in flight before the LDS hand-off, like in the generic kernel
@@ -1345,7 +1467,7 @@ bool patch3x3_ok(const mt4_conv_desc* d, const ConvK& k, bool fast) {
            k.x_total_bytes + (long long)(2 * d->W + 1024) * k.pix_bytes < 0x7fffffffLL;
 }
 
-template <int BM, int BN, int WM_, int WN_, int WS>
+template <int BM, int BN, int WM_, int WN_, int WS, bool EXPAND = false>
 int launch_patch3x3(const ConvK& k, hipStream_t s) {
     ConvK kk = k;
     kk.n_tiles = cdiv(k.Cout, BN);
@@ -1353,7 +1475,7 @@ int launch_patch3x3(const ConvK& k, hipStream_t s) {
     kk.nt_epi = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
     {
         const long long min_mb = MT4_ENV_INT("MT4_NT_MIN_MB", 200);
-        if ((long long)k.M * k.Cout * 2 < min_mb * 1000000LL) kk.nt_epi = 0;
+        if ((long long)k.M * (EXPAND ? k.f_cout : k.Cout) * 2 < min_mb * 1000000LL) kk.nt_epi = 0;
     }
     constexpr int threads = WM_ * WN_ * 64;
     constexpr int rpp = threads / 8;
@@ -1362,9 +1484,10 @@ int launch_patch3x3(const ConvK& k, hipStream_t s) {
     constexpr int epi = BM / (BN >= 256 ? 4 : 2) * (BN * 4 + 16);
     int lds = npatch * pra * 128 + WS * BN * 128;
     if (lds < epi) lds = epi;
+    if (EXPAND && lds < 2 * BM * 128 + epi) lds = 2 * BM * 128 + epi;   // the bf16 tile (two 64-channel planes) + the staging of a pass
     if (WS == 9 && k.SPT != 1) return MT4_EUNSUPPORTED;
     if (lds > 160 * 1024 || (k.SPT > 1 && cdiv(pra, rpp) > 11 - WS)) return MT4_EUNSUPPORTED;   // (next-slice patch pieces ride along with taps 0..)
-    auto fn = conv3x3_patch_kernel<BM, BN, WM_, WN_, WS>;
+    auto fn = conv3x3_patch_kernel<BM, BN, WM_, WN_, WS, EXPAND>;
     if (lds > 65536) {
         MT4_RAISE_LDS(fn);
     }
@@ -1553,6 +1676,17 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     k.x_bytes = (unsigned)(xb < 0x7fffffffLL ? xb : 0);
     k.w_bytes = (unsigned)(wb < 0x7fffffffLL ? wb : 0);
     k.SPT = fast ? k.CPT / 8 : 1;
+    if (d->fuse_w && d->fuse_expand) {
+        // the Bottleneck's conv3 + bn3 + add + ReLU behind its 3x3 conv, in the patch kernel: only where that kernel runs (many tiles: the
+        // caller launches the two convs otherwise -- the results are bit-identical either way)
+        if (!d->fuse_y || !d->fuse_bias || d->fuse_cout <= 0 || (d->fuse_cout % 128) != 0) return MT4_EINVAL;
+        if (((uintptr_t)d->fuse_w | (uintptr_t)d->fuse_y | (uintptr_t)d->fuse_bias) & 15) return MT4_EALIGN;
+        if (!(patch3x3_ok(d, k, fast) && d->Cin == 128 && d->Cout == 128 && d->tile == 0 && !d->x2 &&
+              (long long)cdiv(k.M, 256) * cdiv(d->fuse_cout, 256) >= 256 && !MT4_ENV_SET("MT4_NO_EXPAND_FUSE")))
+            return MT4_EUNSUPPORTED;
+        k.f_w = (const char*)d->fuse_w; k.f_bias = d->fuse_bias; k.f_y = (char*)d->fuse_y; k.f_cout = d->fuse_cout; k.f_relu = d->fuse_relu ? 1 : 0;
+        return d->W <= 31 ? launch_patch3x3<128, 128, 2, 2, 2, true>(k, (hipStream_t)stream) : launch_patch3x3<256, 128, 4, 2, 2, true>(k, (hipStream_t)stream);
+    }
     if (d->fuse_w) {
         // the following 1x1 conv rides in this launch's epilogue: the whole channel width must sit in ONE 256-wide tile
         if (!d->fuse_y || d->fuse_cout <= 0 || (d->fuse_cout % 16) != 0 || d->fuse_cout > 256) return MT4_EINVAL;

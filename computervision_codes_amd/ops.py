@@ -167,9 +167,40 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
                  out_row_map.data_ptr() if out_row_map is not None else None,
                  b, h, w_, cin, ho, wo, cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1],
                  act_code, dt_code(x.dtype), dt_code(od), tile, out_row_map.numel() if out_row_map is not None else 0, y_ld, res_ld,
-                 out_rows_per_image, pix, f_cout, f_w, f_b, f_y, f_relu, res_f32, x2p, x2h, x2w, x2c, x2s)
+                 out_rows_per_image, pix, f_cout, f_w, f_b, f_y, f_relu, res_f32, x2p, x2h, x2w, x2c, x2s, 0)
     check(lib.mt4_conv_nhwc(C.byref(d), _stream()), "mt4_conv_nhwc")
     return out if fuse_next is None else (out, y2)
+
+
+def pack_fragments(w_packed: torch.Tensor) -> torch.Tensor:
+    """a packed bf16 matrix [rows, K] in MFMA fragment order (`mt4_pack_fragments_bf16`): what `conv3x3_expand` reads the expansion weights from"""
+    _need_cuda(w_packed)
+    assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous() and w_packed.dim() == 2
+    out = torch.empty_like(w_packed)
+    check(lib.mt4_pack_fragments_bf16(w_packed.data_ptr(), w_packed.shape[0], w_packed.shape[1], out.data_ptr(), _stream()), "mt4_pack_fragments_bf16")
+    return out
+
+
+def conv3x3_expand(x: torch.Tensor, w2_packed: torch.Tensor, b2: torch.Tensor, w3_frag: torch.Tensor, b3: torch.Tensor, residual: torch.Tensor,
+                   out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """conv2 (3x3, 128 -> 128, + bn2 + ReLU) and conv3 (1x1, + bn3 + residual + ReLU) of a stride-1 Bottleneck in one launch
+    (`mt4_conv_desc.fuse_expand`): the 128-channel map stays in LDS.  Returns None where the kernel does not run (few tiles): the caller launches
+    the two convs -- bit-identical results."""
+    _need_cuda(x, w2_packed, b2, w3_frag, b3, residual, out)
+    b, h, w_, cin = x.shape
+    cout3 = w3_frag.shape[0]
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and cin == 128 and tuple(w2_packed.shape) == (128, packed_k(128, 3, 3, torch.bfloat16))
+    assert w3_frag.dtype == torch.bfloat16 and w3_frag.shape[1] == 128 and residual.is_contiguous() and tuple(residual.shape) == (b, h, w_, cout3)
+    y = torch.empty((b, h, w_, cout3), dtype=torch.bfloat16, device=x.device) if out is None else out
+    assert y.is_contiguous() and tuple(y.shape) == (b, h, w_, cout3) and y.dtype == torch.bfloat16
+    d = ConvDesc(x.data_ptr(), w2_packed.data_ptr(), b2.data_ptr(), residual.data_ptr(), y.data_ptr(), None,
+                 b, h, w_, cin, h, w_, 128, 3, 3, 1, 1, 1, 1, 1, 1, 1, dt_code(x.dtype), dt_code(x.dtype), 0, 0, 0, 0, 0, 0, cout3,
+                 w3_frag.data_ptr(), b3.data_ptr(), y.data_ptr(), 1, 0, None, 0, 0, 0, 0, 1)
+    rc = lib.mt4_conv_nhwc(C.byref(d), _stream())
+    if rc == _lib.MT4_EUNSUPPORTED:
+        return None
+    check(rc, "mt4_conv_nhwc")
+    return y
 
 
 def tcn_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, taps: int, dilation: int = 1,

@@ -47,6 +47,7 @@ class VideoNas:
         self.fuse_next_conv = False
         import os
         self.fuse_stem_pool = not os.environ.get("MT4_NO_STEM_POOL_FUSE")   # stem conv + max-pool in one launch (bf16 uint8-frame path)
+        self.fuse_expand = not os.environ.get("MT4_NO_EXPAND_FUSE")   # layer2's stride-1 blocks: conv2 + conv3 in one launch (large batches)
         self.fuse_next_block = not os.environ.get("MT4_NO_NEXT_FUSE")   # layer2.0's conv1 behind the last layer1 block, in its launch
         self.fuse_downsample = not os.environ.get("MT4_NO_DS_FUSE")   # strided Bottlenecks: conv3 + downsample branch as one GEMM (bf16)
         self.fuse_bottleneck = not os.environ.get("MT4_NO_BNECK_FUSE")   # layer1 Bottlenecks in one launch each (bf16 ResNet-50)
@@ -128,6 +129,8 @@ class VideoNas:
                     p[q + "conv3ds"] = (torch.cat([w3, wd], 1).contiguous(), (b3 + bd).contiguous())
                     if li == 2:      # its conv1 rides behind the last layer1 block (ops.bottleneck_fused_next)
                         p[q + "conv1next"] = ops.bottleneck_pack_next(p[q + "conv1"])
+                if bottleneck and li == 2 and (q + "ds") not in p and self.dtype == torch.bfloat16:   # conv3 behind conv2 in one launch (ops.conv3x3_expand)
+                    p[q + "conv3frag"] = ops.pack_fragments(p[q + "conv3"][0])
         ws, bs, self._head_slices, o = [], [], {}, 0
         for task, k in _HEADS:
             if self.loss_type in (task, "all"):
@@ -192,6 +195,14 @@ class VideoNas:
                 if bottleneck:  # resnet.py:101-121 (stride on the 3x3)
                     o = pending if pending is not None else self._conv(x, q + "conv1", 1)
                     pending = None
+                    if (q + "conv3frag") in self._p and self.fuse_expand and not self.fuse_next_conv:
+                        # conv2 and conv3 (+ residual) of a layer2 identity block in one launch: the 128-channel map stays in LDS (bit-identical;
+                        # None where the patch kernel does not run -- small batches)
+                        (w2, b2), b3 = self._p[q + "conv2"], self._p[q + "conv3"][1]
+                        y = ops.conv3x3_expand(o, w2, b2, self._p[q + "conv3frag"], b3, idt, out=o_buf)
+                        if y is not None:
+                            x = y
+                            continue
                     o = self._conv(o, q + "conv2", 3, stride=s, pad=1)
                     # the next Bottleneck's conv1 (a 1x1 conv on this block's output at the same resolution) rides in this conv3's epilogue
                     # while the 256-channel tile is still in LDS: the map is written once (next residual) and not read back (bf16 only;
@@ -244,8 +255,9 @@ class VideoNas:
         return plan
 
     def launch_groups(self, h: int, w: int):
-        """indices into `conv_plan(h, w)` per kernel launch of one forward, in launch order: one conv per launch, except the layer1 Bottlenecks of
-        the bf16 ResNet-50, which run as one `mt4_bottleneck_fused_bf16` launch each"""
+        """indices into `conv_plan(h, w)` per kernel launch of one forward at bench batch sizes, in launch order: one conv per launch, except (bf16
+        ResNet-50) the layer1 Bottlenecks (one `mt4_bottleneck_fused_bf16` launch each, the last one carrying layer2.0's conv1), conv3 + downsample
+        of the strided blocks (one GEMM) and conv2 + conv3 of layer2's identity blocks (`mt4_conv_desc.fuse_expand`)"""
         plan = self.conv_plan(h, w)
         fused = self.network == "resnet50" and self.fuse_bottleneck and self.dtype == torch.bfloat16
         ds_fused = self.network == "resnet50" and self.fuse_downsample and self.dtype == torch.bfloat16
@@ -260,6 +272,11 @@ class VideoNas:
                     groups.append([i + 1])
                 groups += [[i + 2], [i + 3, i]]
                 i += 4
+                continue
+            if (ds_fused and self.fuse_expand and not self.fuse_next_conv and name.startswith("layer2.") and name.endswith(".conv2")
+                    and not name.startswith("layer2.0.")):      # conv2 + conv3 of layer2's identity blocks (ops.conv3x3_expand; large batches)
+                groups.append([i, i + 1])
+                i += 2
                 continue
             if fused and name.startswith("layer1."):
                 blk = name.split(".")[1]

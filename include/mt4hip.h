@@ -106,6 +106,12 @@ typedef struct mt4_conv_desc {
     const void* x2;             /* [B][x2_H][x2_W][x2_C] bf16 or NULL */
     int32_t x2_H, x2_W, x2_C;
     int32_t x2_stride;          /* s */
+    int32_t fuse_expand;        /* 1 with fuse_w on a 3x3 / stride 1 / pad 1 bf16 launch with Cin == Cout == 128 (layer2's conv2): the fused following
+                                   conv is the Bottleneck's conv3 + bn3 + add + ReLU (resnet.py:112-119).  This launch's own output stays in LDS
+                                   (y is not written), `residual` ([B][H][W][fuse_cout], the block input) is added to y2 = fuse_y before fuse_relu,
+                                   fuse_cout is a multiple of 128 and fuse_w is in fragment order (mt4_pack_fragments_bf16 of the packed
+                                   [fuse_cout][128] matrix).  Runs where the 3x3 patch kernel runs (>= 256 tiles of 256 x 256): MT4_EUNSUPPORTED
+                                   otherwise -- launch the two convs then; the results are bit-identical either way.  0 = fuse_w as described above */
 } mt4_conv_desc;
 
 int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream);
@@ -127,6 +133,20 @@ int64_t mt4_bottleneck_packed_bytes(int32_t Cin, int32_t has_downsample);
 int mt4_bottleneck_pack_bf16(const void* w1, const void* w2, const void* w3, const void* wds, int32_t Cin, void* out, void* stream);
 int mt4_bottleneck_fused_bf16(const void* x, void* y, const void* w_frag, const float* b1, const float* b2, const float* b3, const float* bds,
                               int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t mid, void* stream);
+/* The same launch for an identity block (Cin == 256) that is FOLLOWED by a strided Bottleneck (layer1.2 -> layer2.0): also runs that block's
+ * conv1 + bn1 + ReLU (256 -> 128 channels; resnet.py:101-103 of the next block) on the result while the tile is in LDS.
+ *   w_next: the next conv1's packed bf16 matrix [128][256] in fragment order (mt4_bottleneck_pack_next_bf16, mt4_bottleneck_next_packed_bytes),
+ *   b_next [128] float32.  t_next [B][H][W][128] bf16 = relu(w_next . y + b_next).
+ *   y_even [B][(H+1)/2][(W+1)/2][256] bf16 = the block's output y at the even pixels: all the stride-2 downsample branch (its one other
+ *   reader) takes -- pass it as mt4_conv_desc.x2 with x2_stride 1.
+ * Both outputs are bit-identical to mt4_bottleneck_fused_bf16 followed by mt4_conv_nhwc. */
+int64_t mt4_bottleneck_next_packed_bytes(void);
+int mt4_bottleneck_pack_next_bf16(const void* w1_next, void* out, void* stream);
+int mt4_bottleneck_fused_next_bf16(const void* x, void* y_even, void* t_next, const void* w_frag, const float* b1, const float* b2, const float* b3,
+                                   const void* w_next, const float* b_next, int32_t B, int32_t H, int32_t W, void* stream);
+/* a packed bf16 matrix [rows][row_elems] in MFMA fragment order: [rows / 16][row_elems / 32][lane (r16, q)] x 16 bytes =
+ * w[tile * 16 + r16][step * 32 + 8 q .. + 8), so that a wave's load of one fragment is 1 KB contiguous (rows % 16 == 0, row_elems % 32 == 0) */
+int mt4_pack_fragments_bf16(const void* w_packed, int32_t rows, int32_t row_elems, void* out, void* stream);
 /* elements per packed weight row for a given geometry (Kpad above) */
 int64_t mt4_conv_packed_k(int32_t Cin, int32_t KH, int32_t KW, int32_t dtype);
 

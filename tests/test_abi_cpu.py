@@ -26,7 +26,7 @@ def test_header_symbols_all_exported_and_bound():
 
 def test_abi_version_and_error_strings():
     from computervision_codes_amd import _lib
-    assert _lib.lib.mt4_abi_version() == 5
+    assert _lib.lib.mt4_abi_version() == 6
     assert _lib.lib.mt4_strerror(0) == b"ok"
     assert b"invalid" in _lib.lib.mt4_strerror(-1)
 
@@ -54,7 +54,8 @@ def test_ops_refuse_cpu_tensors():
 def test_struct_layout_matches_header():
     from computervision_codes_amd import _lib
     # 6 pointers + 24 int32 + fuse_cout + the three fuse pointers (8-byte aligned: 25 int32 pad to 104 bytes) + fuse_relu + residual_float
-    assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 26 * 4 + 3 * 8 + 2 * 4
+    # + the second K source: x2 and its four int32, + fuse_expand (padded to 8 bytes)
+    assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 26 * 4 + 3 * 8 + 2 * 4 + 8 + 4 * 4 + 8
     assert _lib.ConvDesc.fuse_w.offset == 6 * 8 + 26 * 4 and _lib.ConvDesc.fuse_relu.offset == 6 * 8 + 26 * 4 + 24
 
 
@@ -66,7 +67,7 @@ def test_integration_doc_struct_matches_header_mirror():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     block = doc[doc.index("class ConvDesc"):doc.index("lib.mt4_conv_nhwc.argtypes")]
-    assert re.findall(r'"([A-Za-z_]+)"', block) == [f[0] for f in _lib.ConvDesc._fields_]
+    assert re.findall(r'"([A-Za-z_][A-Za-z_0-9]*)"', block) == [f[0] for f in _lib.ConvDesc._fields_]
     hdr = open(os.path.join(root, "include", "mt4hip.h")).read()
     struct = hdr[hdr.index("typedef struct mt4_conv_desc {") + len("typedef struct mt4_conv_desc {"):hdr.index("} mt4_conv_desc;")]
     struct = re.sub(r"/\*.*?\*/", "", struct, flags=re.S)

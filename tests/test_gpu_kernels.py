@@ -361,3 +361,24 @@ def test_bottleneck_fused_next_bit_identical(cuda, b, h, w):
     assert float(ref_t.float().abs().max()) > 0.5
     assert torch.equal(y_even.view(torch.int16), ref_y[:, ::2, ::2].contiguous().view(torch.int16))
     assert torch.equal(t.view(torch.int16), ref_t.view(torch.int16)), float((t.float() - ref_t.float()).abs().max())
+
+
+@pytest.mark.parametrize("b,h,w", [(700, 28, 28), (300, 27, 29), (160, 32, 56)])
+def test_conv3x3_expand_bit_identical_to_two_launches(cuda, b, h, w):
+    """`mt4_conv_desc.fuse_expand`: conv2 + bn2 + ReLU and conv3 + bn3 + add + ReLU of a layer2 identity Bottleneck in one launch (the 128-channel map
+    stays in LDS) == the two launches, bit for bit: both patch tiles (rows of <= 31 and of > 31 pixels), ragged last tile"""
+    from computervision_codes_amd import ops
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(9 + h)
+    t1 = torch.randn((b, h, w, 128), generator=g).to(cuda).to(bf)
+    res = torch.randn((b, h, w, 512), generator=g).to(cuda).to(bf)
+    w2 = ops.pack_conv_weight((torch.randn((128, 128, 3, 3), generator=g) / 34).to(cuda), None, bf)
+    w3 = ops.pack_conv_weight((torch.randn((512, 128, 1, 1), generator=g) / 11).to(cuda), None, bf)
+    b2, b3 = (torch.randn(128, generator=g) * 0.3).to(cuda), (torch.randn(512, generator=g) * 0.3).to(cuda)
+    t2 = ops.conv_nhwc(t1, w2, b2, kh=3, kw=3, pad=(1, 1), relu=True)
+    ref = ops.conv_nhwc(t2, w3, b3, kh=1, kw=1, residual=res, relu=True)
+    y = ops.conv3x3_expand(t1, w2, b2, ops.pack_fragments(w3), b3, res)
+    assert y is not None and float(ref.float().abs().max()) > 0.5
+    assert torch.equal(y.view(torch.int16), ref.view(torch.int16)), float((y.float() - ref.float()).abs().max())
+    small = ops.conv3x3_expand(t1[:2].contiguous(), w2, b2, ops.pack_fragments(w3), b3, res[:2].contiguous())
+    assert small is None          # few tiles: the caller runs the two launches

@@ -33,7 +33,7 @@ rm -f $O/prof_q2l_train/*kernel_trace.csv
 echo q2l done
 cd $R
 cp profiles/traffic.json gpurun_out/traffic.json; cp profiles/mfma_util.json gpurun_out/mfma_util.json
-python tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 43 resnet50_bf16_b1336_224x224 gpurun_out/traffic.json
-python tools/collect_mfma_util.py gpurun_out/pmc_mfma 43 resnet50_bf16_b1336_224x224 gpurun_out/mfma_util.json
+python tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 40 resnet50_bf16_b1336_224x224 gpurun_out/traffic.json
+python tools/collect_mfma_util.py gpurun_out/pmc_mfma 40 resnet50_bf16_b1336_224x224 gpurun_out/mfma_util.json
 python tools/collect_tcn_traffic.py gpurun_out/pmc_tenco_FETCH_SIZE gpurun_out/pmc_tenco_WRITE_SIZE tenco4_f32_T256 gpurun_out/traffic.json
 echo all done
