@@ -1180,12 +1180,17 @@ struct StemPoolK {
     unsigned x_bytes, w_bytes;
     int w_row_bytes, Cout, KH;
     int Hs, Ws, Ho, Wo, Hp, Wp;
-    int tiles_per_img;      // pairs of pooled rows
+    int tiles_per_img;      // pairs of pooled rows x column segments
     int pra;                // staged pixels (multiple of 32)
+    // column segments (frames wider than 224 pixels: conv rows of more than 112 pixels): a workgroup computes `cw` conv columns from
+    // cs0 = max(2 Q0 - 1, 0) for the wp_seg pooled columns from Q0 = seg * wp_seg; its span is staged as 8 rows of `rs` pixels.
+    // One segment: cw = Wo, rs = Ws (the span is one linear range of the frame)
+    int segs, cw, rs, wp_seg;
 };
 
+template <int MT>
 __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
-    constexpr int MT = 9, NT = 2, BN = 64, NTH = 512, PPP = NTH * 16 / 32;
+    constexpr int NT = 2, BN = 64, NTH = 512, PPP = NTH * 16 / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1199,9 +1204,13 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
     }
     const int img = bid / a.tiles_per_img;
-    const int P0 = (bid - img * a.tiles_per_img) * 2;
+    const int trem = bid - img * a.tiles_per_img;
+    const int rp = trem / a.segs;
+    const int Q0 = (trem - rp * a.segs) * a.wp_seg;     // first pooled column of the segment
+    const int cs0 = max(2 * Q0 - 1, 0);                 // first conv column computed
+    const int P0 = rp * 2;
     const int c0 = 2 * P0 - 1;                     // first conv row of the tile (-1 for the top tile: computed from zeros / the frame above, never pooled)
-    const int tpr = a.Wo >> 4;                     // 16-pixel tiles per conv row
+    const int tpr = a.cw >> 4;                     // 16-pixel tiles per conv row (segment)
     const int ntile = 5 * tpr;
 
     f32x4 acc[NT][MT];
@@ -1213,14 +1222,14 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = b4;
     }
-    const int p0 = __builtin_amdgcn_readfirstlane((img * a.Hs + c0) * a.Ws);   // frame pixel of LDS pixel 0
+    const int p0 = __builtin_amdgcn_readfirstlane((img * a.Hs + c0) * a.Ws + cs0);   // frame pixel of LDS pixel 0
     int base[MT];                                  // wave-uniform part of the LDS pixel of tile j (scalar registers); + lane_px per lane
     const int lane_px = r16 + (q >> 1);
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int t = min(wave_m + 4 * j, ntile - 1);
         const int row = t / tpr;
-        base[j] = __builtin_amdgcn_readfirstlane(row * a.Ws + (t - row * tpr) * 16);
+        base[j] = __builtin_amdgcn_readfirstlane(row * a.rs + (t - row * tpr) * 16);
     }
     const v4u rsx = make_srd(a.x, a.x_bytes);
     const v4u rsw = make_srd(a.w, a.w_bytes);
@@ -1235,7 +1244,12 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
                 const int t = piece * PPP + (tid >> 1);
                 const int h = (tid & 1) ^ ((t >> 3) & 1);
                 // (pixels in front of the buffer -- the top tile of frame 0 -- wrap to offsets beyond it: range-checked, zeros)
-                const unsigned v[1] = {(unsigned)((p0 + t) * 32 + h * 16)};
+                unsigned v[1] = {(unsigned)((p0 + t) * 32 + h * 16)};
+                if (a.segs > 1) {                  // LDS pixel t = (span row t / rs, column t % rs) of the segment
+                    const int row = t / a.rs;
+                    const int col = t - row * a.rs;
+                    v[0] = cs0 + col < a.Ws ? (unsigned)((p0 + row * a.Ws + col) * 32 + h * 16) : OOB;
+                }
                 lds_dma16_group<1, 0>(rsx, v, 0u, lds_base + piece * (PPP * 32) + wave_u * 1024);
             }
         }
@@ -1258,19 +1272,20 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
             uint4 fw[NT];
 #pragma unroll
             for (int i = 0; i < NT; ++i) fw[i] = *(const uint4*)(wb + rd_w + i * 16 * 128 + sww);
+            constexpr int FB = MT > 9 ? 3 : 5;            // pixel fragments in flight (all of them: over the 128-register budget)
 #pragma unroll
-            for (int j0 = 0; j0 < MT; j0 += 5) {          // two batches of pixel fragments (all nine in flight: over the 128-register budget)
-                uint4 fx[5];
+            for (int j0 = 0; j0 < MT; j0 += FB) {
+                uint4 fx[FB];
 #pragma unroll
-                for (int j = j0; j < MT && j < j0 + 5; ++j) {
-                    const int pix = lane_px + (base[j] + kh * a.Ws + kk * 2);
+                for (int j = j0; j < MT && j < j0 + FB; ++j) {
+                    const int pix = lane_px + (base[j] + kh * a.rs + kk * 2);
                     fx[j - j0] = *(const uint4*)(smem + pix * 32 + (((q & 1) ^ ((pix >> 3) & 1)) << 4));
                 }
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
-                    for (int j = j0; j < MT && j < j0 + 5; ++j)
+                    for (int j = j0; j < MT && j < j0 + FB; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[i]), __builtin_bit_cast(bf16x8_t, fx[j - j0]),
                                                                             acc[i][j], 0, 0, 0);
             }
@@ -1278,7 +1293,7 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
     }
     __syncthreads();   // the conv rows go over the operands
 
-    // conv tile: pixel (row, col) at (row * Wo + col) * 128 B, 16-byte chunks XOR-swizzled with col & 7
+    // conv tile: pixel (row, column - cs0) at (row * cw + col) * 128 B, 16-byte chunks XOR-swizzled with col & 7
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int t = wave_m + 4 * j;
@@ -1290,20 +1305,20 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
                 const int cb = (wave_n * 32 + i * 16 + q * 4) * 2;
                 uint2 o = make_uint2(pack_bf16x2(fmaxf(acc[i][j][0], 0.f), fmaxf(acc[i][j][1], 0.f)),
                                      pack_bf16x2(fmaxf(acc[i][j][2], 0.f), fmaxf(acc[i][j][3], 0.f)));
-                *(uint2*)(smem + (row * a.Wo + col) * 128 + (((cb >> 4) ^ (col & 7)) << 4) + (cb & 8)) = o;
+                *(uint2*)(smem + (row * a.cw + col) * 128 + (((cb >> 4) ^ (col & 7)) << 4) + (cb & 8)) = o;
             }
         }
     }
     __syncthreads();
 
-    const int nvec = 2 * a.Wp * 8;
+    const int nvec = 2 * a.wp_seg * 8;
     for (int v = tid; v < nvec; v += NTH) {
         const int c8 = v & 7;
         const int pp = v >> 3;
-        const int pr = pp >= a.Wp ? 1 : 0;
-        const int pc = pp - pr * a.Wp;
+        const int pr = pp >= a.wp_seg ? 1 : 0;
+        const int pc = Q0 + pp - pr * a.wp_seg;
         const int P = P0 + pr;
-        if (P >= a.Hp || c8 * 8 >= a.Cout) continue;
+        if (P >= a.Hp || pc >= a.Wp || c8 * 8 >= a.Cout) continue;
         uint4 best = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
@@ -1313,7 +1328,8 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
             for (int kw = 0; kw < 3; ++kw) {
                 const int cc = 2 * pc - 1 + kw;
                 if ((unsigned)cc >= (unsigned)a.Wo) continue;
-                const uint4 t = *(const uint4*)(smem + (jr * a.Wo + cc) * 128 + ((c8 ^ (cc & 7)) << 4));
+                const int cr = cc - cs0;              // column inside the segment
+                const uint4 t = *(const uint4*)(smem + (jr * a.cw + cr) * 128 + ((c8 ^ (cr & 7)) << 4));
                 asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.x) : "v"(t.x));
                 asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.y) : "v"(t.y));
                 asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.z) : "v"(t.z));
@@ -1817,15 +1833,16 @@ extern "C" int mt4_pack_conv_weight(const float* w_oihw, const float* scale, voi
 
 // relu(stem conv on the space-to-depth frame) -> 3x3 / 2 max-pool, pad 1, one launch (stem_pool_kernel).  x_s2d [B][Hs][Ws][16] bf16
 // (mt4_preprocess_u8_s2d), w_packed [Cout][KH * 64] bf16 (the 4 x 1 kernel over runs of 4 pixels), y [B][Hp][Wp][Cout] bf16 with
-// Ho = Hs - KH + 1, Wo = Ws - 3, Hp = (Ho - 1) / 2 + 1, Wp = (Wo - 1) / 2 + 1.  Conv rows of up to 112 pixels in whole 16-pixel tiles
-// (224 x 224 frames); wider frames: MT4_EUNSUPPORTED (the caller runs mt4_conv_nhwc + mt4_maxpool3x3s2_nhwc).
+// Ho = Hs - KH + 1, Wo = Ws - 3, Hp = (Ho - 1) / 2 + 1, Wp = (Wo - 1) / 2 + 1.  Conv rows in whole 16-pixel tiles, up to 112 pixels (224-pixel
+// frames) as one tile per pair of pooled rows, up to 224 (448-pixel frames) as two column segments; wider: MT4_EUNSUPPORTED (the caller runs
+// mt4_conv_nhwc + mt4_maxpool3x3s2_nhwc).
 extern "C" int mt4_stem_maxpool_bf16(const void* x_s2d, const void* w_packed, const float* bias, void* y, int32_t B, int32_t Hs, int32_t Ws,
                                      int32_t Cout, int32_t KH, void* stream) {
     mt4_clear_error();
     if (!x_s2d || !w_packed || !y || B <= 0 || Hs <= 0 || Ws <= 3 || KH <= 0 || KH > Hs) return MT4_EINVAL;
     if (((uintptr_t)x_s2d | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)bias) & 15) return MT4_EALIGN;
     const int Ho = Hs - KH + 1, Wo = Ws - 3;
-    if (KH > 8 || Cout != 64 || (Wo & 15) || Wo > 112) return MT4_EUNSUPPORTED;
+    if (KH > 8 || Cout != 64 || (Wo & 15) || Wo > 224) return MT4_EUNSUPPORTED;
     const long long xb = (long long)B * Hs * Ws * 32;
     if (xb >= 0x70000000LL) return MT4_EUNSUPPORTED;
     StemPoolK k{};
@@ -1835,15 +1852,26 @@ extern "C" int mt4_stem_maxpool_bf16(const void* x_s2d, const void* w_packed, co
     k.w_bytes = (unsigned)(Cout * k.w_row_bytes);
     k.Cout = Cout; k.KH = KH; k.Hs = Hs; k.Ws = Ws; k.Ho = Ho; k.Wo = Wo;
     k.Hp = (Ho - 1) / 2 + 1; k.Wp = (Wo - 1) / 2 + 1;
-    k.tiles_per_img = cdiv(k.Hp, 2);
-    k.pra = ((4 + KH) * Ws + 31) / 32 * 32;      // five conv rows: 4 + KH frame rows
+    const bool wide = Wo > 112;       // two column segments of 128 conv columns (the second starts at 2 Q0 - 1), each for half the pooled columns
+    k.segs = wide ? 2 : 1;
+    k.cw = wide ? 128 : Wo;
+    k.rs = wide ? 132 : Ws;           // 128 + 3 pixels of kernel footprint, padded
+    k.wp_seg = wide ? cdiv(k.Wp, 2) : k.Wp;
+    k.tiles_per_img = cdiv(k.Hp, 2) * k.segs;
+    k.pra = ((4 + KH) * k.rs + 31) / 32 * 32;      // five conv rows: 4 + KH frame rows
     int lds = k.pra * 32 + KH * 64 * 128;
-    if (lds < 5 * Wo * 128) lds = 5 * Wo * 128;
+    if (lds < 5 * k.cw * 128) lds = 5 * k.cw * 128;
     if (lds > 80 * 1024) return MT4_EUNSUPPORTED;
     if ((long long)B * k.tiles_per_img > 0x7fffffffLL) return MT4_EUNSUPPORTED;
-    auto fn = stem_pool_kernel;
-    if (lds > 65536) MT4_RAISE_LDS(fn);
-    hipLaunchKernelGGL(fn, dim3((unsigned)(B * k.tiles_per_img)), dim3(512), lds, (hipStream_t)stream, k);
+    if (wide) {
+        auto fn = stem_pool_kernel<10>;
+        MT4_RAISE_LDS(fn);
+        hipLaunchKernelGGL(fn, dim3((unsigned)(B * k.tiles_per_img)), dim3(512), lds, (hipStream_t)stream, k);
+    } else {
+        auto fn = stem_pool_kernel<9>;
+        if (lds > 65536) MT4_RAISE_LDS(fn);
+        hipLaunchKernelGGL(fn, dim3((unsigned)(B * k.tiles_per_img)), dim3(512), lds, (hipStream_t)stream, k);
+    }
     return mt4_check_launch();
 }
 

@@ -411,8 +411,8 @@ def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
 
 
 def stem_maxpool_supported(h: int, w: int) -> bool:
-    """frame sizes `stem_maxpool` takes: even, conv rows (w / 2 pixels) in whole 16-pixel tiles of at most 112"""
-    return h % 2 == 0 and w % 32 == 0 and w // 2 <= 112
+    """frame sizes `stem_maxpool` takes: even, conv rows (w / 2 pixels) in whole 16-pixel tiles of at most 224 (frames up to 448 wide)"""
+    return h % 2 == 0 and w % 32 == 0 and w // 2 <= 224
 
 
 def stem_maxpool(xs: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:

@@ -189,7 +189,8 @@ int mt4_maxpool3x3s2_nhwc(const void* x, void* y, int32_t B, int32_t H, int32_t 
  * bf16 (mt4_preprocess_u8_s2d), w_packed [Cout = 64][KH * 64] bf16 (the KH x 1 kernel over runs of 4 pixels, BatchNorm scale folded in;
  * mt4_pack_conv_weight), bias float32 -> y [B][Hp][Wp][64] bf16, Ho = Hs - KH + 1, Wo = Ws - 3, Hp = (Ho - 1) / 2 + 1, Wp = (Wo - 1) / 2 + 1.
  * Bit-identical to mt4_conv_nhwc (relu) followed by mt4_maxpool3x3s2_nhwc; the Ho x Wo x 64 map never reaches memory.  Wo a multiple of
- * 16 and <= 112 (224 x 224 frames); otherwise MT4_EUNSUPPORTED and the caller runs the two launches. */
+ * 16 and <= 224 (frames up to 448 pixels wide: 224 x 224 and the reference's 256 x 448); otherwise MT4_EUNSUPPORTED and the caller runs
+ * the two launches. */
 int mt4_stem_maxpool_bf16(const void* x_s2d, const void* w_packed, const float* bias, void* y, int32_t B, int32_t Hs, int32_t Ws,
                           int32_t Cout, int32_t KH, void* stream);
 /* AdaptiveAvgPool2d(1) channels-last -> float32 [B][C] (resnet.py:157; the hooked `final_feature`). */

@@ -296,10 +296,11 @@ def test_bottleneck_fused_bit_identical_to_three_launches(cuda, b, h, w, ds):
     assert torch.equal(y.view(torch.int16), ref.view(torch.int16)), float((y.float() - ref.float()).abs().max())
 
 
-@pytest.mark.parametrize("b,h,w", [(3, 224, 224), (2, 68, 64), (1, 8, 32), (5, 30, 96)])
+@pytest.mark.parametrize("b,h,w", [(3, 224, 224), (2, 68, 64), (1, 8, 32), (5, 30, 96), (3, 256, 448), (2, 34, 256), (1, 6, 320)])
 def test_stem_maxpool_fused_bit_identical_to_two_launches(cuda, b, h, w):
     """`mt4_stem_maxpool_bf16` (conv1 / bn1 / relu / maxpool of `resnet.py:145-149` in one launch on the space-to-depth frame) == the stem through
-    `mt4_conv_nhwc` followed by `mt4_maxpool3x3s2_nhwc`, bit for bit: full frames, an odd number of pooled rows, frames smaller than a tile"""
+    `mt4_conv_nhwc` followed by `mt4_maxpool3x3s2_nhwc`, bit for bit: full frames, an odd number of pooled rows, frames smaller than a tile, and the
+    two-column-segment form of frames wider than 224 pixels (the reference's 256 x 448)"""
     from computervision_codes_amd import ops
     from computervision_codes_amd.spatial_cnn import IMAGENET_MEAN, IMAGENET_STD
     g = torch.Generator().manual_seed(11 + h)
