@@ -1186,11 +1186,16 @@ struct StemPoolK {
     // cs0 = max(2 Q0 - 1, 0) for the wp_seg pooled columns from Q0 = seg * wp_seg; its span is staged as 8 rows of `rs` pixels.
     // One segment: cw = Wo, rs = Ws (the span is one linear range of the frame)
     int segs, cw, rs, wp_seg;
+    int ctw;                // conv columns of a segment kept for the pooling (row pitch of the conv tile in LDS): min(cw, 2 wp_seg + 8)
 };
 
-template <int MT>
+template <int MT, int NPASS>
 __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
     constexpr int NT = 2, BN = 64, NTH = 512, PPP = NTH * 16 / 32;
+    constexpr int MTP = (MT + NPASS - 1) / NPASS;      // pixel tiles per pass over K.  Two passes (the finished half waits as packed bf16): with all
+                                                       // 72 / 80 accumulator registers live the fragments do not fit the 128-register budget of
+                                                       // 4 waves per SIMD -- 24 spilled registers per lane and K-step cost the wide form 40 % (1.78 ->
+                                                       // 1.26 ms per 584 frames of 256 x 448), far more than a second walk over the LDS operands
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1213,14 +1218,12 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
     const int tpr = a.cw >> 4;                     // 16-pixel tiles per conv row (segment)
     const int ntile = 5 * tpr;
 
-    f32x4 acc[NT][MT];
+    f32x4 bias4v[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int n = wave_n * 32 + i * 16 + q * 4;
-        f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (a.bias && n < a.Cout) { const float4 t = *(const float4*)(a.bias + n); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
-#pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = b4;
+        bias4v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (a.bias && n < a.Cout) { const float4 t = *(const float4*)(a.bias + n); bias4v[i] = (f32x4){t.x, t.y, t.z, t.w}; }
     }
     const int p0 = __builtin_amdgcn_readfirstlane((img * a.Hs + c0) * a.Ws + cs0);   // frame pixel of LDS pixel 0
     int base[MT];                                  // wave-uniform part of the LDS pixel of tile j (scalar registers); + lane_px per lane
@@ -1263,37 +1266,54 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
     __syncthreads();
 
     const int rd_w = (wave_n * 32 + r16) * 128;
+    uint2 res[NT][MT];                              // the conv rows: ReLU, bf16 (what the stand-alone launch stores)
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        f32x4 acc[NT][MTP];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int jj = 0; jj < MTP; ++jj) acc[i][jj] = bias4v[i];
 #pragma unroll 1
-    for (int kh = 0; kh < a.KH; ++kh) {
-        const char* wb = smem + patch_bytes + kh * (BN * 128);
+        for (int kh = 0; kh < a.KH; ++kh) {
+            const char* wb = smem + patch_bytes + kh * (BN * 128);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int sww = ((kk * 4 + q) ^ (r16 & 7)) << 4;
-            uint4 fw[NT];
+            for (int kk = 0; kk < 2; ++kk) {
+                const int sww = ((kk * 4 + q) ^ (r16 & 7)) << 4;
+                uint4 fw[NT];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) fw[i] = *(const uint4*)(wb + rd_w + i * 16 * 128 + sww);
-            constexpr int FB = MT > 9 ? 3 : 5;            // pixel fragments in flight (all of them: over the 128-register budget)
+                for (int i = 0; i < NT; ++i) fw[i] = *(const uint4*)(wb + rd_w + i * 16 * 128 + sww);
 #pragma unroll
-            for (int j0 = 0; j0 < MT; j0 += FB) {
-                uint4 fx[FB];
+                for (int j0 = 0; j0 < MTP; j0 += 5) {     // batches of pixel fragments (all of them in flight: over the register budget)
+                    uint4 fx[5];
 #pragma unroll
-                for (int j = j0; j < MT && j < j0 + FB; ++j) {
-                    const int pix = lane_px + (base[j] + kh * a.rs + kk * 2);
-                    fx[j - j0] = *(const uint4*)(smem + pix * 32 + (((q & 1) ^ ((pix >> 3) & 1)) << 4));
+                    for (int jj = j0; jj < MTP && jj < j0 + 5; ++jj) {
+                        const int j = ps * MTP + jj < MT ? ps * MTP + jj : MT - 1;
+                        const int pix = lane_px + (base[j] + kh * a.rs + kk * 2);
+                        fx[jj - j0] = *(const uint4*)(smem + pix * 32 + (((q & 1) ^ ((pix >> 3) & 1)) << 4));
+                    }
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int jj = j0; jj < MTP && jj < j0 + 5; ++jj)
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[i]), __builtin_bit_cast(bf16x8_t, fx[jj - j0]),
+                                                                                 acc[i][jj], 0, 0, 0);
                 }
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int i = 0; i < NT; ++i)
-#pragma unroll
-                    for (int j = j0; j < MT && j < j0 + FB; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[i]), __builtin_bit_cast(bf16x8_t, fx[j - j0]),
-                                                                            acc[i][j], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int jj = 0; jj < MTP; ++jj)
+                if (ps * MTP + jj < MT)
+                    res[i][ps * MTP + jj] = make_uint2(pack_bf16x2(fmaxf(acc[i][jj][0], 0.f), fmaxf(acc[i][jj][1], 0.f)),
+                                                       pack_bf16x2(fmaxf(acc[i][jj][2], 0.f), fmaxf(acc[i][jj][3], 0.f)));
     }
     __syncthreads();   // the conv rows go over the operands
 
-    // conv tile: pixel (row, column - cs0) at (row * cw + col) * 128 B, 16-byte chunks XOR-swizzled with col & 7
+    // conv tile: pixel (row, column - cs0) at (row * ctw + col) * 128 B, 16-byte chunks XOR-swizzled with col & 7 (columns the pooling does not
+    // read are dropped: the wide form stays under 80 KB = two workgroups per CU)
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int t = wave_m + 4 * j;
@@ -1303,9 +1323,7 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int cb = (wave_n * 32 + i * 16 + q * 4) * 2;
-                uint2 o = make_uint2(pack_bf16x2(fmaxf(acc[i][j][0], 0.f), fmaxf(acc[i][j][1], 0.f)),
-                                     pack_bf16x2(fmaxf(acc[i][j][2], 0.f), fmaxf(acc[i][j][3], 0.f)));
-                *(uint2*)(smem + (row * a.cw + col) * 128 + (((cb >> 4) ^ (col & 7)) << 4) + (cb & 8)) = o;
+                if (col < a.ctw) *(uint2*)(smem + (row * a.ctw + col) * 128 + (((cb >> 4) ^ (col & 7)) << 4) + (cb & 8)) = res[i][j];
             }
         }
     }
@@ -1329,7 +1347,7 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
                 const int cc = 2 * pc - 1 + kw;
                 if ((unsigned)cc >= (unsigned)a.Wo) continue;
                 const int cr = cc - cs0;              // column inside the segment
-                const uint4 t = *(const uint4*)(smem + (jr * a.cw + cr) * 128 + ((c8 ^ (cr & 7)) << 4));
+                const uint4 t = *(const uint4*)(smem + (jr * a.ctw + cr) * 128 + ((c8 ^ (cr & 7)) << 4));
                 asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.x) : "v"(t.x));
                 asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.y) : "v"(t.y));
                 asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.z) : "v"(t.z));
@@ -1857,18 +1875,19 @@ extern "C" int mt4_stem_maxpool_bf16(const void* x_s2d, const void* w_packed, co
     k.cw = wide ? 128 : Wo;
     k.rs = wide ? 132 : Ws;           // 128 + 3 pixels of kernel footprint, padded
     k.wp_seg = wide ? cdiv(k.Wp, 2) : k.Wp;
+    k.ctw = k.cw < 2 * k.wp_seg + 8 ? k.cw : 2 * k.wp_seg + 8;
     k.tiles_per_img = cdiv(k.Hp, 2) * k.segs;
     k.pra = ((4 + KH) * k.rs + 31) / 32 * 32;      // five conv rows: 4 + KH frame rows
     int lds = k.pra * 32 + KH * 64 * 128;
-    if (lds < 5 * k.cw * 128) lds = 5 * k.cw * 128;
+    if (lds < 5 * k.ctw * 128) lds = 5 * k.ctw * 128;
     if (lds > 80 * 1024) return MT4_EUNSUPPORTED;
     if ((long long)B * k.tiles_per_img > 0x7fffffffLL) return MT4_EUNSUPPORTED;
     if (wide) {
-        auto fn = stem_pool_kernel<10>;
+        auto fn = stem_pool_kernel<10, 2>;
         MT4_RAISE_LDS(fn);
         hipLaunchKernelGGL(fn, dim3((unsigned)(B * k.tiles_per_img)), dim3(512), lds, (hipStream_t)stream, k);
     } else {
-        auto fn = stem_pool_kernel<9>;
+        auto fn = stem_pool_kernel<9, 2>;      // (two passes also here: 1.17 -> 1.10 ms per 1336 frames of 224 x 224, same box)
         if (lds > 65536) MT4_RAISE_LDS(fn);
         hipLaunchKernelGGL(fn, dim3((unsigned)(B * k.tiles_per_img)), dim3(512), lds, (hipStream_t)stream, k);
     }
