@@ -818,8 +818,11 @@ extern "C" int mt4_kd_mix(const float* s, const float* tea_i, const float* tea_v
 // for e >= 4; the V^T fragment is read in the same order), so P never touches LDS.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-template <int NT>  // key/query tiles of 16
-__global__ __launch_bounds__(256) void window_attention_mfma_kernel(const u16* __restrict__ q, const u16* __restrict__ k,
+template <int NT, int NW = 4>  // key/query tiles of 16; waves per workgroup
+// (at 8 - 9 tiles -- Swin's 12 x 12 windows -- the kernel is held to 168 registers = three waves per SIMD: 10 spilled registers, +3 % unmasked and
+//  +11 % on shifted blocks, same-box; four waves per SIMD spill 50 and lose 60 %.  9 tiles run in workgroups of THREE waves: over 4 waves
+//  three of them idle for a third of the loop -- 0.207 -> 0.167 ms on stage 3 of Swin-B/384 at batch 128, 0.451 -> 0.335 on a shifted block)
+__global__ __launch_bounds__(NW * 64, (NT >= 8 && NT <= 9) ? 3 : 1) void window_attention_mfma_kernel(const u16* __restrict__ q, const u16* __restrict__ k,
                                                                     const u16* __restrict__ v, u16* __restrict__ out,
                                                                     const float* __restrict__ bias, const float* __restrict__ mask, int N,
                                                                     int q_stride, int k_stride, int v_stride, int o_stride, int nW,
@@ -842,10 +845,11 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const u16* _
     float* Tb = (float*)(smem + 2 * NP * QK_PITCH + VT_BYTES);   // rel mode: [2T] table + -1e30 pad area, then key index, region id per token
     const int b = blockIdx.y, h = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int nth = NW * 64, nw = NW;          // 4 waves, or 3 (9 tiles)
     const int r16 = lane & 15, qd = lane >> 4;
 
     // ---- stage Q (scaled), K rows and V^T
-    for (int e = tid; e < NP * 4; e += 256) {
+    for (int e = tid; e < NP * 4; e += nth) {
         const int row = e >> 2, pc = e & 3;
         uint4 qv = make_uint4(0, 0, 0, 0), kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
         if (row < N) {
@@ -869,9 +873,9 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const u16* _
     int* Rid = Kidx + NP;
     int mixed = 0;   // shifted block: does this window type hold more than one region?  (only the last row / column of windows do)
     if (rel_table) {
-        for (int e = tid; e < 2 * T + 4; e += 256) Tb[e] = e < T ? rel_table[(long long)h * T + e] : -1e30f;
+        for (int e = tid; e < 2 * T + 4; e += nth) Tb[e] = e < T ? rel_table[(long long)h * T + e] : -1e30f;
         const int* rg = region ? region + (long long)(b % nW) * N : nullptr;
-        for (int e = tid; e < NP; e += 256) {
+        for (int e = tid; e < NP; e += nth) {
             const int yj = e / ws, xj = e - yj * ws;
             Kidx[e] = e < N ? yj * (2 * ws - 1) + xj : -T - 3;                // padded keys index the -1e30 area
             const int r = (rg && e < N) ? rg[e] : (rg ? rg[0] : 0);
@@ -881,14 +885,15 @@ __global__ __launch_bounds__(256) void window_attention_mfma_kernel(const u16* _
         mixed = __syncthreads_or(mixed);
     }
     if (NP2 > NP) {  // zero the V^T columns of the padding half-block
-        for (int e = tid; e < 32 * (NP2 - NP); e += 256) {
+        for (int e = tid; e < 32 * (NP2 - NP); e += nth) {
             const int d = e / (NP2 - NP), c = NP + e % (NP2 - NP);
             *(u16*)(Vt + d * VT_PITCH + c * 2) = 0;
         }
     }
     __syncthreads();
 
-    for (int qt = wave; qt < NT; qt += 4) {
+#pragma unroll 1
+    for (int qt = wave; qt < NT; qt += nw) {
         const bf16x8_t qf = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Qs + (qt * 16 + r16) * QK_PITCH + qd * 16));
         const int query = qt * 16 + r16;
         f32x4 s[NT];
@@ -994,7 +999,11 @@ static int window_attention_launch(const void* q, const void* k, const void* v, 
     switch (NT) {
         case 1: WA(1); break; case 2: WA(2); break; case 3: WA(3); break; case 4: WA(4); break;
         case 5: WA(5); break; case 6: WA(6); break; case 7: WA(7); break; case 8: WA(8); break;
-        case 9: WA(9); break; case 10: WA(10); break; case 11: WA(11); break; case 12: WA(12); break;
+        case 9:       // three waves: 9 query tiles over 4 waves leave three of them idle for a third of the loop
+            hipLaunchKernelGGL((window_attention_mfma_kernel<9, 3>), grid, dim3(192), lds, s, (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, bias_padded,
+                               mask_padded, N, q_stride, k_stride, v_stride, o_stride, nW, scale, rel_table, region, ws);
+            break;
+        case 10: WA(10); break; case 11: WA(11); break; case 12: WA(12); break;
         case 13: WA(13); break; case 14: WA(14); break; case 15: WA(15); break; default: WA(16); break;
     }
 #undef WA
