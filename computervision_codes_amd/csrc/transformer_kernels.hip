@@ -848,32 +848,65 @@ __global__ __launch_bounds__(NW * 64, (NT >= 8 && NT <= 9) ? 3 : 1) void window_
     constexpr int nth = NW * 64, nw = NW;          // 4 waves, or 3 (9 tiles)
     const int r16 = lane & 15, qd = lane >> 4;
 
-    // ---- stage Q (scaled), K rows and V^T
-    for (int e = tid; e < NP * 4; e += nth) {
+    // ---- stage Q (scaled), K rows and V^T.  Every global load of the workgroup is issued before the first LDS store: left as a loop of
+    // load -> store -> load ..., the three (four, with the bias table) round trips to memory ran one after the other and were half of a
+    // workgroup's lifetime
+    constexpr int SI = (NP * 4 + nth - 1) / nth;
+    uint4 qv[SI], kv[SI], vv[SI];
+#pragma unroll
+    for (int i = 0; i < SI; ++i) {
+        const int e = tid + i * nth;
         const int row = e >> 2, pc = e & 3;
-        uint4 qv = make_uint4(0, 0, 0, 0), kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        qv[i] = make_uint4(0, 0, 0, 0); kv[i] = make_uint4(0, 0, 0, 0); vv[i] = make_uint4(0, 0, 0, 0);
         if (row < N) {
             const long long r = (long long)b * N + row;
-            qv = *(const uint4*)(q + r * q_stride + h * 32 + pc * 8);
-            kv = *(const uint4*)(k + r * k_stride + h * 32 + pc * 8);
-            vv = *(const uint4*)(v + r * v_stride + h * 32 + pc * 8);
-            uint32_t* qu = (uint32_t*)&qv;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                qu[i] = pack_bf16x2(__uint_as_float(qu[i] << 16) * scale, __uint_as_float(qu[i] & 0xffff0000u) * scale);
+            qv[i] = *(const uint4*)(q + r * q_stride + h * 32 + pc * 8);
+            kv[i] = *(const uint4*)(k + r * k_stride + h * 32 + pc * 8);
+            vv[i] = *(const uint4*)(v + r * v_stride + h * 32 + pc * 8);
         }
-        *(uint4*)(Qs + row * QK_PITCH + pc * 16) = qv;
-        *(uint4*)(Ks + row * QK_PITCH + pc * 16) = kv;
-        const u16* ve = (const u16*)&vv;
+    }
+    constexpr int TI = 6;                        // bias-table entries per thread held in registers ((2 ws - 1)^2 + 4 <= TI * nth: ws <= 16)
+    float tbv[TI];
+    const int T0 = (2 * ws - 1) * (2 * ws - 1);
+    const bool tb_regs = rel_table && 2 * T0 + 4 <= TI * nth;
+    if (tb_regs) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *(u16*)(Vt + (pc * 8 + i) * VT_PITCH + row * 2) = ve[i];
+        for (int i = 0; i < TI; ++i) {
+            const int e = tid + i * nth;
+            tbv[i] = e < T0 ? rel_table[(long long)h * T0 + e] : -1e30f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SI; ++i) {
+        const int e = tid + i * nth;
+        if (e >= NP * 4) continue;
+        const int row = e >> 2, pc = e & 3;
+        if (row < N) {
+            uint32_t* qu = (uint32_t*)&qv[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                qu[j] = pack_bf16x2(__uint_as_float(qu[j] << 16) * scale, __uint_as_float(qu[j] & 0xffff0000u) * scale);
+        }
+        *(uint4*)(Qs + row * QK_PITCH + pc * 16) = qv[i];
+        *(uint4*)(Ks + row * QK_PITCH + pc * 16) = kv[i];
+        const u16* ve = (const u16*)&vv[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(u16*)(Vt + (pc * 8 + j) * VT_PITCH + row * 2) = ve[j];
     }
     const int T = (2 * ws - 1) * (2 * ws - 1);
     int* Kidx = (int*)(Tb + 2 * T + 4);
     int* Rid = Kidx + NP;
     int mixed = 0;   // shifted block: does this window type hold more than one region?  (only the last row / column of windows do)
     if (rel_table) {
-        for (int e = tid; e < 2 * T + 4; e += nth) Tb[e] = e < T ? rel_table[(long long)h * T + e] : -1e30f;
+        if (tb_regs) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int e = tid + i * nth;
+                if (e < 2 * T + 4) Tb[e] = tbv[i];
+            }
+        } else {
+            for (int e = tid; e < 2 * T + 4; e += nth) Tb[e] = e < T ? rel_table[(long long)h * T + e] : -1e30f;
+        }
         const int* rg = region ? region + (long long)(b % nW) * N : nullptr;
         for (int e = tid; e < NP; e += nth) {
             const int yj = e / ws, xj = e - yj * ws;
