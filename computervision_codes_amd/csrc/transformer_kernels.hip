@@ -342,11 +342,21 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const u16* __restrict__ q
     for (int kt = 0; kt < NKT; ++kt) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < NCH; ++c) {
         if (c) __syncthreads();
-        for (int e = tid; e < NKP * 8; e += 256) {   // K chunk: rows of 64 dims = 8 pieces of 16 B
-            const int row = e >> 3, pc = e & 7;
-            uint4 kv = make_uint4(0, 0, 0, 0);
-            if (row < Nk) kv = *(const uint4*)(k + ((long long)b * Nk + row) * k_stride + h * HD + c * 64 + pc * 8);
-            *(uint4*)(Ks + row * K_PITCH + pc * 16) = kv;
+        {   // K chunk: rows of 64 dims = 8 pieces of 16 B.  All loads of the chunk are issued before the first LDS store (as a load -> store loop
+            // the chunk cost one memory round trip per iteration; rows beyond Nk read row Nk - 1 and are zeroed by a select, not a branch)
+            constexpr int SI = (NKP * 8 + 255) / 256;
+            uint4 kreg[SI];
+#pragma unroll
+            for (int i = 0; i < SI; ++i) {
+                const int e = tid + i * 256, row = e >> 3, pc = e & 7;
+                const uint4 t = *(const uint4*)(k + ((long long)b * Nk + min(row, Nk - 1)) * k_stride + h * HD + c * 64 + pc * 8);
+                kreg[i] = row < Nk ? t : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < SI; ++i) {
+                const int e = tid + i * 256, row = e >> 3, pc = e & 7;
+                if (e < NKP * 8) *(uint4*)(Ks + row * K_PITCH + pc * 16) = kreg[i];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -387,13 +397,24 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const u16* __restrict__ q
     }
     for (int c = 0; c < NCH; ++c) {
         __syncthreads();   // previous chunk's (or the K chunk's) readers are done
-        for (int e = tid; e < NKP2 * 8; e += 256) {   // V chunk, transposed: Vt[d][key]
-            const int row = e >> 3, pc = e & 7;
-            uint4 vv = make_uint4(0, 0, 0, 0);
-            if (row < Nk) vv = *(const uint4*)(v + ((long long)b * Nk + row) * v_stride + h * HD + c * 64 + pc * 8);
-            const u16* ve = (const u16*)&vv;
+        {   // V chunk, transposed: Vt[d][key] (loads first, as for K)
+            constexpr int SI = (NKP2 * 8 + 255) / 256;
+            uint4 vreg[SI];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) *(u16*)(Vt + (pc * 8 + i) * VT_PITCH + row * 2) = ve[i];
+            for (int i = 0; i < SI; ++i) {
+                const int e = tid + i * 256, row = e >> 3, pc = e & 7;
+                const uint4 t = *(const uint4*)(v + ((long long)b * Nk + min(row, Nk - 1)) * v_stride + h * HD + c * 64 + pc * 8);
+                vreg[i] = row < Nk ? t : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < SI; ++i) {
+                const int e = tid + i * 256, row = e >> 3, pc = e & 7;
+                if (e < NKP2 * 8) {
+                    const u16* ve = (const u16*)&vreg[i];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) *(u16*)(Vt + (pc * 8 + j) * VT_PITCH + row * 2) = ve[j];
+                }
+            }
         }
         __syncthreads();
         f32x4 o[4];
@@ -459,12 +480,21 @@ __global__ __launch_bounds__(256) void mha_mfma_f32_kernel(const float* __restri
     for (int c = 0; c < MAXG / 2; ++c) {
         if (c < nch) {   // (uniform)
             if (c) __syncthreads();
-            for (int e = tid; e < NKP * 8; e += 256) {   // K chunk: rows of 32 dims = 8 pieces of 4 floats
-                const int row = e >> 3, pc = e & 7;
-                const int d = c * 32 + pc * 4;
-                float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < Nk && d < hd) kv = *(const float4*)(k + ((long long)b * Nk + row) * k_stride + h * hd + d);
-                *(float4*)(Ks + row * K_PITCH + pc * 4) = kv;
+            {   // K chunk: rows of 32 dims = 8 pieces of 4 floats; every load issued before the first LDS store (clamped address + select)
+                constexpr int SI = (NKP * 8 + 255) / 256;
+                float4 kreg[SI];
+#pragma unroll
+                for (int i = 0; i < SI; ++i) {
+                    const int e = tid + i * 256, row = e >> 3, pc = e & 7;
+                    const int d = c * 32 + pc * 4;
+                    const float4 t = *(const float4*)(k + ((long long)b * Nk + min(row, Nk - 1)) * k_stride + h * hd + min(d, hd - 4));
+                    kreg[i] = (row < Nk && d < hd) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < SI; ++i) {
+                    const int e = tid + i * 256, row = e >> 3, pc = e & 7;
+                    if (e < NKP * 8) *(float4*)(Ks + row * K_PITCH + pc * 4) = kreg[i];
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -500,15 +530,26 @@ __global__ __launch_bounds__(256) void mha_mfma_f32_kernel(const float* __restri
     const float inv = 1.0f / sum;
     for (int c = 0; c < nch; ++c) {
         __syncthreads();
-        for (int e = tid; e < NKP * 8; e += 256) {   // V chunk, transposed: Vt[d][key]
-            const int row = e >> 3, pc = e & 7;
-            const int d = c * 32 + pc * 4;
-            float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < Nk && d < hd) vv = *(const float4*)(v + ((long long)b * Nk + row) * v_stride + h * hd + d);
-            Vt[(pc * 4 + 0) * VT_PITCH + row] = vv.x;
-            Vt[(pc * 4 + 1) * VT_PITCH + row] = vv.y;
-            Vt[(pc * 4 + 2) * VT_PITCH + row] = vv.z;
-            Vt[(pc * 4 + 3) * VT_PITCH + row] = vv.w;
+        {   // V chunk, transposed: Vt[d][key] (loads first, as for K)
+            constexpr int SI = (NKP * 8 + 255) / 256;
+            float4 vreg[SI];
+#pragma unroll
+            for (int i = 0; i < SI; ++i) {
+                const int e = tid + i * 256, row = e >> 3, pc = e & 7;
+                const int d = c * 32 + pc * 4;
+                const float4 t = *(const float4*)(v + ((long long)b * Nk + min(row, Nk - 1)) * v_stride + h * hd + min(d, hd - 4));
+                vreg[i] = (row < Nk && d < hd) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < SI; ++i) {
+                const int e = tid + i * 256, row = e >> 3, pc = e & 7;
+                if (e < NKP * 8) {
+                    Vt[(pc * 4 + 0) * VT_PITCH + row] = vreg[i].x;
+                    Vt[(pc * 4 + 1) * VT_PITCH + row] = vreg[i].y;
+                    Vt[(pc * 4 + 2) * VT_PITCH + row] = vreg[i].z;
+                    Vt[(pc * 4 + 3) * VT_PITCH + row] = vreg[i].w;
+                }
+            }
         }
         __syncthreads();
         f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
