@@ -85,7 +85,7 @@ extern "C" int mt4_pad_nchw_f32(const float* x, void* out, int32_t B, int32_t H,
 // normalised frame pixel (2y+dy-3, 2x+dx-3), zero outside the frame and in channels 12..15.  The 7x7/2 stem is then a 4x4/1 conv whose
 // kernel row is 4 pixels x 16 channels = ONE contiguous 128-byte run: it goes through the LDS-DMA path of mt4_conv_nhwc (x_pixel_stride).
 __global__ void stem_input_s2d_kernel(const uint8_t* __restrict__ in, u16* __restrict__ out, int B, int H, int W, int Hs, int Ws, float m0,
-                                      float m1, float m2, float s0, float s1, float s2) {
+                                      float m1, float m2, float s0, float s1, float s2, int nt) {
     // the 3 x 256 possible bf16 values, once per block (two fp32 divisions per value: per element they cost more than the kernel's memory time)
     __shared__ u16 lut[3][256];
     for (int i = threadIdx.x; i < 768; i += blockDim.x) {
@@ -101,24 +101,40 @@ __global__ void stem_input_s2d_kernel(const uint8_t* __restrict__ in, u16* __res
     const long long t = idx / Ws;
     const int ys = (int)(t % Hs);
     const int b = (int)(t / Hs);
+    // the two pixels of a frame row are 6 contiguous bytes: one unaligned 4-byte + one 2-byte load per row instead of six byte loads (the
+    // launch was bound by the number of load instructions: 12 per thread).  Rows / columns outside the frame are clamped and zeroed by a select
+    struct __attribute__((packed)) Px2 { uint32_t a; uint16_t b; };
+    unsigned raw[12];
+    bool ok[4];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        const int h = 2 * ys + dy - 3, w0 = 2 * xs - 3;
+        const bool hok = (unsigned)h < (unsigned)H;
+        ok[dy * 2 + 0] = hok && (unsigned)w0 < (unsigned)W;
+        ok[dy * 2 + 1] = hok && (unsigned)(w0 + 1) < (unsigned)W;
+        const int hc = min(max(h, 0), H - 1), wc = min(max(w0, 0), W - 2);   // (wc, wc + 1) inside the row; a clamped pair is only read where ok[] is false ... or equals the pair wanted
+        const Px2 t = *(const Px2*)(in + (((long long)b * H + hc) * W + wc) * 3);
+        const bool shifted = wc != w0;          // left / right border: the pair was moved, its pixels are not the ones asked for
+        raw[dy * 6 + 0] = t.a & 0xff; raw[dy * 6 + 1] = (t.a >> 8) & 0xff; raw[dy * 6 + 2] = (t.a >> 16) & 0xff;
+        raw[dy * 6 + 3] = t.a >> 24; raw[dy * 6 + 4] = t.b & 0xff; raw[dy * 6 + 5] = t.b >> 8;
+        if (shifted) {       // w0 = -3, -1 (both or the first pixel outside) or W - 1 (second outside)
+            if (w0 == -1) { raw[dy * 6 + 3] = raw[dy * 6 + 0]; raw[dy * 6 + 4] = raw[dy * 6 + 1]; raw[dy * 6 + 5] = raw[dy * 6 + 2]; }   // pixel 0 of the row is the SECOND of the pair
+            else if (w0 == W - 1) { raw[dy * 6 + 0] = raw[dy * 6 + 3]; raw[dy * 6 + 1] = raw[dy * 6 + 4]; raw[dy * 6 + 2] = raw[dy * 6 + 5]; }   // pixel W-1 is the FIRST
+        }
+    }
     unsigned v[12];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) v[e] = 0u;
+    for (int px = 0; px < 4; ++px)
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            const int h = 2 * ys + dy - 3, w = 2 * xs + dx - 3;
-            if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
-                const uint8_t* p = in + (((long long)b * H + h) * W + w) * 3;
-                v[(dy * 2 + dx) * 3 + 0] = lut[0][p[0]];
-                v[(dy * 2 + dx) * 3 + 1] = lut[1][p[1]];
-                v[(dy * 2 + dx) * 3 + 2] = lut[2][p[2]];
-            }
+        for (int c = 0; c < 3; ++c) {
+            const unsigned t = lut[c][raw[px * 3 + c]];
+            v[px * 3 + c] = ok[px] ? t : 0u;
         }
-    uint4* o = (uint4*)(out + idx * 16);
-    o[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
-    o[1] = make_uint4(v[8] | (v[9] << 16), v[10] | (v[11] << 16), 0u, 0u);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4* o = (u32x4*)(out + idx * 16);
+    const u32x4 lo = {v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)}, hi = {v[8] | (v[9] << 16), v[10] | (v[11] << 16), 0u, 0u};
+    if (nt) { __builtin_nontemporal_store(lo, o); __builtin_nontemporal_store(hi, o + 1); }
+    else { o[0] = lo; o[1] = hi; }
 }
 
 extern "C" int mt4_preprocess_u8_s2d(const uint8_t* frames, void* out, int32_t B, int32_t H, int32_t W, const float mean[3],
@@ -129,7 +145,7 @@ extern "C" int mt4_preprocess_u8_s2d(const uint8_t* frames, void* out, int32_t B
     const int Hs = (H + 6) / 2, Ws = (W + 6) / 2;
     const long long total = (long long)B * Hs * Ws;
     hipLaunchKernelGGL(stem_input_s2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frames, (u16*)out, B, H,
-                       W, Hs, Ws, mean[0], mean[1], mean[2], std[0], std[1], std[2]);
+                       W, Hs, Ws, mean[0], mean[1], mean[2], std[0], std[1], std[2], MT4_ENV_SET("MT4_S2D_NO_NT") ? 0 : 1);
     return mt4_check_launch();
 }
 

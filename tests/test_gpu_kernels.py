@@ -383,3 +383,23 @@ def test_conv3x3_expand_bit_identical_to_two_launches(cuda, b, h, w):
     assert torch.equal(y.view(torch.int16), ref.view(torch.int16)), float((y.float() - ref.float()).abs().max())
     small = ops.conv3x3_expand(t1[:2].contiguous(), w2, b2, ops.pack_fragments(w3), b3, res[:2].contiguous())
     assert small is None          # few tiles: the caller runs the two launches
+
+
+@pytest.mark.parametrize("b,h,w", [(2, 224, 224), (3, 6, 10), (1, 2, 2), (2, 32, 34)])
+def test_preprocess_u8_s2d_matches_torch(cuda, b, h, w):
+    """`mt4_preprocess_u8_s2d` (ToTensor + Normalize of `Spatial_cnn/dataloader.py:153-162`, 3-pixel zero padding, 2 x 2 space-to-depth) against the
+    same arithmetic in torch, bit for bit -- every border column and row (the kernel reads pixel pairs with clamped addresses)"""
+    from computervision_codes_amd import ops
+    from computervision_codes_amd.spatial_cnn import IMAGENET_MEAN, IMAGENET_STD
+    g = torch.Generator().manual_seed(17 + w)
+    frames = torch.randint(0, 256, (b, h, w, 3), generator=g, dtype=torch.uint8)
+    got = ops.preprocess_u8_s2d(frames.to(cuda), IMAGENET_MEAN, IMAGENET_STD).cpu()
+    mean, std = torch.tensor(IMAGENET_MEAN, dtype=torch.float32), torch.tensor(IMAGENET_STD, dtype=torch.float32)
+    x = ((frames.float() / 255.0 - mean) / std).to(torch.bfloat16)
+    hp, wp = h + 6, w + 6
+    pad = torch.zeros((b, hp, wp, 3), dtype=torch.bfloat16)
+    pad[:, 3:3 + h, 3:3 + w] = x
+    s2d = pad.view(b, hp // 2, 2, wp // 2, 2, 3).permute(0, 1, 3, 2, 4, 5).reshape(b, hp // 2, wp // 2, 12)
+    ref = torch.zeros((b, hp // 2, wp // 2, 16), dtype=torch.bfloat16)
+    ref[..., :12] = s2d
+    assert got.shape == ref.shape and torch.equal(got.view(torch.int16), ref.view(torch.int16))
