@@ -235,11 +235,18 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
         }
     }
     uint4 wf3[4][2];
+    uint4 wfd[DS ? 4 : 1][2];     // downsample block: the branch's fragments of this wave's four channel tiles, in flight with conv3's (loaded where
+                                  // they are used, each of the four waited out an L2 round trip behind 16 MFMAs)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const char* wr = a.w3 + ((4 * i + wave) * 2 * 64 + lane) * 16;
         wf3[i][0] = *(const uint4*)wr;
         wf3[i][1] = *(const uint4*)(wr + 1024);
+        if constexpr (DS) {
+            const char* wd = a.wds + ((4 * i + wave) * 2 * 64 + lane) * 16;
+            wfd[i][0] = *(const uint4*)wd;
+            wfd[i][1] = *(const uint4*)(wd + 1024);
+        }
     }
     {
         const int wr_off = r16 * ROW_B + (((cb1 >> 4) ^ (r16 & 7)) << 4) + (cb1 & 8);
@@ -279,18 +286,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused_kernel(const BneckK
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc3[j] = mfma_bf16(wf3[i][kk], fx3[j][kk], acc3[j]);
             if constexpr (DS) {
-                uint4 wfd[2];                              // (loaded here: preloading all four tiles' fragments spills)
-                {
-                    const char* wd = a.wds + (ct * 2 * 64 + lane) * 16;
-                    wfd[0] = *(const uint4*)wd;
-                    wfd[1] = *(const uint4*)(wd + 1024);
-                }
                 const f32x4 bd4 = bias4(a.bds, ct * 16 + q * 4);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {              // the pixel itself in the halo tile: row ty + 1, column shift 1
                     f32x4 accd = bd4;
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) accd = mfma_bf16(wfd[kk], *(const uint4*)(xs + (j + 1) * (16 * ROW_B) + toff[1][kk]), accd);
+                    for (int kk = 0; kk < 2; ++kk) accd = mfma_bf16(wfd[i][kk], *(const uint4*)(xs + (j + 1) * (16 * ROW_B) + toff[1][kk]), accd);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc3[j][e] += bf16_to_f32(f32_to_bf16(accd[e]));   // the stand-alone downsample launch stores bf16
                 }
