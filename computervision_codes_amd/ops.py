@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import contextlib
 import contextvars
+import os
 import ctypes as C
 import functools
 from typing import Optional, Tuple
@@ -64,6 +65,8 @@ def conv_out_size(h: int, k: int, stride: int, pad: int, dil: int) -> int:
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
+_TCN_LINEAR = not os.environ.get("MT4_NO_TCN_LINEAR")     # latency contexts: nn.Linear on few rows through the TCN latency kernel
+_TCN_LINEAR_MAX_ROWS = 512
 _LATENCY_TILES = contextvars.ContextVar("mt4_latency_tiles", default=False)   # per thread / task: forwards may run from several threads
 
 
@@ -227,6 +230,11 @@ def tcn_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tenso
                      1 if relu else 0, dt_code(x.dtype), dt_code(od))
     check(lib.mt4_tcn_conv(C.byref(d), _stream()), "mt4_tcn_conv")
     return out
+
+
+def latency_linear_ok(rows: int, cin: int, dtype: torch.dtype) -> bool:
+    """inside a latency context: does a GEMM / 1-D conv over `rows` frames of `cin` channels take the temporal head's latency kernel?"""
+    return bool(_LATENCY_TILES.get()) and _TCN_LINEAR and rows <= _TCN_LINEAR_MAX_ROWS and tcn_supported(cin, dtype)
 
 
 def tcn_supported(cin: int, dtype: torch.dtype) -> bool:
@@ -517,6 +525,14 @@ def linear(x2d: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tenso
     m, k = x2d.shape
     y_ld = 0 if out is None or out.is_contiguous() else out.stride(0)
     res_ld = 0 if residual is None or residual.is_contiguous() else residual.stride(0)
+    if (_LATENCY_TILES.get() and _TCN_LINEAR and act in (None, "none", "relu") and out_row_map is None and y_ld == 0 and res_ld == 0
+            and m <= _TCN_LINEAR_MAX_ROWS and tcn_supported(k, x2d.dtype) and x2d.is_contiguous() and (residual is None or residual.dtype == x2d.dtype)
+            and (out_dtype is None or out_dtype == x2d.dtype or out_dtype == torch.float32)):
+        # a short sequence's nn.Linear inside a latency context (MS-TCT on one window): the temporal head's latency kernel as a 1-tap conv
+        # (32 x 16 tiles, one workgroup per CU, no barrier in the K loop) instead of the K-split tiles of the generic kernel
+        y = tcn_conv(x2d.view(1, m, k), w_packed, bias, taps=1, residual=residual, relu=(act == "relu"), out_dtype=out_dtype,
+                     out=out.view(1, m, -1) if out is not None else None)
+        return out if out is not None else y.view(m, -1)
     y = conv_nhwc(x2d.view(m, 1, 1, k), w_packed, bias, kh=1, kw=1, residual=residual, act=act, out_row_map=out_row_map,
                   out_dtype=out_dtype, out=out, y_ld=y_ld, res_ld=res_ld)
     return y if out is not None else y.view(m, -1)

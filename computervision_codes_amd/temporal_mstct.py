@@ -118,7 +118,10 @@ class VideoNas:
         feats = []
         cin = d
         for st, c in zip(p["stages"], self.inter):
-            y = ops.conv_nhwc(x.view(b, 1, t, cin), st["merge"][0], st["merge"][1], kh=1, kw=3, pad=(0, 1)).view(b * t, c)
+            if ops.latency_linear_ok(b * t, cin, self.dtype):      # short window: the temporal head's latency kernel (3 taps, dilation 1)
+                y = ops.tcn_conv(x.view(b, t, cin), st["merge"][0], st["merge"][1], taps=3, dilation=1).view(b * t, c)
+            else:
+                y = ops.conv_nhwc(x.view(b, 1, t, cin), st["merge"][0], st["merge"][1], kh=1, kw=3, pad=(0, 1)).view(b * t, c)
             y = ops.layernorm(y, *st["merge_norm"])
             for blk in st["blocks"]:
                 y = self._block(y, blk, b, t, c)
