@@ -158,7 +158,10 @@ def _load() -> C.CDLL:
     return lib
 
 
+ABI_VERSION = 6         # what mt4_abi_version() of a matching libmt4hip.so returns (csrc/misc_kernels.hip)
 lib = _load()
+if lib.mt4_abi_version() != ABI_VERSION:      # a stale libmt4hip.so next to newer Python: fail at import, not in the first launch
+    raise ImportError(f"libmt4hip.so reports ABI {lib.mt4_abi_version()}, this package binds ABI {ABI_VERSION}: rebuild (make -C computervision_codes_amd/csrc)")
 
 
 MT4_EUNSUPPORTED = -4   # include/mt4hip.h
