@@ -30,6 +30,8 @@ extern "C" {
 #define MT4_F32 0
 #define MT4_BF16 1
 
+/* 6 in this revision (5 -> 6: mt4_stem_maxpool_bf16, mt4_bottleneck_fused_next_bf16, mt4_pack_fragments_bf16, the x2 / fuse_expand fields at the
+ * end of mt4_conv_desc).  A binding checks it once at load (computervision_codes_amd/_lib.py: ABI_VERSION). */
 int mt4_abi_version(void);
 const char* mt4_strerror(int code);
 /* last hipError_t (as int) seen by this thread inside the library, 0 if none */
