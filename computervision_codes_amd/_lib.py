@@ -71,6 +71,8 @@ SIGNATURES = {
     "mt4_preprocess_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _FLOAT3, _FLOAT3, _i32, _vp]),
     "mt4_preprocess_u8_s2d": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _FLOAT3, _FLOAT3, _vp]),
     "mt4_pad_nchw_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_png_inflate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_int64, C.c_int64, _vp, _vp]),
+    "mt4_png_unfilter_rgb8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.c_int64, _vp, _vp]),
     "mt4_resize_pass_u8": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mt4_maxpool3x3s2_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mt4_stem_maxpool_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

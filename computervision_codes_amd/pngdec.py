@@ -1,0 +1,84 @@
+"""PNG decode on the GPU.  The reference decodes every frame with PIL inside its DataLoader workers
+(`Spatial_cnn/dataloader.py:257-261`, three worker processes, `Spatial_cnn/test.py:240-241`); here the host only walks the chunk
+list of each file -- signature, IHDR, the concatenated IDAT payload -- and the inflate + scanline unfiltering run on the device
+(`mt4_png_inflate`: one thread per frame, `mt4_png_unfilter_rgb8`).  8-bit RGB, non-interlaced files (what CholecT45 ships);
+anything else raises `UnsupportedPng` and the caller keeps the PIL path for that file."""
+from __future__ import annotations
+
+import struct
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import check, lib
+
+_SIG = b"\x89PNG\r\n\x1a\n"
+
+
+class UnsupportedPng(ValueError):
+    pass
+
+
+def parse_png(data: bytes) -> Tuple[int, int, bytes]:
+    """(width, height, DEFLATE stream) of an 8-bit RGB, non-interlaced PNG: chunk walk only (PNG spec 5.3), the zlib header
+    (RFC 1950: CM = 8, no preset dictionary) stripped, the Adler-32 trailer left in place behind the last block"""
+    if len(data) < 33 or data[:8] != _SIG:
+        raise UnsupportedPng("not a PNG file")
+    pos = 8
+    width = height = None
+    idat: List[bytes] = []
+    while pos + 8 <= len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        if len(body) != n:
+            raise UnsupportedPng("truncated chunk")
+        if typ == b"IHDR":
+            width, height, depth, ctype, comp, filt, inter = struct.unpack(">IIBBBBB", body)
+            if depth != 8 or ctype != 2 or comp != 0 or filt != 0 or inter != 0:
+                raise UnsupportedPng(f"bit depth {depth}, colour type {ctype}, interlace {inter}: only 8-bit RGB, non-interlaced")
+        elif typ == b"IDAT":
+            idat.append(body)
+        elif typ == b"IEND":
+            break
+        pos += 12 + n
+    if width is None or not idat:
+        raise UnsupportedPng("no IHDR / IDAT")
+    z = b"".join(idat)
+    if len(z) < 6 or (z[0] & 0x0F) != 8 or ((z[0] << 8) | z[1]) % 31 != 0 or (z[1] & 0x20):
+        raise UnsupportedPng("bad zlib header")
+    return width, height, z[2:]
+
+
+def decode_batch(files: Sequence[bytes], device="cuda") -> torch.Tensor:
+    """PNG files (bytes) of ONE frame size -> uint8 [N,H,W,3] on the device, equal to `np.asarray(PIL.Image.open(f).convert('RGB'))`.
+    Raises `UnsupportedPng` before any launch if a file is not 8-bit RGB / non-interlaced or the sizes differ, `RuntimeError` if a
+    stream is corrupt."""
+    parsed = [parse_png(f) for f in files]
+    w, h = parsed[0][0], parsed[0][1]
+    if any((p[0], p[1]) != (w, h) for p in parsed):
+        raise UnsupportedPng("frames of different sizes in one batch")
+    n = len(parsed)
+    lengths = np.array([len(p[2]) for p in parsed], dtype=np.int32)
+    offsets = np.zeros(n, dtype=np.int64)
+    offsets[1:] = np.cumsum(lengths[:-1].astype(np.int64))
+    blob = torch.from_numpy(np.frombuffer(b"".join(p[2] for p in parsed) + b"\0" * 8, dtype=np.uint8).copy())
+    dev = torch.device(device)
+    streams = blob.pin_memory().to(dev, non_blocking=True)
+    offs = torch.from_numpy(offsets).to(dev)
+    lens = torch.from_numpy(lengths).to(dev)
+    raw_len = h * (1 + 3 * w)
+    raw_stride = (raw_len + 15) // 16 * 16
+    raw = torch.empty((n, raw_stride), dtype=torch.uint8, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
+    s = ops._stream()
+    check(lib.mt4_png_inflate(streams.data_ptr(), offs.data_ptr(), lens.data_ptr(), raw.data_ptr(), n, raw_stride, raw_len, status.data_ptr(), s),
+          "mt4_png_inflate")
+    check(lib.mt4_png_unfilter_rgb8(raw.data_ptr(), out.data_ptr(), n, h, w, raw_stride, status.data_ptr(), s), "mt4_png_unfilter_rgb8")
+    st = status.cpu()
+    if int(st.abs().max()) != 0:
+        bad = int(torch.nonzero(st)[0])
+        raise RuntimeError(f"PNG decode failed: frame {bad} of the batch, code {int(st[bad])} (include/mt4hip.h: mt4_png_inflate)")
+    return out

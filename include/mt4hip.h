@@ -177,6 +177,18 @@ int mt4_pad_nchw_f32(const float* x, void* out, int32_t B, int32_t H, int32_t W,
 int mt4_preprocess_u8_s2d(const uint8_t* frames, void* out, int32_t B, int32_t H, int32_t W, const float mean[3], const float std[3],
                           void* stream);
 
+/* PNG decode on the device (the reference decodes with PIL in its DataLoader workers, Spatial_cnn/dataloader.py:257-261).
+ * The host only walks the chunk list (IHDR, concatenated IDAT payload); 8-bit RGB, non-interlaced files.
+ *   mt4_png_inflate: B DEFLATE streams (zlib payloads, the 2-byte zlib header stripped), stream i = streams[offsets[i] .. + lengths[i])
+ *     -> the filtered scanlines at raw + i * raw_stride, exactly raw_len = H * (1 + 3 W) bytes; one thread per frame.
+ *     status[i] (device int32) = 0 or: 1 truncated input, 2 bad block type, 3 stored-length mismatch, 4 bad code lengths,
+ *     5 invalid symbol / distance, 6 output overflow, 7 output shorter than raw_len.
+ *   mt4_png_unfilter_rgb8: PNG filters 0-4 undone (bytes per pixel 3) -> uint8 [B][H][W][3]; status[i] = 8 for an unknown filter type.
+ * Both only enqueue; read status after the stream has drained. */
+int mt4_png_inflate(const uint8_t* streams, const int64_t* offsets, const int32_t* lengths, uint8_t* raw, int32_t B, int64_t raw_stride,
+                    int64_t raw_len, int32_t* status, void* stream);
+int mt4_png_unfilter_rgb8(const uint8_t* raw, uint8_t* out, int32_t B, int32_t H, int32_t W, int64_t raw_stride, int32_t* status, void* stream);
+
 /* One separable pass of Pillow's 8-bit resize (`Image.resize(size, BILINEAR)` = `transforms.Resize((256,448))`,
  * Spatial_cnn/dataloader.py:155-159, Spatial_transformer likewise): out = clip8((2^21 + sum_i in[lo+i] * coeffs[o][i]) >> 22).
  * bounds [n_out][2] = (lo, count), coeffs [n_out][ksize] int32 with 22 fractional bits, both built by the host as Pillow's
