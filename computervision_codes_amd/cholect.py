@@ -74,7 +74,8 @@ def load_frames_u8(data_dir: str, video: str, frame_ids, height: int = 256, widt
     return out
 
 
-def load_frames_device(data_dir: str, video: str, frame_ids, height: int = 256, width: int = 448, device="cuda", workers: int = 0):
+def load_frames_device(data_dir: str, video: str, frame_ids, height: int = 256, width: int = 448, device="cuda", workers: int = 0,
+                       decode: str = "host"):
     """Same bytes as `load_frames_u8`, as a uint8 [N,H,W,3] tensor on the GPU: the PNGs are decoded on the host at their native size
     and `Resize((height,width))` runs on the device (`ops.resize_bilinear_u8`, byte-identical to Pillow's bilinear resize).  Frames
     of one native size go through one launch pair; a video mixing sizes falls back to one group per size.  workers > 1: the PNGs
@@ -85,15 +86,35 @@ def load_frames_device(data_dir: str, video: str, frame_ids, height: int = 256, 
 
     from . import ops
 
-    def decode(fid):
+    if decode == "device":
+        # decode = "device": the files are only read; inflate + unfiltering run on the GPU (`pngdec.decode_batch`, 8-bit RGB non-interlaced PNGs --
+        # what the dataset ships; anything else raises `pngdec.UnsupportedPng`).  Same bytes as the Pillow path.
+        from . import pngdec
+        files = []
+        for fid in frame_ids:
+            with open(os.path.join(data_dir, "data", video, "{}.png".format(str(int(fid)).zfill(6))), "rb") as fh:
+                files.append(fh.read())
+        sizes: Dict[tuple, List[int]] = {}
+        for i, f in enumerate(files):
+            w0, h0, _ = pngdec._idat_spans(f)
+            sizes.setdefault((h0, w0), []).append(i)
+        out = torch.empty((len(files), height, width, 3), dtype=torch.uint8, device=device)
+        for (h0, w0), idx in sizes.items():
+            x = pngdec.decode_batch([files[i] for i in idx], device)
+            y = x if (h0, w0) == (height, width) else ops.resize_bilinear_u8(x, height, width)
+            out[torch.tensor(idx, device=device)] = y
+        return out
+    assert decode == "host"
+
+    def decode_one(fid):
         with Image.open(os.path.join(data_dir, "data", video, "{}.png".format(str(int(fid)).zfill(6)))) as im:
             return np.asarray(im.convert("RGB"))
     if workers > 1 and len(frame_ids) > 1:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=workers) as ex:
-            raw = list(ex.map(decode, frame_ids))
+            raw = list(ex.map(decode_one, frame_ids))
     else:
-        raw = [decode(fid) for fid in frame_ids]
+        raw = [decode_one(fid) for fid in frame_ids]
     out = torch.empty((len(raw), height, width, 3), dtype=torch.uint8, device=device)
     groups: Dict[tuple, List[int]] = {}
     for i, a in enumerate(raw):

@@ -1,18 +1,24 @@
 // PNG decode on the device (the reference decodes every frame with PIL inside its DataLoader workers,
 // `Spatial_cnn/dataloader.py:257-261`, three processes, `Spatial_cnn/test.py:240-241`).  Two launches per batch of frames:
-//   mt4_png_inflate       zlib / DEFLATE (RFC 1950 / 1951) streams -> the filtered scanlines, ONE THREAD PER FRAME: a DEFLATE stream is
-//                         a serial bit stream, the parallelism is across the frames of a video (hundreds per batch);
-//   mt4_png_unfilter_rgb8 the five PNG scanline filters (PNG spec 9.2) undone for 8-bit RGB -> [B][H][W][3] uint8.
+//   mt4_png_inflate       zlib / DEFLATE (RFC 1950 / 1951) streams -> the filtered scanlines, ONE WAVE PER FRAME;
+//   mt4_png_unfilter_rgb8 the five PNG scanline filters (PNG spec 9.2) undone for 8-bit RGB -> [B][H][W][3] uint8, one wave per frame.
 // The host side (pngdec.py) only walks the chunk list of each file (IHDR, IDAT concatenation) -- no inflate, no pixel work on the CPU.
-// Decoder structure: canonical-Huffman decode by code length with per-length counts and a sorted symbol list (the classic table-free
-// scheme: at most 15 steps per symbol, no per-block lookup table to build); the count / symbol arrays of a thread live in LDS, index-major
-// ([entry][thread]) so that the lanes of a wave reading the same entry hit different banks.
+// A DEFLATE stream is a serial bit stream; what a wave can do in parallel is everything around the bit decode, and that is where a
+// thread-per-frame decoder (the first version: 0.4 k frames/s at 480 x 854, every output byte a dependent global store / load) spends its time:
+//   * the 64 lanes run the SAME decode (uniform control flow, no divergence): Huffman tables, the 32 KB history window and the code-length
+//     scratch are the wave's own LDS, read at one address by every lane (broadcast);
+//   * symbols are decoded through first-level lookup tables (11 bits literal / length, 10 bits distance: one LDS read per symbol), filled by
+//     all lanes in parallel for every dynamic block; longer codes fall back to the canonical decode by code length;
+//   * a match is copied by the lanes in parallel inside the window; finished 8 KB pieces of the window go to memory as 16-byte vectors.
+// The unfilter kernel keeps the raw and the previous row in LDS: rows of type None / Up are done by all lanes, Sub / Average / Paeth (a
+// recurrence along the row per channel) by three lanes -- from LDS, so the chain runs at register speed.
 #include "mt4_common.h"
 
 namespace {
 
-constexpr int PNG_THREADS = 64;
 constexpr int MAXBITS = 15, MAXL = 288, MAXD = 32;
+constexpr int WIN = 32768, FLUSH = 8192;
+constexpr int LBITS = 11, DBITS = 10;
 
 __device__ const unsigned short kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __device__ const unsigned char kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -20,76 +26,126 @@ __device__ const unsigned short kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25
 __device__ const unsigned char kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __device__ const unsigned char kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
+// Bit input.  The wave holds 512 bytes of the stream in registers (lane i: the two dwords 2i, 2i + 1 of the current chunk, aligned to 4 bytes in
+// memory); a refill takes the next dword with a lane read -- one memory round trip per 512 bytes instead of one per 4 (which was most of a
+// symbol's time).  Everything else is identical in every lane.
 struct Bits {
-    const uint8_t* p;
-    const uint8_t* end;
+    const uint32_t* base;      // aligned dword that holds the first byte of the stream
+    long long nbits;           // bits in the stream
+    long long used;            // bits consumed so far (> nbits: the stream was truncated)
     unsigned long long buf;
     int cnt;
-    int bad;      // ran past the end of the stream
+    int dw;                    // index (from base) of the next dword to take
+    int chunk0;                // dword index of the chunk in registers
+    uint32_t w0, w1;           // this lane's two dwords of the chunk
+    int bad;
 };
 
-__device__ __forceinline__ void refill(Bits& b) {
+__device__ __forceinline__ void load_chunk(Bits& b, int lane) {
+    b.chunk0 = b.dw & ~127;
+    const uint2 t = *(const uint2*)(b.base + b.chunk0 + 2 * lane);      // (the host pads the blob by 1 KB: reading past the last stream is in bounds)
+    b.w0 = t.x; b.w1 = t.y;
+}
+
+__device__ __forceinline__ void refill(Bits& b, int lane) {
     if (b.cnt <= 32) {
-        if (b.p + 4 <= b.end) {
-            struct __attribute__((packed)) U4 { uint32_t v; };
-            b.buf |= (unsigned long long)((const U4*)b.p)->v << b.cnt;
-            b.p += 4;
-            b.cnt += 32;
-        } else {
-            while (b.cnt <= 56 && b.p < b.end) { b.buf |= (unsigned long long)(*b.p++) << b.cnt; b.cnt += 8; }
-        }
+        if (b.dw - b.chunk0 >= 128) load_chunk(b, lane);
+        const int j = __builtin_amdgcn_readfirstlane(b.dw - b.chunk0);
+        const uint32_t lo = __builtin_amdgcn_readlane(b.w0, j >> 1), hi = __builtin_amdgcn_readlane(b.w1, j >> 1);
+        b.buf |= (unsigned long long)((j & 1) ? hi : lo) << b.cnt;
+        b.cnt += 32;
+        b.dw += 1;
     }
 }
 
-__device__ __forceinline__ unsigned getbits(Bits& b, int n) {   // n <= 16
-    if (b.cnt < n) { refill(b); if (b.cnt < n) { b.bad = 1; return 0; } }
+__device__ __forceinline__ unsigned getbits(Bits& b, int n, int lane) {   // n <= 16
+    refill(b, lane);
     const unsigned v = (unsigned)(b.buf & ((1ull << n) - 1));
     b.buf >>= n;
     b.cnt -= n;
+    b.used += n;
     return v;
 }
 
-// tables of one thread, in LDS: entry-major
+// canonical Huffman code of one alphabet, in LDS: count[len], symbols sorted by (length, value), first-level lookup table
 struct Huff {
-    unsigned short* count;    // [MAXBITS + 1] entries, stride PNG_THREADS
-    unsigned short* symbol;   // [n] entries, stride PNG_THREADS
+    unsigned short* count;    // [MAXBITS + 1]
+    unsigned short* symbol;   // [n]
+    unsigned short* tab;      // [1 << tbits]: (code length << 9) | symbol, 0 = longer than tbits (or unused): canonical decode
+    int tbits;
 };
-#define HC(h, i) (h).count[(i) * PNG_THREADS]
-#define HS(h, i) (h).symbol[(i) * PNG_THREADS]
 
-// canonical code from the code lengths: count[len] = number of codes of that length, symbol[] = symbols ordered by (length, value).
-// Returns < 0 for an over-subscribed set, > 0 for an incomplete one (allowed only for a single-code distance tree), 0 for a complete one.
-__device__ int construct(Huff& h, const unsigned char* lens, int n) {
-    for (int len = 0; len <= MAXBITS; ++len) HC(h, len) = 0;
-    for (int s = 0; s < n; ++s) HC(h, lens[s]) = HC(h, lens[s]) + 1;
-    if (HC(h, 0) == n) return 0;          // no codes: complete, but decoding any symbol fails
+__device__ __forceinline__ unsigned rev_bits(unsigned c, int len) { return __brev(c) >> (32 - len); }
+// every lane reads the same LDS address in the decode path: telling the compiler so (readfirstlane) moves the whole bit-stream state machine --
+// buffer, counters, branches -- to the scalar unit; as vector values every branch waited on a v_cmp and every 64-bit shift ran at quarter rate
+#define UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
+
+// from the code lengths lens[0..n) (LDS): counts, sorted symbols, lookup table.  Called by the whole wave; returns (uniformly) < 0 for an
+// over-subscribed set, > 0 for an incomplete one, 0 for a complete one.
+__device__ int construct(Huff& h, const unsigned char* lens, int n, int lane) {
+    __syncthreads();          // (single-wave block: orders the LDS traffic of the previous user of these arrays)
+    if (lane <= MAXBITS) h.count[lane] = 0;
+    for (int i = lane; i < (1 << h.tbits); i += 64) h.tab[i] = 0;
+    __syncthreads();
+    if (lane == 0)
+        for (int s = 0; s < n; ++s) h.count[lens[s]] = h.count[lens[s]] + 1;
+    __syncthreads();
+    if (UNI(h.count[0]) == n) return 0;
     int left = 1;
-    for (int len = 1; len <= MAXBITS; ++len) {
-        left <<= 1;
-        left -= HC(h, len);
-        if (left < 0) return left;
-    }
-    unsigned short offs[MAXBITS + 1];
+    unsigned short offs[MAXBITS + 2], first[MAXBITS + 1];
     offs[1] = 0;
-    for (int len = 1; len < MAXBITS; ++len) offs[len + 1] = offs[len] + HC(h, len);
-    for (int s = 0; s < n; ++s)
-        if (lens[s]) { HS(h, offs[lens[s]]) = (unsigned short)s; offs[lens[s]]++; }
+    int code = 0;
+    for (int len = 1; len <= MAXBITS; ++len) {
+        const int c = UNI(h.count[len]);
+        left = (left << 1) - c;
+        if (left < 0) return left;
+        first[len] = (unsigned short)code;          // canonical code of the first symbol of this length
+        code = (code + c) << 1;
+        offs[len + 1] = offs[len] + c;
+    }
+    if (lane == 0) {
+        unsigned short o[MAXBITS + 1];
+        for (int len = 1; len <= MAXBITS; ++len) o[len] = offs[len];
+        for (int s = 0; s < n; ++s)
+            if (lens[s]) { h.symbol[o[lens[s]]] = (unsigned short)s; o[lens[s]]++; }
+    }
+    __syncthreads();
+    const int nsym = offs[MAXBITS + 1];
+    for (int p = lane; p < nsym; p += 64) {      // lookup entries of sorted position p
+        int len = 1;
+        while (p >= offs[len + 1]) ++len;
+        if (len <= h.tbits) {
+            const unsigned c = first[len] + (p - offs[len]);
+            const unsigned r = rev_bits(c, len);
+            const unsigned short e = (unsigned short)((len << 9) | h.symbol[p]);
+            for (unsigned k = r; k < (1u << h.tbits); k += (1u << len)) h.tab[k] = e;
+        }
+    }
+    __syncthreads();
     return left;
 }
 
-__device__ __forceinline__ int decode_sym(Bits& b, const Huff& h) {
-    refill(b);
-    int code = 0, first = 0, index = 0;
+__device__ __forceinline__ int decode_sym(Bits& b, const Huff& h, int lane) {
+    refill(b, lane);
+    const int e = UNI(h.tab[b.buf & ((1u << h.tbits) - 1)]);
+    if (e) {
+        const int elen = e >> 9;
+        b.buf >>= elen;
+        b.cnt -= elen;
+        b.used += elen;
+        return e & 511;
+    }
+    int code = 0, first = 0, index = 0;      // a code longer than the table's index: canonical decode by length
     unsigned long long buf = b.buf;
-    const int avail = b.cnt < MAXBITS ? b.cnt : MAXBITS;
-    for (int len = 1; len <= avail; ++len) {
+    for (int len = 1; len <= MAXBITS; ++len) {
         code |= (int)(buf & 1);
         buf >>= 1;
-        const int count = HC(h, len);
+        const int count = UNI(h.count[len]);
         if (code - count < first) {
             b.buf = buf;
             b.cnt -= len;
-            return HS(h, index + (code - first));
+            b.used += len;
+            return UNI(h.symbol[index + (code - first)]);
         }
         index += count;
         first += count;
@@ -102,151 +158,237 @@ __device__ __forceinline__ int decode_sym(Bits& b, const Huff& h) {
 
 // error codes written to status[]: 0 ok, 1 truncated input, 2 bad block type, 3 stored-length mismatch, 4 bad code lengths,
 // 5 invalid symbol / distance, 6 output overflow, 7 output short of H * (1 + 3 W)
-__global__ __launch_bounds__(PNG_THREADS) void png_inflate_kernel(const uint8_t* __restrict__ streams, const long long* __restrict__ offsets,
-                                                                   const int* __restrict__ lengths, uint8_t* __restrict__ raw, int B,
-                                                                   long long raw_stride, long long raw_len, int* __restrict__ status) {
-    __shared__ unsigned short lcount[(MAXBITS + 1) * PNG_THREADS], lsym[MAXL * PNG_THREADS];
-    __shared__ unsigned short dcount[(MAXBITS + 1) * PNG_THREADS], dsym[MAXD * PNG_THREADS];
-    const int t = threadIdx.x;
-    const int img = blockIdx.x * PNG_THREADS + t;
-    if (img >= B) return;
-    Huff lc{lcount + t, lsym + t}, dc{dcount + t, dsym + t};
+__global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restrict__ streams, const long long* __restrict__ offsets,
+                                                         const int* __restrict__ lengths, uint8_t* __restrict__ raw, int B, long long raw_stride,
+                                                         long long raw_len64, int* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t win[WIN];
+    __shared__ unsigned short lcount[MAXBITS + 1], lsym[MAXL], ltab[1 << LBITS];
+    __shared__ unsigned short dcount[MAXBITS + 1], dsym[MAXD], dtab[1 << DBITS];
+    __shared__ unsigned char lens[384];
+    __shared__ unsigned short s_lbase[32], s_dbase[32];
+    __shared__ unsigned char s_lext[32], s_dext[32];
+    const int lane = threadIdx.x;
+    const int img = blockIdx.x;
+    if (lane < 29) { s_lbase[lane] = kLenBase[lane]; s_lext[lane] = kLenExtra[lane]; }      // (as __device__ tables every match paid four memory round trips)
+    if (lane < 30) { s_dbase[lane] = kDistBase[lane]; s_dext[lane] = kDistExtra[lane]; }
+    __syncthreads();
+    Huff lc{lcount, lsym, ltab, LBITS}, dc{dcount, dsym, dtab, DBITS};
     Bits b;
-    b.p = streams + offsets[img];
-    b.end = b.p + lengths[img];
-    b.buf = 0; b.cnt = 0; b.bad = 0;
-    uint8_t* const out = raw + (long long)img * raw_stride;
-    long long pos = 0;
+    {
+        const uint8_t* p0 = streams + offsets[img];
+        const int mis = (int)((uintptr_t)p0 & 3);
+        b.base = (const uint32_t*)(p0 - mis);
+        b.nbits = (long long)lengths[img] * 8;
+        b.used = 0; b.buf = 0; b.cnt = 0; b.bad = 0; b.dw = 0; b.chunk0 = 0;
+        load_chunk(b, lane);
+        refill(b, lane);
+        b.buf >>= 8 * mis;           // bytes in front of the stream inside its first dword
+        b.cnt -= 8 * mis;
+    }
+    uint8_t* const out = raw + (long long)img * raw_stride;      // (16-byte aligned: raw_stride % 16 == 0, host-checked)
+    int pos = 0, flushed = 0;                 // (32-bit: raw_len < 2 GiB, host-checked; 64-bit compares have no scalar form)
+    const int raw_len = (int)raw_len64;
     int err = 0, last = 0;
-    unsigned char lens[MAXL + MAXD];
+    auto flush_to = [&](int upto) {       // window bytes [flushed, upto) -> memory; whole 16-byte vectors while they last
+        while (flushed + 16 * 64 <= upto) {
+            *(uint4*)(out + flushed + lane * 16) = *(const uint4*)(win + ((flushed + lane * 16) & (WIN - 1)));
+            flushed += 16 * 64;
+        }
+        for (int i = flushed + lane; i < upto; i += 64) out[i] = win[i & (WIN - 1)];
+        flushed = upto;
+    };
     while (!last && !err) {
-        last = (int)getbits(b, 1);
-        const int type = (int)getbits(b, 2);
-        if (b.bad) { err = 1; break; }
+        last = (int)getbits(b, 1, lane);
+        const int type = (int)getbits(b, 2, lane);
+        if (b.bad || b.used > b.nbits) { err = 1; break; }
         if (type == 0) {                       // stored
-            b.buf >>= (b.cnt & 7);
-            b.cnt -= (b.cnt & 7);
-            const unsigned len = getbits(b, 16), nlen = getbits(b, 16);
-            if (b.bad) { err = 1; break; }
+            const int drop = b.cnt & 7;          // to the next byte boundary of the stream
+            b.buf >>= drop; b.cnt -= drop; b.used += drop;
+            const unsigned len = getbits(b, 16, lane), nlen = getbits(b, 16, lane);
+            if (b.bad || b.used > b.nbits) { err = 1; break; }
             if ((len ^ 0xffffu) != nlen) { err = 3; break; }
             if (pos + len > raw_len) { err = 6; break; }
-            for (unsigned i = 0; i < len; ++i) {
-                const unsigned v = getbits(b, 8);
-                out[pos++] = (uint8_t)v;
+            if (b.used + 8ll * len > b.nbits) { err = 1; break; }
+            // the lanes copy the block from the stream (b.used is a whole number of bytes here), then the bit reader restarts behind it
+            const uint8_t* sp = (const uint8_t*)b.base + ((uintptr_t)(streams + offsets[img]) & 3) + (b.used >> 3);
+            unsigned done = 0;
+            while (done < len) {
+                const unsigned chunk = min(len - done, (unsigned)FLUSH);
+                for (unsigned i = lane; i < chunk; i += 64) win[(pos + i) & (WIN - 1)] = sp[done + i];
+                pos += chunk;
+                done += chunk;
+                __syncthreads();
+                if (pos - flushed >= FLUSH) flush_to(flushed + (pos - flushed) / FLUSH * FLUSH);      // (whole pieces: `flushed` stays 16-byte aligned)
+                __syncthreads();
             }
-            if (b.bad) { err = 1; break; }
+            b.used += 8ll * len;
+            {   // restart the bit reader at the byte behind the block
+                const long long byte = ((uintptr_t)(streams + offsets[img]) & 3) + (b.used >> 3);
+                b.dw = (int)(byte >> 2);
+                b.buf = 0; b.cnt = 0;
+                load_chunk(b, lane);
+                refill(b, lane);
+                const int mis2 = (int)(byte & 3);
+                b.buf >>= 8 * mis2;
+                b.cnt -= 8 * mis2;
+            }
             continue;
         }
         if (type == 3) { err = 2; break; }
         if (type == 1) {                       // fixed codes
-            int s = 0;
-            for (; s < 144; ++s) lens[s] = 8;
-            for (; s < 256; ++s) lens[s] = 9;
-            for (; s < 280; ++s) lens[s] = 7;
-            for (; s < 288; ++s) lens[s] = 8;
-            construct(lc, lens, 288);
-            for (s = 0; s < 30; ++s) lens[s] = 5;
-            construct(dc, lens, 30);
+            __syncthreads();
+            for (int s = lane; s < 288; s += 64) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            __syncthreads();
+            construct(lc, lens, 288, lane);
+            __syncthreads();
+            if (lane < 30) lens[lane] = 5;
+            __syncthreads();
+            construct(dc, lens, 30, lane);
         } else {                               // dynamic codes
-            const int nlen = (int)getbits(b, 5) + 257, ndist = (int)getbits(b, 5) + 1, ncode = (int)getbits(b, 4) + 4;
-            if (b.bad) { err = 1; break; }
+            const int nlen = (int)getbits(b, 5, lane) + 257, ndist = (int)getbits(b, 5, lane) + 1, ncode = (int)getbits(b, 4, lane) + 4;
+            if (b.bad || b.used > b.nbits) { err = 1; break; }
             if (nlen > 286 || ndist > 30) { err = 4; break; }
-            for (int i = 0; i < 19; ++i) lens[i] = 0;
-            for (int i = 0; i < ncode; ++i) lens[kClOrder[i]] = (unsigned char)getbits(b, 3);
-            if (construct(lc, lens, 19) != 0) { err = 4; break; }
-            int idx = 0;
+            __syncthreads();
+            if (lane < 19) lens[lane] = 0;
+            __syncthreads();
+            for (int i = 0; i < ncode; ++i) {
+                const unsigned v = getbits(b, 3, lane);
+                if (lane == 0) lens[kClOrder[i]] = (unsigned char)v;
+            }
+            __syncthreads();
+            if (construct(lc, lens, 19, lane) != 0) { err = 4; break; }
+            // the code lengths of both alphabets, run-length coded: decoded by every lane, kept in LDS behind the 19 entries in use
+            unsigned char* cl = lens + 24;
+            int idx = 0, prev = 0;
             while (idx < nlen + ndist) {
-                const int sym = decode_sym(b, lc);
+                const int sym = decode_sym(b, lc, lane);
                 if (sym < 0) { err = 1; break; }
-                if (sym < 16) { lens[idx++] = (unsigned char)sym; continue; }
+                if (sym < 16) {
+                    if (lane == 0) cl[idx] = (unsigned char)sym;
+                    prev = sym;
+                    ++idx;
+                    continue;
+                }
                 int rep, val = 0;
                 if (sym == 16) {
                     if (idx == 0) { err = 4; break; }
-                    val = lens[idx - 1];
-                    rep = 3 + (int)getbits(b, 2);
-                } else if (sym == 17) rep = 3 + (int)getbits(b, 3);
-                else rep = 11 + (int)getbits(b, 7);
+                    val = prev;
+                    rep = 3 + (int)getbits(b, 2, lane);
+                } else if (sym == 17) rep = 3 + (int)getbits(b, 3, lane);
+                else rep = 11 + (int)getbits(b, 7, lane);
                 if (idx + rep > nlen + ndist) { err = 4; break; }
-                while (rep--) lens[idx++] = (unsigned char)val;
+                for (int i = lane; i < rep; i += 64) cl[idx + i] = (unsigned char)val;
+                idx += rep;
+                prev = val;
             }
             if (err) break;
-            if (b.bad) { err = 1; break; }
-            if (lens[256] == 0) { err = 4; break; }
-            // (the code-length table is dead: build the literal / length table over it)
-            unsigned char dl[MAXD];
-            for (int i = 0; i < ndist; ++i) dl[i] = lens[nlen + i];
-            int r = construct(lc, lens, nlen);
-            if (r < 0 || (r > 0 && nlen - HC(lc, 0) != 1)) { err = 4; break; }
-            r = construct(dc, dl, ndist);
-            if (r < 0 || (r > 0 && ndist - HC(dc, 0) != 1)) { err = 4; break; }
+            if (b.bad || b.used > b.nbits) { err = 1; break; }
+            __syncthreads();
+            if (UNI(cl[256]) == 0) { err = 4; break; }
+            // (cl sits at lens + 24: move it down to lens[0..nlen) and the distance lengths behind it, 8-byte apart from the code-length use)
+            unsigned char mine[6];
+            const int total = nlen + ndist;
+            for (int k = 0; k < 6; ++k) mine[k] = (lane + 64 * k) < total ? cl[lane + 64 * k] : 0;
+            __syncthreads();
+            for (int k = 0; k < 6; ++k) if ((lane + 64 * k) < total) lens[lane + 64 * k] = mine[k];
+            __syncthreads();
+            int r = construct(lc, lens, nlen, lane);
+            if (r < 0 || (r > 0 && nlen - UNI(lc.count[0]) != 1)) { err = 4; break; }
+            r = construct(dc, lens + nlen, ndist, lane);
+            if (r < 0 || (r > 0 && ndist - UNI(dc.count[0]) != 1)) { err = 4; break; }
         }
         // literal / length + distance codes of the block
         for (;;) {
-            int sym = decode_sym(b, lc);
+            int sym = decode_sym(b, lc, lane);
             if (sym < 0) { err = 1; break; }
             if (sym < 256) {
                 if (pos >= raw_len) { err = 6; break; }
-                out[pos++] = (uint8_t)sym;
-                continue;
+                if (lane == 0) win[pos & (WIN - 1)] = (uint8_t)sym;
+                ++pos;
+            } else {
+                if (sym == 256) break;
+                sym -= 257;
+                if (sym >= 29) { err = 5; break; }
+                const int len = UNI(s_lbase[sym]) + (int)getbits(b, UNI(s_lext[sym]), lane);
+                const int ds = decode_sym(b, dc, lane);
+                if (ds < 0) { err = 1; break; }
+                if (ds >= 30) { err = 5; break; }
+                const int dist = UNI(s_dbase[ds]) + (int)getbits(b, UNI(s_dext[ds]), lane);
+                if (b.bad || b.used > b.nbits) { err = 1; break; }
+                if (dist > pos) { err = 5; break; }
+                if (pos + len > raw_len) { err = 6; break; }
+                // the lanes copy the match inside the window; an overlapping match (dist < len) repeats its first dist bytes
+                if (dist >= len) {
+                    for (int i = lane; i < len; i += 64) win[(pos + i) & (WIN - 1)] = win[(pos - dist + i) & (WIN - 1)];
+                } else {
+                    for (int i = lane; i < len; i += 64) win[(pos + i) & (WIN - 1)] = win[(pos - dist + (i % dist)) & (WIN - 1)];
+                }
+                pos += len;
             }
-            if (sym == 256) break;
-            sym -= 257;
-            if (sym >= 29) { err = 5; break; }
-            const int len = kLenBase[sym] + (int)getbits(b, kLenExtra[sym]);
-            const int ds = decode_sym(b, dc);
-            if (ds < 0) { err = 1; break; }
-            if (ds >= 30) { err = 5; break; }
-            const long long dist = kDistBase[ds] + (long long)getbits(b, kDistExtra[ds]);
-            if (b.bad) { err = 1; break; }
-            if (dist > pos) { err = 5; break; }
-            if (pos + len > raw_len) { err = 6; break; }
-            const uint8_t* src = out + pos - dist;
-            for (int i = 0; i < len; ++i) out[pos + i] = src[i];      // (overlapping copies repeat the pattern, byte by byte as DEFLATE defines)
-            pos += len;
+            if (pos - flushed >= FLUSH) {
+                __syncthreads();
+                flush_to(flushed + FLUSH);
+                __syncthreads();
+            }
         }
     }
+    __syncthreads();
+    if (!err) flush_to(pos);
+    if (!err && b.used > b.nbits) err = 1;
     if (!err && pos != raw_len) err = 7;
-    status[img] = err;
+    if (lane == 0) status[img] = err;
 }
 
-// PNG filters, 8-bit RGB (bytes per pixel = 3): raw row = filter type + 3 W bytes.  One thread per (frame, channel): the Sub / Average /
-// Paeth predictors chain along the row per channel, every row needs the finished row above.
-__global__ void png_unfilter_rgb8_kernel(const uint8_t* __restrict__ raw, uint8_t* __restrict__ out, int B, int H, int W, long long raw_stride,
-                                         int* __restrict__ status) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * 3) return;
-    const int img = idx / 3, c = idx - img * 3;
+// PNG filters, 8-bit RGB (bytes per pixel = 3): raw row = filter type + 3 W bytes.  One wave per frame; the raw row and the two decoded rows
+// (previous, current) live in LDS.
+constexpr int UNF_MAXROW = 3 * 4096;
+__global__ __launch_bounds__(64) void png_unfilter_rgb8_kernel(const uint8_t* __restrict__ raw, uint8_t* __restrict__ out, int B, int H, int W,
+                                                               long long raw_stride, int* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t rrow[UNF_MAXROW + 16], rows[2][UNF_MAXROW + 16];
+    const int lane = threadIdx.x, img = blockIdx.x;
     const uint8_t* r = raw + (long long)img * raw_stride;
     uint8_t* o = out + (long long)img * H * W * 3;
-    const int rowb = 1 + 3 * W;
+    const int nb = 3 * W, rowb = 1 + nb;
     int bad = 0;
     for (int y = 0; y < H; ++y) {
-        const uint8_t* row = r + (long long)y * rowb;
-        const int ft = row[0];
-        uint8_t* cur = o + (long long)y * W * 3;
-        const uint8_t* up = y ? cur - W * 3 : nullptr;
-        int left = 0, upleft = 0;
-        if (ft > 4) bad = 1;
-        for (int x = 0; x < W; ++x) {
-            const int v = row[1 + 3 * x + c];
-            const int a = left, bb = up ? up[3 * x + c] : 0, cc = upleft;
-            int pred;
-            if (ft == 0) pred = 0;
-            else if (ft == 1) pred = a;
-            else if (ft == 2) pred = bb;
-            else if (ft == 3) pred = (a + bb) >> 1;
-            else {
-                const int p = a + bb - cc;
-                const int pa = abs(p - a), pb = abs(p - bb), pc = abs(p - cc);
-                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : cc);
+        const uint8_t* src = r + (long long)y * rowb;
+        uint8_t* cur = rows[y & 1];
+        const uint8_t* up = rows[(y & 1) ^ 1];
+        const int ft = src[0];
+        for (int i = lane; i < nb; i += 64) rrow[i] = src[1 + i];
+        __syncthreads();
+        if (ft == 0) {
+            for (int i = lane; i < nb; i += 64) cur[i] = rrow[i];
+        } else if (ft == 2) {
+            for (int i = lane; i < nb; i += 64) cur[i] = (uint8_t)(rrow[i] + (y ? up[i] : 0));
+        } else if (ft <= 4) {
+            if (lane < 3) {
+                int left = 0, upleft = 0;
+                for (int x = 0; x < W; ++x) {
+                    const int i = 3 * x + lane;
+                    const int v = rrow[i], a = left, bb = y ? up[i] : 0, cc = upleft;
+                    int pred;
+                    if (ft == 1) pred = a;
+                    else if (ft == 3) pred = (a + bb) >> 1;
+                    else {
+                        const int p = a + bb - cc;
+                        const int pa = abs(p - a), pb = abs(p - bb), pc = abs(p - cc);
+                        pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : cc);
+                    }
+                    const int px = (v + pred) & 255;
+                    cur[i] = (uint8_t)px;
+                    left = px;
+                    upleft = bb;
+                }
             }
-            const int px = (v + pred) & 255;
-            cur[3 * x + c] = (uint8_t)px;
-            left = px;
-            upleft = bb;
+        } else {
+            bad = 1;
         }
+        __syncthreads();
+        uint8_t* dst = o + (long long)y * nb;
+        for (int i = lane; i < nb; i += 64) dst[i] = cur[i];
     }
-    if (bad && c == 0) status[img] = 8;     // unknown filter type
+    if (bad && lane == 0) status[img] = 8;     // unknown filter type
 }
 
 }  // namespace
@@ -258,8 +400,10 @@ extern "C" int mt4_png_inflate(const uint8_t* streams, const int64_t* offsets, c
                                int64_t raw_stride, int64_t raw_len, int32_t* status, void* stream) {
     mt4_clear_error();
     if (!streams || !offsets || !lengths || !raw || !status || B <= 0 || raw_len <= 0 || raw_stride < raw_len) return MT4_EINVAL;
-    hipLaunchKernelGGL(png_inflate_kernel, dim3((unsigned)((B + PNG_THREADS - 1) / PNG_THREADS)), dim3(PNG_THREADS), 0, (hipStream_t)stream, streams,
-                       (const long long*)offsets, (const int*)lengths, raw, B, (long long)raw_stride, (long long)raw_len, status);
+    if (raw_len >= 0x7fffff00LL) return MT4_EUNSUPPORTED;
+    if ((raw_stride & 15) || ((uintptr_t)raw & 15)) return MT4_EALIGN;
+    hipLaunchKernelGGL(png_inflate_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, streams, (const long long*)offsets, (const int*)lengths,
+                       raw, B, (long long)raw_stride, (long long)raw_len, status);
     return mt4_check_launch();
 }
 
@@ -268,8 +412,7 @@ extern "C" int mt4_png_unfilter_rgb8(const uint8_t* raw, uint8_t* out, int32_t B
                                      void* stream) {
     mt4_clear_error();
     if (!raw || !out || !status || B <= 0 || H <= 0 || W <= 0 || raw_stride < (int64_t)H * (1 + 3 * W)) return MT4_EINVAL;
-    const int n = B * 3;
-    hipLaunchKernelGGL(png_unfilter_rgb8_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, raw, out, B, H, W,
-                       (long long)raw_stride, status);
+    if (3 * W > UNF_MAXROW) return MT4_EUNSUPPORTED;
+    hipLaunchKernelGGL(png_unfilter_rgb8_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, raw, out, B, H, W, (long long)raw_stride, status);
     return mt4_check_launch();
 }

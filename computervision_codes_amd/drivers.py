@@ -38,6 +38,8 @@ def _common(p: argparse.ArgumentParser):
     p.add_argument("--dtype", type=str, default="fp32", choices=["fp32", "bf16"])
     p.add_argument("--device_batch", type=int, default=512, help="frames per extraction pass on the GPU (results do not depend on it)")
     p.add_argument("--decode_workers", type=int, default=8, help="host threads decoding PNGs")
+    p.add_argument("--png_decode", type=str, default="host", choices=["host", "device"],
+                   help="device: inflate + PNG unfiltering on the GPU (mt4_png_inflate / mt4_png_unfilter_rgb8), the host only reads the files")
 
 
 def _dist():
@@ -92,7 +94,7 @@ def spatial_cnn_test(argv=None) -> Dict[str, np.ndarray]:
         lab = labels[v]
         ids_all = lab["ivt"][:, 0]                             # file order, no shuffle, drop_last False (`test.py:227-242`)
         load = lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.image_height, F.image_width,   # decode on the
-                                                       workers=F.decode_workers)                                # host, Resize on the GPU
+                                                       workers=F.decode_workers, decode=F.png_decode)          # host (or device), Resize on the GPU
         feat, lgs = extract.extract_video_device(model, len(ids_all), load, F.device_batch)
         for key, lg in zip(("i", "v", "t", "ivt"), lgs):
             m[key].update(lab[key][:, 1:], torch.sigmoid(torch.from_numpy(lg)).numpy())   # `test.py:162-169`

@@ -70,3 +70,5 @@ def test_device_frame_loader_equals_host_loader(cuda, tmp_path):
     ref = cholect.load_frames_u8(str(tmp_path), "VID01", ids, 64, 96)
     got = cholect.load_frames_device(str(tmp_path), "VID01", ids, 64, 96, device=cuda)
     assert got.dtype == torch.uint8 and tuple(got.shape) == ref.shape and np.array_equal(got.cpu().numpy(), ref)
+    dev = cholect.load_frames_device(str(tmp_path), "VID01", ids, 64, 96, device=cuda, decode="device")      # inflate + unfilter on the GPU too
+    assert dev.dtype == torch.uint8 and np.array_equal(dev.cpu().numpy(), ref)
