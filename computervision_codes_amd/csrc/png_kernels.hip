@@ -31,8 +31,8 @@ __device__ const unsigned char kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5,
 // symbol's time).  Everything else is identical in every lane.
 struct Bits {
     const uint32_t* base;      // aligned dword that holds the first byte of the stream
-    long long nbits;           // bits in the stream
-    long long used;            // bits consumed so far (> nbits: the stream was truncated)
+    int nbits;                 // bits in the stream (< 2^31: host-checked)
+    int mis;                   // bytes in front of the stream inside base[0]
     unsigned long long buf;
     int cnt;
     int dw;                    // index (from base) of the next dword to take
@@ -58,14 +58,25 @@ __device__ __forceinline__ void refill(Bits& b, int lane) {
     }
 }
 
+// bits of the stream consumed so far (derived, not maintained: the per-symbol path carries as little state as it can -- a wave issues one
+// instruction every 4-5 cycles, the instruction count of the literal loop IS its time)
+__device__ __forceinline__ int bits_used(const Bits& b) { return 32 * b.dw - b.cnt - 8 * b.mis; }
+
 __device__ __forceinline__ unsigned getbits(Bits& b, int n, int lane) {   // n <= 16
     refill(b, lane);
     const unsigned v = (unsigned)(b.buf & ((1ull << n) - 1));
     b.buf >>= n;
     b.cnt -= n;
-    b.used += n;
     return v;
 }
+
+// the wave's LDS (one wave per workgroup)
+__shared__ __attribute__((aligned(16))) uint8_t g_win[WIN];
+__shared__ unsigned short g_lcount[MAXBITS + 1], g_lsym[MAXL], g_ltab[1 << LBITS];
+__shared__ unsigned short g_dcount[MAXBITS + 1], g_dsym[MAXD], g_dtab[1 << DBITS];
+__shared__ unsigned char g_lens[384];
+__shared__ unsigned short s_lbase[32], s_dbase[32];
+__shared__ unsigned char s_lext[32], s_dext[32];
 
 // canonical Huffman code of one alphabet, in LDS: count[len], symbols sorted by (length, value), first-level lookup table
 struct Huff {
@@ -82,7 +93,10 @@ __device__ __forceinline__ unsigned rev_bits(unsigned c, int len) { return __bre
 
 // from the code lengths lens[0..n) (LDS): counts, sorted symbols, lookup table.  Called by the whole wave; returns (uniformly) < 0 for an
 // over-subscribed set, > 0 for an incomplete one, 0 for a complete one.
-__device__ int construct(Huff& h, const unsigned char* lens, int n, int lane) {
+// (not inlined: five call sites, and inlined its loops kept the kernel's scalar registers spilling into vector lanes on the per-symbol path)
+__device__ __noinline__ int construct(int which, int lens_off, int n, int lane) {
+    Huff h = which ? Huff{g_dcount, g_dsym, g_dtab, DBITS} : Huff{g_lcount, g_lsym, g_ltab, LBITS};
+    const unsigned char* lens = g_lens + lens_off;
     __syncthreads();          // (single-wave block: orders the LDS traffic of the previous user of these arrays)
     if (lane <= MAXBITS) h.count[lane] = 0;
     for (int i = lane; i < (1 << h.tbits); i += 64) h.tab[i] = 0;
@@ -132,7 +146,6 @@ __device__ __forceinline__ int decode_sym(Bits& b, const Huff& h, int lane) {
         const int elen = e >> 9;
         b.buf >>= elen;
         b.cnt -= elen;
-        b.used += elen;
         return e & 511;
     }
     int code = 0, first = 0, index = 0;      // a code longer than the table's index: canonical decode by length
@@ -144,7 +157,6 @@ __device__ __forceinline__ int decode_sym(Bits& b, const Huff& h, int lane) {
         if (code - count < first) {
             b.buf = buf;
             b.cnt -= len;
-            b.used += len;
             return UNI(h.symbol[index + (code - first)]);
         }
         index += count;
@@ -161,25 +173,21 @@ __device__ __forceinline__ int decode_sym(Bits& b, const Huff& h, int lane) {
 __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restrict__ streams, const long long* __restrict__ offsets,
                                                          const int* __restrict__ lengths, uint8_t* __restrict__ raw, int B, long long raw_stride,
                                                          long long raw_len64, int* __restrict__ status) {
-    __shared__ __attribute__((aligned(16))) uint8_t win[WIN];
-    __shared__ unsigned short lcount[MAXBITS + 1], lsym[MAXL], ltab[1 << LBITS];
-    __shared__ unsigned short dcount[MAXBITS + 1], dsym[MAXD], dtab[1 << DBITS];
-    __shared__ unsigned char lens[384];
-    __shared__ unsigned short s_lbase[32], s_dbase[32];
-    __shared__ unsigned char s_lext[32], s_dext[32];
+    uint8_t* const win = g_win;
+    unsigned char* const lens = g_lens;
     const int lane = threadIdx.x;
     const int img = blockIdx.x;
     if (lane < 29) { s_lbase[lane] = kLenBase[lane]; s_lext[lane] = kLenExtra[lane]; }      // (as __device__ tables every match paid four memory round trips)
     if (lane < 30) { s_dbase[lane] = kDistBase[lane]; s_dext[lane] = kDistExtra[lane]; }
     __syncthreads();
-    Huff lc{lcount, lsym, ltab, LBITS}, dc{dcount, dsym, dtab, DBITS};
+    const Huff lc{g_lcount, g_lsym, g_ltab, LBITS}, dc{g_dcount, g_dsym, g_dtab, DBITS};
     Bits b;
     {
         const uint8_t* p0 = streams + offsets[img];
         const int mis = (int)((uintptr_t)p0 & 3);
         b.base = (const uint32_t*)(p0 - mis);
-        b.nbits = (long long)lengths[img] * 8;
-        b.used = 0; b.buf = 0; b.cnt = 0; b.bad = 0; b.dw = 0; b.chunk0 = 0;
+        b.nbits = lengths[img] * 8;
+        b.mis = mis; b.buf = 0; b.cnt = 0; b.bad = 0; b.dw = 0; b.chunk0 = 0;
         load_chunk(b, lane);
         refill(b, lane);
         b.buf >>= 8 * mis;           // bytes in front of the stream inside its first dword
@@ -200,17 +208,18 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
     while (!last && !err) {
         last = (int)getbits(b, 1, lane);
         const int type = (int)getbits(b, 2, lane);
-        if (b.bad || b.used > b.nbits) { err = 1; break; }
+        if (b.bad || bits_used(b) > b.nbits) { err = 1; break; }
         if (type == 0) {                       // stored
             const int drop = b.cnt & 7;          // to the next byte boundary of the stream
-            b.buf >>= drop; b.cnt -= drop; b.used += drop;
+            b.buf >>= drop; b.cnt -= drop;
             const unsigned len = getbits(b, 16, lane), nlen = getbits(b, 16, lane);
-            if (b.bad || b.used > b.nbits) { err = 1; break; }
+            if (b.bad || bits_used(b) > b.nbits) { err = 1; break; }
             if ((len ^ 0xffffu) != nlen) { err = 3; break; }
-            if (pos + len > raw_len) { err = 6; break; }
-            if (b.used + 8ll * len > b.nbits) { err = 1; break; }
-            // the lanes copy the block from the stream (b.used is a whole number of bytes here), then the bit reader restarts behind it
-            const uint8_t* sp = (const uint8_t*)b.base + ((uintptr_t)(streams + offsets[img]) & 3) + (b.used >> 3);
+            if (pos + (int)len > raw_len) { err = 6; break; }
+            const int used = bits_used(b);       // (a whole number of bytes here)
+            if (used + 8 * (int)len > b.nbits) { err = 1; break; }
+            // the lanes copy the block from the stream, then the bit reader restarts behind it
+            const uint8_t* sp = (const uint8_t*)b.base + b.mis + (used >> 3);
             unsigned done = 0;
             while (done < len) {
                 const unsigned chunk = min(len - done, (unsigned)FLUSH);
@@ -221,14 +230,13 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 if (pos - flushed >= FLUSH) flush_to(flushed + (pos - flushed) / FLUSH * FLUSH);      // (whole pieces: `flushed` stays 16-byte aligned)
                 __syncthreads();
             }
-            b.used += 8ll * len;
             {   // restart the bit reader at the byte behind the block
-                const long long byte = ((uintptr_t)(streams + offsets[img]) & 3) + (b.used >> 3);
-                b.dw = (int)(byte >> 2);
+                const int byte = b.mis + (used >> 3) + (int)len;
+                b.dw = byte >> 2;
                 b.buf = 0; b.cnt = 0;
                 load_chunk(b, lane);
                 refill(b, lane);
-                const int mis2 = (int)(byte & 3);
+                const int mis2 = byte & 3;
                 b.buf >>= 8 * mis2;
                 b.cnt -= 8 * mis2;
             }
@@ -239,14 +247,14 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
             __syncthreads();
             for (int s = lane; s < 288; s += 64) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
             __syncthreads();
-            construct(lc, lens, 288, lane);
+            construct(0, 0, 288, lane);
             __syncthreads();
             if (lane < 30) lens[lane] = 5;
             __syncthreads();
-            construct(dc, lens, 30, lane);
+            construct(1, 0, 30, lane);
         } else {                               // dynamic codes
             const int nlen = (int)getbits(b, 5, lane) + 257, ndist = (int)getbits(b, 5, lane) + 1, ncode = (int)getbits(b, 4, lane) + 4;
-            if (b.bad || b.used > b.nbits) { err = 1; break; }
+            if (b.bad || bits_used(b) > b.nbits) { err = 1; break; }
             if (nlen > 286 || ndist > 30) { err = 4; break; }
             __syncthreads();
             if (lane < 19) lens[lane] = 0;
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 if (lane == 0) lens[kClOrder[i]] = (unsigned char)v;
             }
             __syncthreads();
-            if (construct(lc, lens, 19, lane) != 0) { err = 4; break; }
+            if (construct(0, 0, 19, lane) != 0) { err = 4; break; }
             // the code lengths of both alphabets, run-length coded: decoded by every lane, kept in LDS behind the 19 entries in use
             unsigned char* cl = lens + 24;
             int idx = 0, prev = 0;
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 prev = val;
             }
             if (err) break;
-            if (b.bad || b.used > b.nbits) { err = 1; break; }
+            if (b.bad || bits_used(b) > b.nbits) { err = 1; break; }
             __syncthreads();
             if (UNI(cl[256]) == 0) { err = 4; break; }
             // (cl sits at lens + 24: move it down to lens[0..nlen) and the distance lengths behind it, 8-byte apart from the code-length use)
@@ -292,13 +300,32 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
             __syncthreads();
             for (int k = 0; k < 6; ++k) if ((lane + 64 * k) < total) lens[lane + 64 * k] = mine[k];
             __syncthreads();
-            int r = construct(lc, lens, nlen, lane);
+            int r = construct(0, 0, nlen, lane);
             if (r < 0 || (r > 0 && nlen - UNI(lc.count[0]) != 1)) { err = 4; break; }
-            r = construct(dc, lens + nlen, ndist, lane);
+            r = construct(1, nlen, ndist, lane);
             if (r < 0 || (r > 0 && ndist - UNI(dc.count[0]) != 1)) { err = 4; break; }
         }
         // literal / length + distance codes of the block
         for (;;) {
+            {   // run of literals: one table read, one window write, a handful of scalar instructions each; leaves the loop on anything else (a
+                // length code, a code longer than the table's index, the end of the block, the flush point, the end of the output)
+                const int limit = min(raw_len, flushed + FLUSH);
+                for (;;) {
+                    refill(b, lane);
+                    const int e = UNI(g_ltab[b.buf & ((1u << LBITS) - 1)]);
+                    if (e == 0 || (e & 256) || pos >= limit) break;
+                    if (lane == 0) win[pos & (WIN - 1)] = (uint8_t)e;
+                    ++pos;
+                    b.buf >>= (e >> 9);
+                    b.cnt -= (e >> 9);
+                }
+                if (pos >= limit && pos < raw_len) {        // flush point
+                    __syncthreads();
+                    flush_to(flushed + FLUSH);
+                    __syncthreads();
+                    continue;
+                }
+            }
             int sym = decode_sym(b, lc, lane);
             if (sym < 0) { err = 1; break; }
             if (sym < 256) {
@@ -314,7 +341,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 if (ds < 0) { err = 1; break; }
                 if (ds >= 30) { err = 5; break; }
                 const int dist = UNI(s_dbase[ds]) + (int)getbits(b, UNI(s_dext[ds]), lane);
-                if (b.bad || b.used > b.nbits) { err = 1; break; }
+                if (b.bad || bits_used(b) > b.nbits) { err = 1; break; }
                 if (dist > pos) { err = 5; break; }
                 if (pos + len > raw_len) { err = 6; break; }
                 // the lanes copy the match inside the window; an overlapping match (dist < len) repeats its first dist bytes
@@ -334,7 +361,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
     }
     __syncthreads();
     if (!err) flush_to(pos);
-    if (!err && b.used > b.nbits) err = 1;
+    if (!err && bits_used(b) > b.nbits) err = 1;
     if (!err && pos != raw_len) err = 7;
     if (lane == 0) status[img] = err;
 }
