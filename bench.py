@@ -388,7 +388,44 @@ def e2e_script_bench(dev):
                 includes="preprocess + trunk + heads + D2H of features and logits (pinned, once per video) + sync",
                 excludes="PNG decode and H2D of the frames (host side)")
             del m
+    out["png_decode_480x854"] = png_decode_bench(dev)
     return out
+
+
+def png_decode_bench(dev, n=1024):
+    """the stage in front of the extractor on real data: PNG files -> uint8 frames on the device (`pngdec.decode_batch`: the host walks the chunk
+    lists and uploads the compressed bytes, inflate + unfiltering run in HIP).  16 distinct synthetic frames of the dataset's native 480 x 854
+    (smooth structure + sensor-like noise: ~650 KB per PNG), repeated to n per call; kernel time from HIP events, wall time incl. the host part."""
+    import io
+    try:
+        from PIL import Image
+    except Exception:
+        return None
+    from computervision_codes_amd import pngdec
+    h, w = 480, 854
+    rng = np.random.default_rng(0)
+    y, x = np.mgrid[0:h, 0:w]
+    files = []
+    for i in range(16):
+        base = (np.stack([(x + 7 * i) % 256, (y * 2 + 3 * i) % 256, ((x + y) // 2) % 256], -1)).astype(np.int32)
+        blobs = 40 * np.sin(x[..., None] / (17.0 + i) + np.arange(3)) * np.cos(y[..., None] / (23.0 + i))
+        fr = np.clip(base * 0.5 + 60 + blobs + rng.normal(0, 3.0, (h, w, 3)), 0, 255).astype(np.uint8)
+        b = io.BytesIO()
+        Image.fromarray(fr, "RGB").save(b, format="PNG")
+        files.append(b.getvalue())
+    files = [files[i % 16] for i in range(n)]
+    pngdec.decode_batch(files[:64], dev)
+    torch.cuda.synchronize()
+    tm = {}
+    t0 = time.perf_counter()
+    out = pngdec.decode_batch(files, dev, timings=tm)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    assert tuple(out.shape) == (n, h, w, 3)
+    gpu_ms = tm["inflate_ms"] + tm["unfilter_ms"]
+    return dict(frames_per_s_gpu_time=round(n / gpu_ms * 1e3, 1), frames_per_s_wall=round(n / wall, 1), frames_per_call=n, kb_per_png=round(sum(map(len, files)) / n / 1e3),
+                inflate_ms=round(tm["inflate_ms"], 2), unfilter_ms=round(tm["unfilter_ms"], 2),
+                note="wall = host chunk walk + gather + upload of the compressed bytes (one thread) + the two launches; the extraction records above start from decoded frames")
 
 
 def spatial_train_bench(dev):
