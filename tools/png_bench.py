@@ -20,7 +20,7 @@ for i in range(16):      # 16 distinct synthetic "video frames": smooth structur
 files = [files[i % 16] for i in range(n)]
 print(f"{n} frames of {h}x{w}, {sum(map(len, files)) / n / 1e3:.0f} KB per PNG", flush=True)
 dev = torch.device("cuda:0")
-out = pngdec.decode_batch(files[:16], dev); torch.cuda.synchronize()
+out = pngdec.decode_batch(files, dev); torch.cuda.synchronize()      # (first call: page-locks the staging buffer)
 tm = {}
 t0 = time.perf_counter(); out = pngdec.decode_batch(files, dev, timings=tm); torch.cuda.synchronize(); t1 = time.perf_counter()
 print(f"device decode (parse + H2D of the compressed bytes + inflate + unfilter): {n / (t1 - t0):.0f} frames/s ({(t1 - t0) * 1e3:.1f} ms; "
