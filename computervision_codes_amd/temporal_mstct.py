@@ -74,7 +74,10 @@ class VideoNas:
             for b in range(self.num_block):
                 q = f"TemporalEncoder.block{s}.{b}"
                 g, l = q + ".Global_Relational_Block", q + ".Local_Relational_Block"
-                st["blocks"].append(dict(n1=ln(q + ".norm1"), n2=ln(q + ".norm2"), q=lin(g + ".q"), kv=lin(g + ".kv"), proj=lin(g + ".proj"),
+                # q and kv (`Temporal_Encoder.py:80-84`: two nn.Linear on the same normalised input) as ONE GEMM over the stacked weights
+                qkv = (ops.pack_linear_weight(torch.cat([sd[g + ".q.weight"], sd[g + ".kv.weight"]], 0).to(dev), dt),
+                       torch.cat([sd[g + ".q.bias"], sd[g + ".kv.bias"]], 0).to(dev).contiguous())
+                st["blocks"].append(dict(n1=ln(q + ".norm1"), n2=ln(q + ".norm2"), qkv=qkv, proj=lin(g + ".proj"),
                                          l1=lin(l + ".linear1"), l2=lin(l + ".linear2"),
                                          tc=(sd[l + ".TC.weight"][:, 0, :].to(dev).contiguous(), sd[l + ".TC.bias"].to(dev).contiguous())))
             p["stages"].append(st)
@@ -93,11 +96,10 @@ class VideoNas:
 
     def _block(self, x, blk, b, t, c):
         y = ops.layernorm(x, *blk["n1"])
-        q = ops.linear(y, *blk["q"])
-        kv = ops.linear(y, *blk["kv"])
+        qkv = ops.linear(y, *blk["qkv"])                                  # [B*T, 3C]: q | k | v column slices
         hd = c // self.head
-        a = ops.attention(q, kv[:, :c], kv[:, c:], batch=b, heads=self.head, nq=t, nk=t, hd=hd, q_stride=c, k_stride=2 * c, v_stride=2 * c,
-                          scale=hd ** -0.5)
+        a = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch=b, heads=self.head, nq=t, nk=t, hd=hd, q_stride=3 * c, k_stride=3 * c,
+                          v_stride=3 * c, scale=hd ** -0.5)
         x = ops.linear(a, *blk["proj"], residual=x)
         y = ops.layernorm(x, *blk["n2"])
         h = ops.linear(y, *blk["l1"])
