@@ -264,7 +264,8 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 if (lane == 0) lens[kClOrder[i]] = (unsigned char)v;
             }
             __syncthreads();
-            if (construct(0, 0, 19, lane) != 0) { err = 4; break; }
+            if (UNI(construct(0, 0, 19, lane)) != 0) { err = 4; break; }      // (a call's result counts as divergent unless told otherwise -- and a
+                                                                                   //  divergent loop exit drags the whole bit-stream state into vector registers)
             // the code lengths of both alphabets, run-length coded: decoded by every lane, kept in LDS behind the 19 entries in use
             unsigned char* cl = lens + 24;
             int idx = 0, prev = 0;
@@ -300,9 +301,9 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
             __syncthreads();
             for (int k = 0; k < 6; ++k) if ((lane + 64 * k) < total) lens[lane + 64 * k] = mine[k];
             __syncthreads();
-            int r = construct(0, 0, nlen, lane);
+            int r = UNI(construct(0, 0, nlen, lane));
             if (r < 0 || (r > 0 && nlen - UNI(lc.count[0]) != 1)) { err = 4; break; }
-            r = construct(1, nlen, ndist, lane);
+            r = UNI(construct(1, nlen, ndist, lane));
             if (r < 0 || (r > 0 && ndist - UNI(dc.count[0]) != 1)) { err = 4; break; }
         }
         // literal / length + distance codes of the block
