@@ -61,6 +61,9 @@ def load_labels(data_dir: str, video: str) -> Dict[str, np.ndarray]:
     return out
 
 
+_WARNED_PNG = False
+
+
 def load_frames_u8(data_dir: str, video: str, frame_ids, height: int = 256, width: int = 448) -> np.ndarray:
     """decode + `Resize((height,width))` (bilinear, as torchvision does on PIL images; `dataloader.py:155-159`) -> uint8 [N,H,W,3]"""
     from PIL import Image
@@ -94,16 +97,24 @@ def load_frames_device(data_dir: str, video: str, frame_ids, height: int = 256, 
         for fid in frame_ids:
             with open(os.path.join(data_dir, "data", video, "{}.png".format(str(int(fid)).zfill(6))), "rb") as fh:
                 files.append(fh.read())
-        sizes: Dict[tuple, List[int]] = {}
-        for i, f in enumerate(files):
-            w0, h0, _ = pngdec._idat_spans(f)
-            sizes.setdefault((h0, w0), []).append(i)
-        out = torch.empty((len(files), height, width, 3), dtype=torch.uint8, device=device)
-        for (h0, w0), idx in sizes.items():
-            x = pngdec.decode_batch([files[i] for i in idx], device)
-            y = x if (h0, w0) == (height, width) else ops.resize_bilinear_u8(x, height, width)
-            out[torch.tensor(idx, device=device)] = y
-        return out
+        try:
+            sizes: Dict[tuple, List[int]] = {}
+            for i, f in enumerate(files):
+                w0, h0, _ = pngdec._idat_spans(f)
+                sizes.setdefault((h0, w0), []).append(i)
+            out = torch.empty((len(files), height, width, 3), dtype=torch.uint8, device=device)
+            for (h0, w0), idx in sizes.items():
+                x = pngdec.decode_batch([files[i] for i in idx], device)
+                y = x if (h0, w0) == (height, width) else ops.resize_bilinear_u8(x, height, width)
+                out[torch.tensor(idx, device=device)] = y
+            return out
+        except pngdec.UnsupportedPng as e:
+            # a PNG flavour the device decoder does not cover (palette, grey, alpha, 16-bit, interlaced): this batch goes through Pillow; said once
+            global _WARNED_PNG
+            if not _WARNED_PNG:
+                print(f"[cholect] --png_decode device: {e}; such files are decoded by Pillow on the host", flush=True)
+                _WARNED_PNG = True
+            decode = "host"
     assert decode == "host"
 
     def decode_one(fid):

@@ -72,3 +72,8 @@ def test_device_frame_loader_equals_host_loader(cuda, tmp_path):
     assert got.dtype == torch.uint8 and tuple(got.shape) == ref.shape and np.array_equal(got.cpu().numpy(), ref)
     dev = cholect.load_frames_device(str(tmp_path), "VID01", ids, 64, 96, device=cuda, decode="device")      # inflate + unfilter on the GPU too
     assert dev.dtype == torch.uint8 and np.array_equal(dev.cpu().numpy(), ref)
+    Image.fromarray(rng.integers(0, 256, (64, 96), dtype=np.uint8), "L").save(d / "000005.png")     # a grey-scale file: not covered by the device
+    ids6 = ids + [5]                                                                                    # decoder -> that batch falls back to Pillow
+    ref6 = cholect.load_frames_u8(str(tmp_path), "VID01", ids6, 64, 96)
+    dev6 = cholect.load_frames_device(str(tmp_path), "VID01", ids6, 64, 96, device=cuda, decode="device")
+    assert np.array_equal(dev6.cpu().numpy(), ref6)
