@@ -384,10 +384,14 @@ def spatial_transformer_test(argv=None) -> Dict[str, np.ndarray]:
     for vi in mine:
         v, chunks = videos[vi], []
         ids_all = labels[v]["ivt"][:, 0]
-        for s in range(0, len(ids_all), F.batch):
-            fr = cholect.load_frames_device(F.data_dir, v, ids_all[s:s + F.batch], F.img_size, F.img_size)
-            chunks.append(model(fr)[3][0].float().cpu())
-        feats_local[featfile.video_key(v, "transformer")] = torch.vstack(chunks).numpy()
+        # device batches (a frame's feature does not depend on the batch it rides in), decode on --decode_workers threads (or on the device), the
+        # video's features stay on the GPU until its end: one D2H per video instead of one synchronous copy per --batch frames (`test.py:357-376`)
+        step = max(1, min(F.device_batch, 256))
+        for s in range(0, len(ids_all), step):
+            fr = cholect.load_frames_device(F.data_dir, v, ids_all[s:s + step], F.img_size, F.img_size, workers=F.decode_workers,
+                                            decode=F.png_decode)
+            chunks.append(model(fr)[3][0].float())
+        feats_local[featfile.video_key(v, "transformer")] = torch.vstack(chunks).cpu().numpy()
     merged = extract.gather_feats(feats_local)
     if rank == 0:
         featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type), merged)
