@@ -232,9 +232,11 @@ def spatial_cnn_train(argv=None) -> Dict[str, float]:
             m = Recognition({"i": 6, "v": 10, "t": 15, "ivt": 100}[vt])
             for v in val_videos:
                 lv = labels[v][vt]
-                for s0 in range(0, len(lv), F.batch):
-                    fr = cholect.load_frames_device(F.data_dir, v, lv[s0:s0 + F.batch, 0], F.image_height, F.image_width)
-                    m.update(lv[s0:s0 + F.batch, 1:], _sigmoid(model.extract_u8(fr)["ivt".index(vt) if single else 3][1]))
+                vb = max(F.batch, min(getattr(F, "device_batch", F.batch), 256))     # validation passes in device batches (results do not depend on it)
+                for s0 in range(0, len(lv), vb):
+                    fr = cholect.load_frames_device(F.data_dir, v, lv[s0:s0 + vb, 0], F.image_height, F.image_width,
+                                                    workers=getattr(F, "decode_workers", 0), decode=getattr(F, "png_decode", "host"))
+                    m.update(lv[s0:s0 + vb, 1:], _sigmoid(model.extract_u8(fr)["ivt".index(vt) if single else 3][1]))
                 m.video_end()
             score = float(m.compute_video_AP()["mAP"]) if val_videos else 0.0
             last["val_mAP_ivt"] = score
@@ -548,9 +550,11 @@ def spatial_transformer_train(argv=None) -> Dict[str, float]:
             gi = "ivt".index(F.loss_type)
             for v in val_videos:
                 lv = labels[v][F.loss_type]
-                for s0 in range(0, len(lv), F.batch):
-                    fr = cholect.load_frames_device(F.data_dir, v, lv[s0:s0 + F.batch, 0], F.img_size, F.img_size)
-                    m.update(lv[s0:s0 + F.batch, 1:], _sigmoid(model(fr)[gi][1]))
+                vb = max(F.batch, min(getattr(F, "device_batch", F.batch), 128))     # validation passes in device batches (results do not depend on it)
+                for s0 in range(0, len(lv), vb):
+                    fr = cholect.load_frames_device(F.data_dir, v, lv[s0:s0 + vb, 0], F.img_size, F.img_size,
+                                                    workers=getattr(F, "decode_workers", 0), decode=getattr(F, "png_decode", "host"))
+                    m.update(lv[s0:s0 + vb, 1:], _sigmoid(model(fr)[gi][1]))
                 m.video_end()
             score = float(m.compute_video_AP()["mAP"]) if val_videos else 0.0
             last["val_mAP"] = score
