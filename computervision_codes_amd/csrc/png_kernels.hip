@@ -19,6 +19,7 @@ namespace {
 constexpr int MAXBITS = 15, MAXL = 288, MAXD = 32;
 constexpr int WIN = 32768, FLUSH = 8192;
 constexpr int LBITS = 11, DBITS = 10;
+constexpr int EMPTY = 256;       // lookup entry without a code
 
 __device__ const unsigned short kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __device__ const unsigned char kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -71,7 +72,7 @@ __device__ __forceinline__ unsigned getbits(Bits& b, int n, int lane) {   // n <
 }
 
 // the wave's LDS (one wave per workgroup)
-__shared__ __attribute__((aligned(16))) uint8_t g_win[WIN];
+__shared__ __attribute__((aligned(16))) uint8_t g_win[WIN + 64];      // (+ 64 spare bytes: where lanes 1..63 put their copy of a literal)
 __shared__ unsigned short g_lcount[MAXBITS + 1], g_lsym[MAXL], g_ltab[1 << LBITS];
 __shared__ unsigned short g_dcount[MAXBITS + 1], g_dsym[MAXD], g_dtab[1 << DBITS];
 __shared__ unsigned char g_lens[384];
@@ -82,7 +83,8 @@ __shared__ unsigned char s_lext[32], s_dext[32];
 struct Huff {
     unsigned short* count;    // [MAXBITS + 1]
     unsigned short* symbol;   // [n]
-    unsigned short* tab;      // [1 << tbits]: (code length << 9) | symbol, 0 = longer than tbits (or unused): canonical decode
+    unsigned short* tab;      // [1 << tbits]: (code length << 9) | symbol; EMPTY (length 0, bit 8 set like every non-literal) = longer than tbits
+                              // (or unused): canonical decode
     int tbits;
 };
 
@@ -99,7 +101,7 @@ __device__ __noinline__ int construct(int which, int lens_off, int n, int lane) 
     const unsigned char* lens = g_lens + lens_off;
     __syncthreads();          // (single-wave block: orders the LDS traffic of the previous user of these arrays)
     if (lane <= MAXBITS) h.count[lane] = 0;
-    for (int i = lane; i < (1 << h.tbits); i += 64) h.tab[i] = 0;
+    for (int i = lane; i < (1 << h.tbits); i += 64) h.tab[i] = EMPTY;
     __syncthreads();
     if (lane == 0)
         for (int s = 0; s < n; ++s) h.count[lens[s]] = h.count[lens[s]] + 1;
@@ -142,7 +144,7 @@ __device__ __noinline__ int construct(int which, int lens_off, int n, int lane) 
 __device__ __forceinline__ int decode_sym(Bits& b, const Huff& h, int lane) {
     refill(b, lane);
     const int e = UNI(h.tab[b.buf & ((1u << h.tbits) - 1)]);
-    if (e) {
+    if (e >> 9) {
         const int elen = e >> 9;
         b.buf >>= elen;
         b.cnt -= elen;
@@ -308,13 +310,37 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
         }
         // literal / length + distance codes of the block
         for (;;) {
-            {   // run of literals: one table read, one window write, a handful of scalar instructions each; leaves the loop on anything else (a
-                // length code, a code longer than the table's index, the end of the block, the flush point, the end of the output)
+            {   // run of literals; leaves the loop on anything else (a length code, a code longer than the table's index, the end of the block,
+                // the flush point, the end of the output)
                 const int limit = min(raw_len, flushed + FLUSH);
-                for (;;) {
+                // Lane l looks up the code that would start l bits further on, so ONE LDS round trip serves every literal that starts within
+                // the next 23 bits (a refill leaves >= 33 valid bits, a table hit is <= 11 long): the scalar unit then walks the lanes' entries
+                // (readlane at the running bit offset).  Lanes 1..63 write their copy of a literal to a spare byte instead of sitting behind
+                // an exec mask that would be set and restored per symbol.  (One lookup per literal: ~230 cycles each; this: ~100.)
+                // Lanes >= 23 hold a sentinel (bit 8 set, no length, not EMPTY), so the walk has ONE exit test per literal.
+                const int spare = WIN + lane;
+                constexpr unsigned SENT = EMPTY + 1;
+                bool other = false;
+                while (pos + 24 <= limit) {
+                    refill(b, lane);
+                    const unsigned short t = g_ltab[(unsigned)(b.buf >> lane) & ((1u << LBITS) - 1)];
+                    const int ev = lane < 23 ? (int)t : (int)SENT;
+                    unsigned off = 0;
+                    unsigned e = (unsigned)__builtin_amdgcn_readlane(ev, 0);
+                    while (!(e & 256)) {
+                        win[lane == 0 ? (pos & (WIN - 1)) : spare] = (uint8_t)e;
+                        ++pos;
+                        off += e >> 9;
+                        e = (unsigned)__builtin_amdgcn_readlane(ev, off);
+                    }
+                    b.buf >>= off;
+                    b.cnt -= off;
+                    if (e != SENT) { other = true; break; }
+                }
+                while (!other) {           // next to the flush point / the end of the output: one lookup per literal
                     refill(b, lane);
                     const int e = UNI(g_ltab[b.buf & ((1u << LBITS) - 1)]);
-                    if (e == 0 || (e & 256) || pos >= limit) break;
+                    if ((e & 256) || pos >= limit) break;
                     if (lane == 0) win[pos & (WIN - 1)] = (uint8_t)e;
                     ++pos;
                     b.buf >>= (e >> 9);

@@ -389,9 +389,10 @@ def spatial_transformer_test(argv=None) -> Dict[str, np.ndarray]:
         # device batches (a frame's feature does not depend on the batch it rides in), decode on --decode_workers threads (or on the device), the
         # video's features stay on the GPU until its end: one D2H per video instead of one synchronous copy per --batch frames (`test.py:357-376`)
         step = max(1, min(F.device_batch, 256))
-        for s in range(0, len(ids_all), step):
-            fr = cholect.load_frames_device(F.data_dir, v, ids_all[s:s + step], F.img_size, F.img_size, workers=F.decode_workers,
-                                            decode=F.png_decode)
+        load = lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.img_size, F.img_size, workers=F.decode_workers,
+                                                       decode=F.png_decode)
+        spans = [(s, min(len(ids_all), s + step)) for s in range(0, len(ids_all), step)]
+        for fr in extract.iter_chunks(spans, load):            # the next span is decoded while this one runs
             chunks.append(model(fr)[3][0].float())
         feats_local[featfile.video_key(v, "transformer")] = torch.vstack(chunks).cpu().numpy()
     merged = extract.gather_feats(feats_local)

@@ -7,6 +7,7 @@ single pickle the temporal stage reads.
 """
 from __future__ import annotations
 
+from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, Dict, List, Mapping, Sequence
 
 import numpy as np
@@ -36,15 +37,42 @@ def extract_video(frames: torch.Tensor, forward: Callable[[torch.Tensor], torch.
     return torch.vstack(out).numpy() if out else np.zeros((0, 0), np.float32)
 
 
-def extract_video_device(model, n_frames: int, load_chunk: Callable[[int, int], torch.Tensor], device_batch: int = 512, streams: int = 1):
+def iter_chunks(spans: Sequence[tuple], load_chunk: Callable[[int, int], torch.Tensor], prefetch: bool = True):
+    """Yield `load_chunk(s, e)` for every span in order.  With `prefetch` the NEXT span is read and decoded on a helper thread while the
+    caller works on this one (the reference's DataLoader workers run ahead of the model the same way, `Spatial_cnn/test.py:240-241`).
+    Device and stream are per-thread state: the helper takes the caller's, so whatever it launches is ordered before the caller's first
+    use of the frames."""
+    if not prefetch or len(spans) < 2 or not torch.cuda.is_available():
+        for s, e in spans:
+            yield load_chunk(s, e)
+        return
+    dev, cur = torch.cuda.current_device(), torch.cuda.current_stream()
+
+    def ahead(s, e):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(cur):
+            return load_chunk(s, e)
+    pool = ThreadPoolExecutor(1)
+    try:
+        nxt = pool.submit(ahead, *spans[0])
+        for i in range(len(spans)):
+            fr = nxt.result()
+            nxt = pool.submit(ahead, *spans[i + 1]) if i + 1 < len(spans) else None
+            yield fr
+    finally:
+        pool.shutdown(wait=True)
+
+
+def extract_video_device(model, n_frames: int, load_chunk: Callable[[int, int], torch.Tensor], device_batch: int = 512, streams: int = 1,
+                         prefetch: bool = True):
     """One video through the spatial extractor the MI355X way (`Spatial_cnn/test.py:143-177` restated): frames [s, e) arrive as uint8
     device tensors from `load_chunk(s, e)` in file order, `device_batch` of them per pass (a frame's result does not depend on the batch
     it rides in -- bit-exact, tests/test_gpu_models.py -- so the reference's `--batch` need not bound the launch size); features and
     the four heads' logits stay on the device until the video ends, then cross to the host ONCE through pinned memory.
     Returns (feat [N,D] float32 ndarray, logits (i, v, t, ivt) float32 ndarrays)."""
     feats, logits = [], [[], [], [], []]
-    for s in range(0, n_frames, device_batch):
-        fr = load_chunk(s, min(n_frames, s + device_batch))
+    spans = [(s, min(n_frames, s + device_batch)) for s in range(0, n_frames, device_batch)]
+    for fr in iter_chunks(spans, load_chunk, prefetch):
         (_, li), (_, lv), (_, lt), (feat, livt) = model.extract_u8(fr, streams=streams)
         feats.append(feat)
         for acc, lg in zip(logits, (li, lv, lt, livt)):
