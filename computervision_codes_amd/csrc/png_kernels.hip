@@ -72,7 +72,7 @@ __device__ __forceinline__ unsigned getbits(Bits& b, int n, int lane) {   // n <
 }
 
 // the wave's LDS (one wave per workgroup)
-__shared__ __attribute__((aligned(16))) uint8_t g_win[WIN + 64];      // (+ 64 spare bytes: where lanes 1..63 put their copy of a literal)
+__shared__ __attribute__((aligned(16))) uint8_t g_win[WIN];
 __shared__ unsigned short g_lcount[MAXBITS + 1], g_lsym[MAXL], g_ltab[1 << LBITS];
 __shared__ unsigned short g_dcount[MAXBITS + 1], g_dsym[MAXD], g_dtab[1 << DBITS];
 __shared__ unsigned char g_lens[384];
@@ -314,25 +314,31 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 // the flush point, the end of the output)
                 const int limit = min(raw_len, flushed + FLUSH);
                 // Lane l looks up the code that would start l bits further on, so ONE LDS round trip serves every literal that starts within
-                // the next 23 bits (a refill leaves >= 33 valid bits, a table hit is <= 11 long): the scalar unit then walks the lanes' entries
-                // (readlane at the running bit offset).  Lanes 1..63 write their copy of a literal to a spare byte instead of sitting behind
-                // an exec mask that would be set and restored per symbol.  (One lookup per literal: ~230 cycles each; this: ~100.)
-                // Lanes >= 23 hold a sentinel (bit 8 set, no length, not EMPTY), so the walk has ONE exit test per literal.
-                const int spare = WIN + lane;
+                // the buffered bits (a refill leaves 33..64 of them, a table hit is <= 11 long): the scalar unit then walks the lanes' entries
+                // (readlane at the running bit offset).  The literals of a walk are collected in one vector register (literal k
+                // in lane k, v_writelane) and stored by the lanes together: 7 instructions per literal.  (One lookup per literal: 33.)
+                // The lanes past the buffered bits hold a sentinel (bit 8 set, no length, not EMPTY), so the walk has ONE exit test per literal.
                 constexpr unsigned SENT = EMPTY + 1;
                 bool other = false;
-                while (pos + 24 <= limit) {
+                while (pos + 56 <= limit) {              // (a walk consumes at most 64 - 11 + 1 one-bit codes)
                     refill(b, lane);
                     const unsigned short t = g_ltab[(unsigned)(b.buf >> lane) & ((1u << LBITS) - 1)];
-                    const int ev = lane < 23 ? (int)t : (int)SENT;
+                    const int ev = lane <= min(b.cnt - LBITS, 63 - LBITS) ? (int)t : (int)SENT;   // an entry is good while its LBITS index bits are
+                                                                                                 // stream bits (and the walk ends on a lane <= 63)
                     unsigned off = 0;
                     unsigned e = (unsigned)__builtin_amdgcn_readlane(ev, 0);
+                    int lits = 0;                    // literal k of this walk -> lane k; the lanes store them together behind the walk
+                    unsigned n = 0;
                     while (!(e & 256)) {
-                        win[lane == 0 ? (pos & (WIN - 1)) : spare] = (uint8_t)e;
-                        ++pos;
+                        // (no builtin for v_writelane in this compiler; two different SGPR operands exceed the constant-bus limit unless the
+                        //  lane select sits in M0)
+                        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(lits) : "s"(e), "s"(n) : "m0");
+                        ++n;
                         off += e >> 9;
                         e = (unsigned)__builtin_amdgcn_readlane(ev, off);
                     }
+                    if (lane < (int)n) win[(pos + lane) & (WIN - 1)] = (uint8_t)lits;
+                    pos += n;
                     b.buf >>= off;
                     b.cnt -= off;
                     if (e != SENT) { other = true; break; }
