@@ -5,11 +5,13 @@
 // The host side (pngdec.py) only walks the chunk list of each file (IHDR, IDAT concatenation) -- no inflate, no pixel work on the CPU.
 // A DEFLATE stream is a serial bit stream; what a wave can do in parallel is everything around the bit decode, and that is where a
 // thread-per-frame decoder (the first version: 0.4 k frames/s at 480 x 854, every output byte a dependent global store / load) spends its time:
-//   * the 64 lanes run the SAME decode (uniform control flow, no divergence): Huffman tables, the 32 KB history window and the code-length
+//   * the 64 lanes run the SAME decode (uniform control flow, no divergence): Huffman tables, the most recent 8 KB of the output (a ring) and the code-length
 //     scratch are the wave's own LDS, read at one address by every lane (broadcast);
 //   * symbols are decoded through first-level lookup tables (11 bits literal / length, 10 bits distance: one LDS read per symbol), filled by
 //     all lanes in parallel for every dynamic block; longer codes fall back to the canonical decode by code length;
-//   * a match is copied by the lanes in parallel inside the window; finished 8 KB pieces of the window go to memory as 16-byte vectors.
+//   * a match is copied by the lanes in parallel inside the ring (from the frame's output in memory when it reaches further back); finished
+//     4 KB pieces of the ring go to memory as 16-byte vectors;
+//   * a run of literals is looked up by the lanes in parallel (lane l: the code that starts l bits ahead), see the literal run below.
 // The unfilter kernel keeps the raw and the previous row in LDS: rows of type None / Up are done by all lanes, Sub / Average / Paeth (a
 // recurrence along the row per channel) by three lanes -- from LDS, so the chain runs at register speed.
 #include "mt4_common.h"
@@ -17,7 +19,11 @@
 namespace {
 
 constexpr int MAXBITS = 15, MAXL = 288, MAXD = 32;
-constexpr int WIN = 32768, FLUSH = 8192;
+// The wave keeps the last WIN bytes of its output in an LDS ring and writes them out in pieces of FLUSH bytes; DEFLATE's 32 KB history beyond
+// the ring is the frame's own output in memory (a match that reaches further back than the ring reads it from there: 0.2 % of the symbols are
+// matches at all, and a scanline of a 854-pixel frame is 2.5 KB).  A 32 KB ring allowed four frames per CU; this size allows ten, and a wave
+// that waits ~100 cycles per literal hop needs neighbours on its SIMD.
+constexpr int WIN = 8192, FLUSH = 4096, NEAR = WIN - 512;      // matches up to NEAR bytes back are copied inside the ring
 constexpr int LBITS = 11, DBITS = 10;
 constexpr int EMPTY = 256;       // lookup entry without a code
 
@@ -72,7 +78,7 @@ __device__ __forceinline__ unsigned getbits(Bits& b, int n, int lane) {   // n <
 }
 
 // the wave's LDS (one wave per workgroup)
-__shared__ __attribute__((aligned(16))) uint8_t g_win[WIN];
+__shared__ __attribute__((aligned(16))) uint8_t g_win[WIN + 64];      // (+ 64 spare bytes: where lanes 1..63 put their copy of a literal)
 __shared__ unsigned short g_lcount[MAXBITS + 1], g_lsym[MAXL], g_ltab[1 << LBITS];
 __shared__ unsigned short g_dcount[MAXBITS + 1], g_dsym[MAXD], g_dtab[1 << DBITS];
 __shared__ unsigned char g_lens[384];
@@ -315,9 +321,12 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 const int limit = min(raw_len, flushed + FLUSH);
                 // Lane l looks up the code that would start l bits further on, so ONE LDS round trip serves every literal that starts within
                 // the buffered bits (a refill leaves 33..64 of them, a table hit is <= 11 long): the scalar unit then walks the lanes' entries
-                // (readlane at the running bit offset).  The literals of a walk are collected in one vector register (literal k
-                // in lane k, v_writelane) and stored by the lanes together: 7 instructions per literal.  (One lookup per literal: 33.)
+                // (readlane at the running bit offset).  Lanes 1..63 write their copy of a literal to a spare byte instead of sitting behind
+                // an exec mask that would be set and restored per hop: 11 instructions per literal.  (One lookup per literal: 33.  Collecting
+                // the literals by v_writelane -- 8 instructions -- measured the same: the hop is bound by its vector -> scalar -> vector
+                // dependency, not by issue.)
                 // The lanes past the buffered bits hold a sentinel (bit 8 set, no length, not EMPTY), so the walk has ONE exit test per literal.
+                const int spare = WIN + lane;
                 constexpr unsigned SENT = EMPTY + 1;
                 bool other = false;
                 while (pos + 56 <= limit) {              // (a walk consumes at most 64 - 11 + 1 one-bit codes)
@@ -327,18 +336,12 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                                                                                                  // stream bits (and the walk ends on a lane <= 63)
                     unsigned off = 0;
                     unsigned e = (unsigned)__builtin_amdgcn_readlane(ev, 0);
-                    int lits = 0;                    // literal k of this walk -> lane k; the lanes store them together behind the walk
-                    unsigned n = 0;
                     while (!(e & 256)) {
-                        // (no builtin for v_writelane in this compiler; two different SGPR operands exceed the constant-bus limit unless the
-                        //  lane select sits in M0)
-                        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(lits) : "s"(e), "s"(n) : "m0");
-                        ++n;
+                        win[lane == 0 ? (pos & (WIN - 1)) : spare] = (uint8_t)e;
+                        ++pos;
                         off += e >> 9;
                         e = (unsigned)__builtin_amdgcn_readlane(ev, off);
                     }
-                    if (lane < (int)n) win[(pos + lane) & (WIN - 1)] = (uint8_t)lits;
-                    pos += n;
                     b.buf >>= off;
                     b.cnt -= off;
                     if (e != SENT) { other = true; break; }
@@ -378,7 +381,12 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 if (dist > pos) { err = 5; break; }
                 if (pos + len > raw_len) { err = 6; break; }
                 // the lanes copy the match inside the window; an overlapping match (dist < len) repeats its first dist bytes
-                if (dist >= len) {
+                if (dist > NEAR) {
+                    // behind the ring: those bytes left in a flush (pos - dist + len < flushed: FLUSH + 258 + len < NEAR); the fence completes
+                    // this wave's stores and drops what its L1 holds of the lines
+                    __threadfence();
+                    for (int i = lane; i < len; i += 64) win[(pos + i) & (WIN - 1)] = out[pos - dist + i];
+                } else if (dist >= len) {
                     for (int i = lane; i < len; i += 64) win[(pos + i) & (WIN - 1)] = win[(pos - dist + i) & (WIN - 1)];
                 } else {
                     for (int i = lane; i < len; i += 64) win[(pos + i) & (WIN - 1)] = win[(pos - dist + (i % dist)) & (WIN - 1)];

@@ -95,7 +95,9 @@ def spatial_cnn_test(argv=None) -> Dict[str, np.ndarray]:
         ids_all = lab["ivt"][:, 0]                             # file order, no shuffle, drop_last False (`test.py:227-242`)
         load = lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.image_height, F.image_width,   # decode on the
                                                        workers=F.decode_workers, decode=F.png_decode)          # host (or device), Resize on the GPU
-        feat, lgs = extract.extract_video_device(model, len(ids_all), load, F.device_batch)
+        # (the device PNG decoder runs one wave per frame, ten per CU: it is handed several passes' worth of frames at once)
+        feat, lgs = extract.extract_video_device(model, len(ids_all), load, F.device_batch,
+                                                 load_batch=2560 if F.png_decode == "device" else None)
         for key, lg in zip(("i", "v", "t", "ivt"), lgs):
             m[key].update(lab[key][:, 1:], torch.sigmoid(torch.from_numpy(lg)).numpy())   # `test.py:162-169`
             m[key].video_end()

@@ -64,19 +64,23 @@ def iter_chunks(spans: Sequence[tuple], load_chunk: Callable[[int, int], torch.T
 
 
 def extract_video_device(model, n_frames: int, load_chunk: Callable[[int, int], torch.Tensor], device_batch: int = 512, streams: int = 1,
-                         prefetch: bool = True):
+                         prefetch: bool = True, load_batch: int = None):
     """One video through the spatial extractor the MI355X way (`Spatial_cnn/test.py:143-177` restated): frames [s, e) arrive as uint8
     device tensors from `load_chunk(s, e)` in file order, `device_batch` of them per pass (a frame's result does not depend on the batch
     it rides in -- bit-exact, tests/test_gpu_models.py -- so the reference's `--batch` need not bound the launch size); features and
-    the four heads' logits stay on the device until the video ends, then cross to the host ONCE through pinned memory.
+    the four heads' logits stay on the device until the video ends, then cross to the host ONCE through pinned memory.  `load_batch`
+    (a multiple of `device_batch`): frames per `load_chunk` call when the loader wants more than one pass at a time (the device PNG decoder
+    runs one wave per frame and fills the GPU from ~2500 frames on).
     Returns (feat [N,D] float32 ndarray, logits (i, v, t, ivt) float32 ndarrays)."""
     feats, logits = [], [[], [], [], []]
-    spans = [(s, min(n_frames, s + device_batch)) for s in range(0, n_frames, device_batch)]
-    for fr in iter_chunks(spans, load_chunk, prefetch):
-        (_, li), (_, lv), (_, lt), (feat, livt) = model.extract_u8(fr, streams=streams)
-        feats.append(feat)
-        for acc, lg in zip(logits, (li, lv, lt, livt)):
-            acc.append(lg)
+    load_batch = max(device_batch, load_batch or device_batch) // device_batch * device_batch      # whole passes per load
+    spans = [(s, min(n_frames, s + load_batch)) for s in range(0, n_frames, load_batch)]
+    for span in iter_chunks(spans, load_chunk, prefetch):
+        for s in range(0, span.shape[0], device_batch):
+            (_, li), (_, lv), (_, lt), (feat, livt) = model.extract_u8(span[s:s + device_batch], streams=streams)
+            feats.append(feat)
+            for acc, lg in zip(logits, (li, lv, lt, livt)):
+                acc.append(lg)
     if not feats:
         return np.zeros((0, 0), np.float32), tuple(np.zeros((0, 0), np.float32) for _ in range(4))
     dev_out = [torch.cat(feats).float()] + [torch.cat(l).float() for l in logits]

@@ -41,6 +41,29 @@ def test_png_decode_matches_pillow(cuda, kind, h, w, level):
         assert np.array_equal(got[i], ref), (kind, h, w, level, i)
 
 
+@pytest.mark.parametrize("w,period", [(1024, 3), (1024, 4), (1024, 10), (700, 15), (854, 2), (854, 3), (853, 3), (2600, 1)])
+def test_png_decode_matches_beyond_the_lds_ring(cuda, w, period):
+    """random rows repeating every `period` rows: the only matches are `period` scanlines back (6 ... 31 KB), i.e. behind the 8 KB ring the
+    decoder keeps in LDS -- those are copied from the frame's own output in memory.  (854 / 853 x 3: 7689 / 7680 bytes back, either side of the limit for a copy inside the ring.)"""
+    import zlib
+    from PIL import Image
+    from computervision_codes_amd import pngdec
+    rng = np.random.default_rng(w + period)
+    h = 6 * period + 5
+    files, frames = [], []
+    for k in range(3):
+        rows = rng.integers(0, 256, (period, w, 3), dtype=np.uint8)
+        fr = np.concatenate([rows] * (h // period + 1))[:h].copy()
+        fr[-1, : w // 2] = rng.integers(0, 256, (w // 2, 3), dtype=np.uint8)      # a row that matches only in part
+        f = _png(fr, compress_level=9)
+        # the encoder did find the far matches: the stream is far smaller than the random rows repeated
+        assert len(f) < 0.45 * fr.size if period * (3 * w + 1) < 32768 - 300 else True
+        files.append(f); frames.append(fr)
+    got = pngdec.decode_batch(files, cuda).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], frames[i]), (w, period, i)
+
+
 def test_png_decode_optimized_and_many_frames(cuda):
     """`optimize=True` (maximum-effort deflate, dynamic blocks only) and a batch larger than one workgroup of decoder threads"""
     from computervision_codes_amd import pngdec
