@@ -392,10 +392,10 @@ def e2e_script_bench(dev):
     return out
 
 
-def png_decode_bench(dev, n=1024):
+def png_decode_bench(dev, n=2560):
     """the stage in front of the extractor on real data: PNG files -> uint8 frames on the device (`pngdec.decode_batch`: the host walks the chunk
     lists and uploads the compressed bytes, inflate + unfiltering run in HIP).  16 distinct synthetic frames of the dataset's native 480 x 854
-    (smooth structure + sensor-like noise: ~650 KB per PNG), repeated to n per call; kernel time from HIP events, wall time incl. the host part."""
+    (smooth structure + sensor-like noise: ~650 KB per PNG), repeated to n per call (2560: what the extraction driver hands the decoder at once, one full round of ten frames per CU); kernel time from HIP events, wall time incl. the host part."""
     import io
     try:
         from PIL import Image

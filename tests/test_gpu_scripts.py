@@ -65,6 +65,30 @@ def test_student_pipeline_scripts(cuda, tmp_path):
     assert "AP_ivt=" in log
 
 
+def test_extraction_script_device_png_decode_writes_the_same_features(cuda, tmp_path):
+    """`Spatial_cnn/test.py --png_decode device` (inflate + unfilter in HIP, loads of several passes, next load on the helper thread) writes
+    the same feature file as the Pillow path, byte for byte; passes of 2 frames over 5-frame videos"""
+    tree = tmp_path / "MT4MTLKD"
+    shutil.copytree(os.path.join(ROOT, "MT4MTLKD"), tree)
+    data = str(tmp_path / "CholecT45")
+    vids = _make_dataset(data, n_frames=5)
+    sd_cnn = synth.fill_from_shapes(shapes.spatial_cnn_shapes("resnet18"), seed=11)
+    os.makedirs(tree / "Spatial_cnn" / "__checkpoint__" / "run_SwinL2Res18")
+    torch.save(sd_cnn, tree / "Spatial_cnn" / "__checkpoint__" / "run_SwinL2Res18" / "rendezvous_lcholect45-crossval_cholect1.pth")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = {}
+    for mode in ("host", "device"):
+        r = subprocess.run([sys.executable, "test.py", "-e", "--network", "resnet18", "--student_dim", "512", "--loss_type", "all",
+                            "--dataset_variant=cholect45-crossval", "--kfold", "1", "--batch=8", "--version=SwinL2Res18", "--dtype", "bf16",
+                            "--data_dir", data, "--image_height", "64", "--image_width", "96", "--device_batch", "2", "--png_decode", mode],
+                           cwd=tree / "Spatial_cnn", env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out[mode] = pickle.load(open(tree / "0-5fold" / "data_feats" / "run_SwinL2Res18" / "k1_feats.pkl", "rb"))
+    assert list(out["host"]) == list(out["device"]) == [v[-2:] for v in vids]
+    for k in out["host"]:
+        assert out["host"][k].shape == (5, 512) and np.array_equal(out["host"][k], out["device"][k]), k
+
+
 def test_tenco_train_driver_runs_and_checkpoints(cuda, tmp_path):
     """`Temporal_tenco/run.py -t -e`: two epochs on the synthetic dataset, `_latest.pth` in the reference's key layout, then eval"""
     from computervision_codes_amd import featfile
