@@ -141,7 +141,12 @@ class VideoNas:
         feat = ops.linear(concat, *p["fuse"])                        # Classifier (network.py:104-118), dropout = identity
         y = ops.linear(feat, *p["pred"], out_dtype=torch.float32).view(b, t, -1)
         concat_ref = concat.view(b, t, 4 * e).permute(0, 2, 1)       # [B, 4E, T] view
-        ys = {k: torch.zeros((b, t, n), device=x.device) for k, n in _K.items()}
+        zeros = torch.zeros(b * t * sum(n for k, n in _K.items() if k != self.loss_type), device=x.device)      # (one fill for the unused heads)
+        ys, at = {}, 0
+        for k, n in _K.items():
+            if k != self.loss_type:
+                ys[k] = zeros[at:at + b * t * n].view(b, t, n)
+                at += b * t * n
         fs = {k: concat_ref for k in _K}
         ys[self.loss_type] = y
         fs[self.loss_type] = feat.view(b, t, e).permute(0, 2, 1)
