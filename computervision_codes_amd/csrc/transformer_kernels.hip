@@ -574,6 +574,155 @@ __global__ __launch_bounds__(256) void mha_mfma_f32_kernel(const float* __restri
     }
 }
 
+// The same core for a launch that cannot fill the chip with one wave per 16 queries (one MS-TCT window: 8 heads x 256 queries = 128 waves,
+// each busy 1.7 us per 32-dim chunk with its 128 fp32 matrix instructions): the four waves of a workgroup share 16 queries and split the KEYS
+// (key tiles 4w .. 4w+3 of 16), so 4x the waves carry a quarter of the matrix work each.  Row maxima and sums meet in LDS (fixed order
+// wave 0..3: deterministic), the partial P.V tiles of a chunk likewise, and 128 threads store the summed chunk.
+template <int NKT>
+__global__ __launch_bounds__(256) void mha_mfma_f32_ksplit_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                                  float* __restrict__ out, int Nq, int Nk, int hd, int q_stride, int k_stride,
+                                                                  int v_stride, int o_stride, float scale) {
+    constexpr int NKP = NKT * 16, NKW = NKT / 4;
+    constexpr int K_PITCH = 36, VT_PITCH = NKP + 4, MAXG = 8;
+    constexpr int MAIN = NKP * K_PITCH > 32 * VT_PITCH ? NKP * K_PITCH : 32 * VT_PITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ks = (float*)smem;
+    float* Vt = (float*)smem;
+    float* red = (float*)smem + MAIN;          // [2][4][16]: row maxima, row sums per wave
+    float* part = red + 128;                   // [4][16][32]: a chunk's partial output tiles per wave
+    const int h = blockIdx.x, b = blockIdx.y, q0 = blockIdx.z * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, qd = lane >> 4;
+    const int query = q0 + r16;
+    const bool q_ok = query < Nq;
+    const int nch = (hd + 31) / 32;
+
+    float4 qf[MAXG];
+    {
+        const float* qp = q + ((long long)b * Nq + (q_ok ? query : 0)) * q_stride + h * hd;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            const int d = g * 16 + qd * 4;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q_ok && d < hd) t = *(const float4*)(qp + d);
+            qf[g] = make_float4(t.x * scale, t.y * scale, t.z * scale, t.w * scale);
+        }
+    }
+    f32x4 s[NKW];
+#pragma unroll
+    for (int j = 0; j < NKW; ++j) s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < MAXG / 2; ++c) {
+        if (c < nch) {   // (uniform)
+            if (c) __syncthreads();
+            {
+                constexpr int SI = (NKP * 8 + 255) / 256;
+                float4 kreg[SI];
+#pragma unroll
+                for (int i = 0; i < SI; ++i) {
+                    const int e = tid + i * 256, row = e >> 3, pc = e & 7;
+                    const int d = c * 32 + pc * 4;
+                    const float4 t = *(const float4*)(k + ((long long)b * Nk + min(row, Nk - 1)) * k_stride + h * hd + min(d, hd - 4));
+                    kreg[i] = (row < Nk && d < hd) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < SI; ++i) {
+                    const int e = tid + i * 256, row = e >> 3, pc = e & 7;
+                    if (e < NKP * 8) *(float4*)(Ks + row * K_PITCH + pc * 4) = kreg[i];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NKW; ++j)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const float4 kf = *(const float4*)(Ks + ((wave * NKW + j) * 16 + r16) * K_PITCH + g * 16 + qd * 4);
+                    const float4 qv = qf[c * 2 + g];
+                    s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qv.x, s[j], 0, 0, 0);
+                    s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qv.y, s[j], 0, 0, 0);
+                    s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qv.z, s[j], 0, 0, 0);
+                    s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qv.w, s[j], 0, 0, 0);
+                }
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NKW; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if ((wave * NKW + j) * 16 + qd * 4 + e >= Nk) s[j][e] = -1e30f;
+            mx = fmaxf(mx, s[j][e]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (qd == 0) red[wave * 16 + r16] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[r16], red[16 + r16]), fmaxf(red[32 + r16], red[48 + r16]));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NKW; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[j][e] = __expf(s[j][e] - mx); sum += s[j][e]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    if (qd == 0) red[64 + wave * 16 + r16] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (((red[64 + r16] + red[80 + r16]) + red[96 + r16]) + red[112 + r16]);
+    for (int c = 0; c < nch; ++c) {
+        __syncthreads();      // the K chunk / the previous V chunk and its partial tiles are done with
+        {
+            constexpr int SI = (NKP * 8 + 255) / 256;
+            float4 vreg[SI];
+#pragma unroll
+            for (int i = 0; i < SI; ++i) {
+                const int e = tid + i * 256, row = e >> 3, pc = e & 7;
+                const int d = c * 32 + pc * 4;
+                const float4 t = *(const float4*)(v + ((long long)b * Nk + min(row, Nk - 1)) * v_stride + h * hd + min(d, hd - 4));
+                vreg[i] = (row < Nk && d < hd) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < SI; ++i) {
+                const int e = tid + i * 256, row = e >> 3, pc = e & 7;
+                if (e < NKP * 8) {
+                    Vt[(pc * 4 + 0) * VT_PITCH + row] = vreg[i].x;
+                    Vt[(pc * 4 + 1) * VT_PITCH + row] = vreg[i].y;
+                    Vt[(pc * 4 + 2) * VT_PITCH + row] = vreg[i].z;
+                    Vt[(pc * 4 + 3) * VT_PITCH + row] = vreg[i].w;
+                }
+            }
+        }
+        __syncthreads();
+        f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int j = 0; j < NKW; ++j)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const float4 vf = *(const float4*)(Vt + (dt * 16 + r16) * VT_PITCH + (wave * NKW + j) * 16 + qd * 4);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, s[j][0], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, s[j][1], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, s[j][2], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, s[j][3], o[dt], 0, 0, 0);
+            }
+        // lane (r16 = query, qd) holds dims 16dt + 4qd .. +3 of the chunk: part[wave][query][dim]
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            *(float4*)(part + (wave * 16 + r16) * 32 + dt * 16 + qd * 4) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+        __syncthreads();
+        if (tid < 128) {      // thread: query tid / 8, dims 4 (tid % 8) .. +3 of the chunk
+            const int qq = tid >> 3, d4 = (tid & 7) * 4;
+            const float4 a0 = *(const float4*)(part + (0 * 16 + qq) * 32 + d4), a1 = *(const float4*)(part + (1 * 16 + qq) * 32 + d4);
+            const float4 a2 = *(const float4*)(part + (2 * 16 + qq) * 32 + d4), a3 = *(const float4*)(part + (3 * 16 + qq) * 32 + d4);
+            const float iv = 1.0f / (((red[64 + qq] + red[80 + qq]) + red[96 + qq]) + red[112 + qq]);
+            const int d = c * 32 + d4;
+            if (q0 + qq < Nq && d < hd)
+                *(float4*)(out + ((long long)b * Nq + q0 + qq) * o_stride + h * hd + d) =
+                    make_float4((((a0.x + a1.x) + a2.x) + a3.x) * iv, (((a0.y + a1.y) + a2.y) + a3.y) * iv,
+                                (((a0.z + a1.z) + a2.z) + a3.z) * iv, (((a0.w + a1.w) + a2.w) + a3.w) * iv);
+        }
+    }
+    (void)inv;
+}
+
 extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* out, const float* bias, const float* mask,
                              int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t hd, int32_t q_stride, int32_t k_stride,
                              int32_t v_stride, int32_t o_stride, int32_t nW, float scale, int32_t dtype, void* stream) {
@@ -610,7 +759,23 @@ extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* 
     if (dtype == MT4_F32 && hd <= 128 && (hd % 4) == 0 && !bias && !mask && Nk <= 256 && (q_stride % 4) == 0 && (k_stride % 4) == 0 &&
         (v_stride % 4) == 0 && (o_stride % 4) == 0 && ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0) &&
         cdiv(Nq, 64) <= 65535 && !MT4_ENV_SET("MT4_NO_MHA_MFMA")) {
-        const dim3 grid(H, B, cdiv(Nq, 64)), block(256);
+        const dim3 block(256);
+        // too few 64-query workgroups for the chip (one MS-TCT window: 32): four waves per 16 queries, keys split between them
+        static const bool no_ksplit = MT4_ENV_SET("MT4_NO_MHA_KSPLIT");
+        if ((long long)H * B * cdiv(Nq, 64) < 128 && cdiv(Nq, 16) <= 65535 && !no_ksplit) {
+            const dim3 grid(H, B, cdiv(Nq, 16));
+            if (Nk <= 128) {
+                const size_t lds = sizeof(float) * (size_t)((128 * 36 > 32 * 132 ? 128 * 36 : 32 * 132) + 128 + 4 * 16 * 32);
+                hipLaunchKernelGGL((mha_mfma_f32_ksplit_kernel<8>), grid, block, lds, s, (const float*)q, (const float*)k, (const float*)v, (float*)out,
+                                   Nq, Nk, hd, q_stride, k_stride, v_stride, o_stride, scale);
+            } else {
+                const size_t lds = sizeof(float) * (size_t)((256 * 36 > 32 * 260 ? 256 * 36 : 32 * 260) + 128 + 4 * 16 * 32);
+                hipLaunchKernelGGL((mha_mfma_f32_ksplit_kernel<16>), grid, block, lds, s, (const float*)q, (const float*)k, (const float*)v, (float*)out,
+                                   Nq, Nk, hd, q_stride, k_stride, v_stride, o_stride, scale);
+            }
+            return mt4_check_launch();
+        }
+        const dim3 grid(H, B, cdiv(Nq, 64));
         if (Nk <= 128) {
             const size_t lds = sizeof(float) * (size_t)(128 * 36 > 32 * 132 ? 128 * 36 : 32 * 132);
             hipLaunchKernelGGL((mha_mfma_f32_kernel<8>), grid, block, lds, s, (const float*)q, (const float*)k, (const float*)v, (float*)out, Nq, Nk, hd,

@@ -128,7 +128,9 @@ def test_mha_mfma_head_dim_256(cuda, B, H, Nq, Nk):
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,hd", [(1, 8, 256, 256, 32), (1, 8, 256, 256, 48), (1, 8, 256, 256, 72), (1, 8, 256, 256, 108),
-                                           (2, 3, 100, 77, 108), (1, 2, 70, 130, 20), (3, 1, 5, 16, 128), (1, 8, 37, 37, 72)])
+                                           (2, 3, 100, 77, 108), (1, 2, 70, 130, 20), (3, 1, 5, 16, 128), (1, 8, 37, 37, 72),
+                                           (16, 8, 64, 200, 48), (4, 8, 250, 256, 108)])      # (the last two: enough 64-query workgroups, one wave per 16 queries;
+                                                                                              #  the others: four waves per 16 queries, keys split)
 def test_mha_mfma_fp32(cuda, B, H, Nq, Nk, hd):
     """the exact-fp32 matrix-unit core behind `mt4_attention` (fp32, no bias / mask, <= 256 keys, head dim <= 128: MS-TCT's
     Global_Relational_Block, `Temporal_Encoder.py:80-86`, incl. the short last chunk of a video) against the fp32 oracle"""
