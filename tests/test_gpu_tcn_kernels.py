@@ -22,6 +22,8 @@ CASES = [  # (B, T, Cin, Cout, taps, dilation)
     (1, 256, 512, 512, 1, 1), (1, 256, 2048, 512, 1, 1), (1, 256, 512, 131, 1, 1), (1, 256, 512, 100, 1, 1),
     (1, 77, 64, 64, 3, 16), (1, 77, 64, 64, 3, 64), (1, 77, 64, 64, 3, 128), (1, 1, 64, 48, 3, 1), (1, 5, 32, 16, 3, 2), (1, 33, 96, 20, 3, 3),
     (2, 120, 64, 64, 3, 8), (3, 50, 128, 131, 3, 5), (2, 300, 64, 32, 3, 64), (1, 1500, 64, 64, 3, 512), (1, 1000, 64, 64, 3, 4), (2, 40, 32, 7, 1, 1),
+    # wide 1-tap layers (MS-TCT's nn.Linear GEMMs), whole and ragged channel counts
+    (1, 256, 864, 6912, 1, 1), (1, 256, 256, 3100, 1, 1), (1, 256, 576, 2592, 1, 1), (1, 256, 128, 1508, 1, 1), (2, 100, 64, 3075, 1, 1), (1, 250, 6912, 864, 1, 1),
 ]
 
 
