@@ -93,10 +93,15 @@ def load_frames_device(data_dir: str, video: str, frame_ids, height: int = 256, 
         # decode = "device": the files are only read; inflate + unfiltering run on the GPU (`pngdec.decode_batch`, 8-bit RGB non-interlaced PNGs --
         # what the dataset ships; anything else raises `pngdec.UnsupportedPng`).  Same bytes as the Pillow path.
         from . import pngdec
-        files = []
-        for fid in frame_ids:
+        def read_one(fid):
             with open(os.path.join(data_dir, "data", video, "{}.png".format(str(int(fid)).zfill(6))), "rb") as fh:
-                files.append(fh.read())
+                return fh.read()
+        if workers > 1 and len(frame_ids) > 1:        # (file reads release the GIL: one thread read 0.65 MB files at ~3 GB/s, the whole pipeline's limit)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=workers) as ex:
+                files = list(ex.map(read_one, frame_ids))
+        else:
+            files = [read_one(fid) for fid in frame_ids]
         try:
             sizes: Dict[tuple, List[int]] = {}
             for i, f in enumerate(files):

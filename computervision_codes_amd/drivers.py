@@ -95,9 +95,11 @@ def spatial_cnn_test(argv=None) -> Dict[str, np.ndarray]:
         ids_all = lab["ivt"][:, 0]                             # file order, no shuffle, drop_last False (`test.py:227-242`)
         load = lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.image_height, F.image_width,   # decode on the
                                                        workers=F.decode_workers, decode=F.png_decode)          # host (or device), Resize on the GPU
-        # (the device PNG decoder runs one wave per frame, ten per CU: it is handed several passes' worth of frames at once)
-        feat, lgs = extract.extract_video_device(model, len(ids_all), load, F.device_batch,
-                                                 load_batch=2560 if F.png_decode == "device" else None)
+        # (the device PNG decoder runs one wave per frame and needs >= 1024 frames to fill the chip: it is handed several passes' worth at once,
+        # and two loads run ahead, so that gathering one load's compressed bytes on the host overlaps the inflate of the load before it)
+        dev_dec = F.png_decode == "device"
+        feat, lgs = extract.extract_video_device(model, len(ids_all), load, F.device_batch, prefetch=2 if dev_dec else 1,
+                                                 load_batch=1024 if dev_dec else None)
         for key, lg in zip(("i", "v", "t", "ivt"), lgs):
             m[key].update(lab[key][:, 1:], torch.sigmoid(torch.from_numpy(lg)).numpy())   # `test.py:162-169`
             m[key].video_end()

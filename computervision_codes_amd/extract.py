@@ -37,12 +37,14 @@ def extract_video(frames: torch.Tensor, forward: Callable[[torch.Tensor], torch.
     return torch.vstack(out).numpy() if out else np.zeros((0, 0), np.float32)
 
 
-def iter_chunks(spans: Sequence[tuple], load_chunk: Callable[[int, int], torch.Tensor], prefetch: bool = True):
-    """Yield `load_chunk(s, e)` for every span in order.  With `prefetch` the NEXT span is read and decoded on a helper thread while the
-    caller works on this one (the reference's DataLoader workers run ahead of the model the same way, `Spatial_cnn/test.py:240-241`).
-    Device and stream are per-thread state: the helper takes the caller's, so whatever it launches is ordered before the caller's first
+def iter_chunks(spans: Sequence[tuple], load_chunk: Callable[[int, int], torch.Tensor], prefetch=1):
+    """Yield `load_chunk(s, e)` for every span in order.  With `prefetch` = k > 0 the next k spans are read and decoded on helper threads
+    while the caller works on this one (the reference's DataLoader workers run ahead of the model the same way, `Spatial_cnn/test.py:240-241`);
+    k = 2 lets the host part of one load (file reads, gathering the compressed bytes) overlap the device part of the load before it.
+    Device and stream are per-thread state: the helpers take the caller's, so whatever they launch is ordered before the caller's first
     use of the frames."""
-    if not prefetch or len(spans) < 2 or not torch.cuda.is_available():
+    depth = int(prefetch)
+    if depth <= 0 or len(spans) < 2 or not torch.cuda.is_available():
         for s, e in spans:
             yield load_chunk(s, e)
         return
@@ -52,19 +54,21 @@ def iter_chunks(spans: Sequence[tuple], load_chunk: Callable[[int, int], torch.T
         torch.cuda.set_device(dev)
         with torch.cuda.stream(cur):
             return load_chunk(s, e)
-    pool = ThreadPoolExecutor(1)
+    depth = min(depth, len(spans))
+    pool = ThreadPoolExecutor(depth)
     try:
-        nxt = pool.submit(ahead, *spans[0])
+        pending = [pool.submit(ahead, *spans[i]) for i in range(depth)]
         for i in range(len(spans)):
-            fr = nxt.result()
-            nxt = pool.submit(ahead, *spans[i + 1]) if i + 1 < len(spans) else None
+            fr = pending.pop(0).result()
+            if i + depth < len(spans):
+                pending.append(pool.submit(ahead, *spans[i + depth]))
             yield fr
     finally:
         pool.shutdown(wait=True)
 
 
 def extract_video_device(model, n_frames: int, load_chunk: Callable[[int, int], torch.Tensor], device_batch: int = 512, streams: int = 1,
-                         prefetch: bool = True, load_batch: int = None):
+                         prefetch=1, load_batch: int = None):
     """One video through the spatial extractor the MI355X way (`Spatial_cnn/test.py:143-177` restated): frames [s, e) arrive as uint8
     device tensors from `load_chunk(s, e)` in file order, `device_batch` of them per pass (a frame's result does not depend on the batch
     it rides in -- bit-exact, tests/test_gpu_models.py -- so the reference's `--batch` need not bound the launch size); features and

@@ -6,6 +6,7 @@ anything else raises `UnsupportedPng` and the caller keeps the PIL path for that
 from __future__ import annotations
 
 import struct
+import threading
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -77,15 +78,16 @@ def _idat_spans(data: bytes) -> Tuple[int, int, List[Tuple[int, int]]]:
     return width, height, spans
 
 
-_PINNED = None
+_TLS = threading.local()
 
 
 def _staging(nbytes: int) -> torch.Tensor:
-    """pinned host buffer for the compressed bytes, kept between calls (page-locking 0.7 GB per call cost as much as the decode)"""
-    global _PINNED
-    if _PINNED is None or _PINNED.numel() < nbytes:
-        _PINNED = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8).pin_memory()
-    return _PINNED[:nbytes]
+    """pinned host buffer for the compressed bytes, kept between calls (page-locking 0.7 GB per call cost as much as the decode); one per
+    calling thread -- the extraction driver gathers the next spans on helper threads while an earlier one is still uploading"""
+    buf = getattr(_TLS, "pinned", None)
+    if buf is None or buf.numel() < nbytes:
+        buf = _TLS.pinned = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8).pin_memory()
+    return buf[:nbytes]
 
 
 def decode_batch(files: Sequence[bytes], device="cuda", timings: dict = None, workers: int = 8) -> torch.Tensor:
