@@ -109,7 +109,7 @@ def load_frames_device(data_dir: str, video: str, frame_ids, height: int = 256, 
                 sizes.setdefault((h0, w0), []).append(i)
             out = torch.empty((len(files), height, width, 3), dtype=torch.uint8, device=device)
             for (h0, w0), idx in sizes.items():
-                x = pngdec.decode_batch([files[i] for i in idx], device)
+                x = pngdec.decode_batch([files[i] for i in idx], device, workers=max(8, workers))
                 y = x if (h0, w0) == (height, width) else ops.resize_bilinear_u8(x, height, width)
                 out[torch.tensor(idx, device=device)] = y
             return out
