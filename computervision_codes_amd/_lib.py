@@ -73,6 +73,7 @@ SIGNATURES = {
     "mt4_pad_nchw_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_png_inflate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_int64, C.c_int64, _vp, _vp]),
     "mt4_png_unfilter_rgb8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.c_int64, _vp, _vp]),
+    "mt4_copy_spans_u8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "mt4_resize_pass_u8": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mt4_maxpool3x3s2_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mt4_stem_maxpool_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -160,7 +161,7 @@ def _load() -> C.CDLL:
     return lib
 
 
-ABI_VERSION = 6         # what mt4_abi_version() of a matching libmt4hip.so returns (csrc/misc_kernels.hip)
+ABI_VERSION = 7         # what mt4_abi_version() of a matching libmt4hip.so returns (csrc/misc_kernels.hip)
 lib = _load()
 if lib.mt4_abi_version() != ABI_VERSION:      # a stale libmt4hip.so next to newer Python: fail at import, not in the first launch
     raise ImportError(f"libmt4hip.so reports ABI {lib.mt4_abi_version()}, this package binds ABI {ABI_VERSION}: rebuild (make -C computervision_codes_amd/csrc)")

@@ -93,16 +93,17 @@ def load_frames_device(data_dir: str, video: str, frame_ids, height: int = 256, 
         # decode = "device": the files are only read; inflate + unfiltering run on the GPU (`pngdec.decode_batch`, 8-bit RGB non-interlaced PNGs --
         # what the dataset ships; anything else raises `pngdec.UnsupportedPng`).  Same bytes as the Pillow path.
         from . import pngdec
-        def read_one(fid):
-            with open(os.path.join(data_dir, "data", video, "{}.png".format(str(int(fid)).zfill(6))), "rb") as fh:
-                return fh.read()
-        if workers > 1 and len(frame_ids) > 1:        # (file reads release the GIL: one thread read 0.65 MB files at ~3 GB/s, the whole pipeline's limit)
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=workers) as ex:
-                files = list(ex.map(read_one, frame_ids))
-        else:
-            files = [read_one(fid) for fid in frame_ids]
+        paths = [os.path.join(data_dir, "data", video, "{}.png".format(str(int(fid)).zfill(6))) for fid in frame_ids]
         try:
+            try:      # one frame size (a video): the files go to the device as they lie on disk, no host copy of the compressed bytes
+                x = pngdec.decode_files(paths, device, workers=max(8, workers))
+                return x if tuple(x.shape[1:3]) == (height, width) else ops.resize_bilinear_u8(x, height, width)
+            except pngdec.MixedSizes:
+                pass
+            files = []
+            for p in paths:
+                with open(p, "rb") as fh:
+                    files.append(fh.read())
             sizes: Dict[tuple, List[int]] = {}
             for i, f in enumerate(files):
                 w0, h0, _ = pngdec._idat_spans(f)

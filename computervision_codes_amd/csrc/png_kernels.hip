@@ -475,6 +475,27 @@ extern "C" int mt4_png_inflate(const uint8_t* streams, const int64_t* offsets, c
     return mt4_check_launch();
 }
 
+// byte spans src[src_off[i] .. + len[i]) -> dst[dst_off[i] ..): the IDAT payloads of whole PNG files (uploaded as they lie on disk) packed into
+// the contiguous zlib streams mt4_png_inflate reads -- the host neither copies nor touches the compressed bytes.  One workgroup per span.
+namespace {
+__global__ __launch_bounds__(256) void copy_spans_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const long long* __restrict__ so,
+                                                         const long long* __restrict__ dof, const int* __restrict__ len) {
+    const uint8_t* s = src + so[blockIdx.x];
+    uint8_t* d = dst + dof[blockIdx.x];
+    const int l = len[blockIdx.x];
+    for (int i = threadIdx.x; i < l; i += 256) d[i] = s[i];
+}
+}  // namespace
+
+extern "C" int mt4_copy_spans_u8(const uint8_t* src, uint8_t* dst, const int64_t* src_off, const int64_t* dst_off, const int32_t* len, int32_t n,
+                                 void* stream) {
+    mt4_clear_error();
+    if (!src || !dst || !src_off || !dst_off || !len || n <= 0) return MT4_EINVAL;
+    hipLaunchKernelGGL(copy_spans_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, src, dst, (const long long*)src_off,
+                       (const long long*)dst_off, len);
+    return mt4_check_launch();
+}
+
 // the filtered scanlines of mt4_png_inflate -> uint8 frames [B][H][W][3] (PNG color type 2, bit depth 8, no interlace)
 extern "C" int mt4_png_unfilter_rgb8(const uint8_t* raw, uint8_t* out, int32_t B, int32_t H, int32_t W, int64_t raw_stride, int32_t* status,
                                      void* stream) {

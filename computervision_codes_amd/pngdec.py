@@ -22,6 +22,10 @@ class UnsupportedPng(ValueError):
     pass
 
 
+class MixedSizes(UnsupportedPng):
+    """the files of one call do not share a frame size (the caller groups them)"""
+
+
 def parse_png(data: bytes) -> Tuple[int, int, bytes]:
     """(width, height, DEFLATE stream) of an 8-bit RGB, non-interlaced PNG: chunk walk only (PNG spec 5.3), the zlib header
     (RFC 1950: CM = 8, no preset dictionary) stripped, the Adler-32 trailer left in place behind the last block"""
@@ -97,7 +101,7 @@ def decode_batch(files: Sequence[bytes], device="cuda", timings: dict = None, wo
     metas = [_idat_spans(f) for f in files]
     w, h = metas[0][0], metas[0][1]
     if any((m[0], m[1]) != (w, h) for m in metas):
-        raise UnsupportedPng("frames of different sizes in one batch")
+        raise MixedSizes("frames of different sizes in one batch")
     n = len(metas)
     lengths = np.array([sum(l for _, l in m[2]) - 2 for m in metas], dtype=np.int32)      # without the 2-byte zlib header
     if int(lengths.min()) < 4:
@@ -132,6 +136,11 @@ def decode_batch(files: Sequence[bytes], device="cuda", timings: dict = None, wo
     streams = blob.to(dev, non_blocking=True)
     offs = torch.from_numpy(offsets).to(dev)
     lens = torch.from_numpy(lengths).to(dev)
+    return _decode_streams(streams, offs, lens, n, h, w, dev, timings)
+
+
+def _decode_streams(streams, offs, lens, n, h, w, dev, timings=None) -> torch.Tensor:
+    """inflate + unfilter of n zlib streams that lie in `streams` (device) at `offs` / `lens` (device arrays)"""
     raw_len = h * (1 + 3 * w)
     raw_stride = (raw_len + 15) // 16 * 16
     raw = torch.empty((n, raw_stride), dtype=torch.uint8, device=dev)
@@ -155,3 +164,69 @@ def decode_batch(files: Sequence[bytes], device="cuda", timings: dict = None, wo
         bad = int(torch.nonzero(st)[0])
         raise RuntimeError(f"PNG decode failed: frame {bad} of the batch, code {int(st[bad])} (include/mt4hip.h: mt4_png_inflate)")
     return out
+
+
+def decode_files(paths: Sequence[str], device="cuda", timings: dict = None, workers: int = 8) -> torch.Tensor:
+    """PNG files on disk (ONE frame size) -> uint8 [N,H,W,3] on the device, as `decode_batch`, without a host copy of the compressed bytes:
+    the files are read straight into one pinned buffer (`readinto`, `workers` threads), uploaded as they lie on disk, and their IDAT
+    payloads are packed into contiguous zlib streams on the device (`mt4_copy_spans_u8`).  The host only walks the chunk lists."""
+    import os
+    n = len(paths)
+    sizes = np.array([os.path.getsize(p) for p in paths], dtype=np.int64)
+    foff = np.zeros(n, dtype=np.int64)
+    foff[1:] = np.cumsum((sizes[:-1] + 15) // 16 * 16)
+    total = int(foff[-1] + sizes[-1])
+    blob = _staging(total)
+    host = blob.numpy()
+    metas: List = [None] * n
+
+    def read_one(i):
+        view = memoryview(host)[int(foff[i]):int(foff[i] + sizes[i])]
+        with open(paths[i], "rb", buffering=0) as fh:
+            got = 0
+            while got < len(view):
+                k = fh.readinto(view[got:])
+                if not k:
+                    raise UnsupportedPng(f"{paths[i]}: short read")
+                got += k
+        m = _idat_spans(view)
+        so, sl = m[2][0]
+        if sl < 2 or (view[so] & 0x0F) != 8 or ((view[so] << 8) | view[so + 1]) % 31 != 0 or (view[so + 1] & 0x20):
+            raise UnsupportedPng("bad zlib header")
+        metas[i] = m
+
+    if workers > 1 and n >= 2 * workers:        # (reads release the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(read_one, range(n)))
+    else:
+        for i in range(n):
+            read_one(i)
+    w, h = metas[0][0], metas[0][1]
+    if any((m[0], m[1]) != (w, h) for m in metas):
+        raise MixedSizes("frames of different sizes in one batch")
+    lengths = np.array([sum(l for _, l in m[2]) - 2 for m in metas], dtype=np.int32)      # without the 2-byte zlib header
+    if int(lengths.min()) < 4:
+        raise UnsupportedPng("empty zlib stream")
+    offsets = np.zeros(n, dtype=np.int64)
+    offsets[1:] = np.cumsum(lengths[:-1].astype(np.int64))
+    src, dst, ln = [], [], []
+    for i, m in enumerate(metas):
+        o, skip = int(offsets[i]), 2
+        for so, sl in m[2]:
+            if skip:
+                so, sl, skip = so + skip, sl - skip, 0
+            if sl:
+                src.append(int(foff[i]) + so); dst.append(o); ln.append(sl)
+            o += sl
+    dev = torch.device(device)
+    files_dev = blob.to(dev, non_blocking=True)
+    spans = torch.from_numpy(np.array([src, dst], dtype=np.int64)).to(dev)
+    span_len = torch.from_numpy(np.array(ln, dtype=np.int32)).to(dev)
+    streams = torch.empty(int(offsets[-1] + lengths[-1]) + 1024, dtype=torch.uint8, device=dev)     # (+ 1 KB: the decoder prefetches 512-byte pieces)
+    streams[-1024:].zero_()
+    check(lib.mt4_copy_spans_u8(files_dev.data_ptr(), streams.data_ptr(), spans[0].data_ptr(), spans[1].data_ptr(), span_len.data_ptr(), len(ln),
+                                ops._stream()), "mt4_copy_spans_u8")
+    offs = torch.from_numpy(offsets).to(dev)
+    lens = torch.from_numpy(lengths).to(dev)
+    return _decode_streams(streams, offs, lens, n, h, w, dev, timings)

@@ -188,6 +188,10 @@ int mt4_preprocess_u8_s2d(const uint8_t* frames, void* out, int32_t B, int32_t H
 int mt4_png_inflate(const uint8_t* streams, const int64_t* offsets, const int32_t* lengths, uint8_t* raw, int32_t B, int64_t raw_stride,
                     int64_t raw_len, int32_t* status, void* stream);
 int mt4_png_unfilter_rgb8(const uint8_t* raw, uint8_t* out, int32_t B, int32_t H, int32_t W, int64_t raw_stride, int32_t* status, void* stream);
+/* n byte spans src[src_off[i] .. + len[i]) -> dst[dst_off[i] ..) (device pointers and device offset / length arrays): packs the IDAT payloads
+ * of PNG files uploaded whole into the contiguous streams mt4_png_inflate reads (pngdec.decode_files; the reference's PIL reads the chunks on
+ * the host, Spatial_cnn/dataloader.py:257-261). */
+int mt4_copy_spans_u8(const uint8_t* src, uint8_t* dst, const int64_t* src_off, const int64_t* dst_off, const int32_t* len, int32_t n, void* stream);
 
 /* One separable pass of Pillow's 8-bit resize (`Image.resize(size, BILINEAR)` = `transforms.Resize((256,448))`,
  * Spatial_cnn/dataloader.py:155-159, Spatial_transformer likewise): out = clip8((2^21 + sum_i in[lo+i] * coeffs[o][i]) >> 22).

@@ -87,3 +87,24 @@ def test_png_decode_rejects_what_it_does_not_cover(cuda):
         bad[i] ^= 0xFF
         bad[i + 1] ^= 0x5A
         pngdec.decode_batch([bytes(bad), good], cuda)
+
+
+def test_png_decode_files_from_disk_equals_decode_batch(cuda, tmp_path):
+    """`decode_files`: the files read straight into pinned memory, uploaded whole, IDAT payloads packed on the device (`mt4_copy_spans_u8`) --
+    same frames as `decode_batch` on the same bytes (multi-chunk IDAT: frames large enough for several 64 KB chunks); mixed sizes are refused"""
+    from computervision_codes_amd import pngdec
+    frames = _frames(19, 200, 320, 3, "photo")
+    paths = []
+    for i in range(19):
+        f = _png(frames[i], compress_level=(1, 6, 9)[i % 3])
+        p = tmp_path / f"{i:06d}.png"
+        p.write_bytes(f)
+        paths.append(str(p))
+    assert len(pngdec._idat_spans(open(paths[0], "rb").read())[2]) > 1
+    a = pngdec.decode_files(paths, cuda, workers=4)
+    b = pngdec.decode_batch([open(p, "rb").read() for p in paths], cuda)
+    assert torch.equal(a, b) and np.array_equal(a.cpu().numpy(), frames)
+    odd = tmp_path / "odd.png"
+    odd.write_bytes(_png(_frames(1, 64, 96, 5, "photo")[0]))
+    with pytest.raises(pngdec.MixedSizes):
+        pngdec.decode_files(paths[:3] + [str(odd)], cuda)
