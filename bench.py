@@ -389,7 +389,57 @@ def e2e_script_bench(dev):
                 excludes="PNG decode and H2D of the frames (host side)")
             del m
     out["png_decode_480x854"] = png_decode_bench(dev)
+    try:
+        out["from_png_files_480x854"] = png_files_bench(dev)
+    except Exception as e:                       # (no writable temp directory / no Pillow: the record says so, the bench line stands)
+        out["from_png_files_480x854"] = {"error": repr(e)}
     return out
+
+
+def png_files_bench(dev, n=2048):
+    """The same per-video loop from PNG FILES on disk, decode included (what `Spatial_cnn/test.py` does per video): n synthetic frames of the
+    dataset's native 480 x 854 written to a temp directory, `cholect.load_frames_device` (decode, Resize to 256 x 448) -> ResNet-50 bf16 ->
+    one D2H; Pillow on 16 host threads against the device decoder as the extraction driver runs it (loads of 1024 frames, two ahead)."""
+    import io
+    import shutil
+    import tempfile
+    from PIL import Image
+    from computervision_codes_amd import cholect, extract, shapes, synth
+    from computervision_codes_amd.spatial_cnn import VideoNas
+    root = tempfile.mkdtemp(prefix="mt4_png_")
+    try:
+        os.makedirs(os.path.join(root, "data", "VID01"))
+        h, w = 480, 854
+        rng = np.random.default_rng(0)
+        y, x = np.mgrid[0:h, 0:w]
+        blobs = []
+        for i in range(16):
+            base = (np.stack([(x + 7 * i) % 256, (y * 2 + 3 * i) % 256, ((x + y) // 2) % 256], -1)).astype(np.int32)
+            wave = 40 * np.sin(x[..., None] / (17.0 + i) + np.arange(3)) * np.cos(y[..., None] / (23.0 + i))
+            fr = np.clip(base * 0.5 + 60 + wave + rng.normal(0, 3.0, (h, w, 3)), 0, 255).astype(np.uint8)
+            b = io.BytesIO()
+            Image.fromarray(fr, "RGB").save(b, format="PNG")
+            blobs.append(b.getvalue())
+        for i in range(n):
+            with open(os.path.join(root, "data", "VID01", f"{i:06d}.png"), "wb") as f:
+                f.write(blobs[i % 16])
+        args = types.SimpleNamespace(network="resnet50", loss_type="all", student_dim=2048, teacher_dim=1536, train=False)
+        m = VideoNas(args=args, dtype=torch.bfloat16, device=str(dev)).eval().load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes("resnet50"), seed=3))
+        ids = np.arange(n)
+        rec, ref = {"frames_per_video": n, "kb_per_png": len(blobs[0]) // 1000, "network": "resnet50 bf16, Resize to 256x448"}, None
+        for key, decode, load_batch, depth in (("pillow_16_threads", "host", None, 1), ("device_decode", "device", 1024, 2)):
+            load = lambda s, e: cholect.load_frames_device(root, "VID01", ids[s:e], 256, 448, device=dev, workers=16, decode=decode)
+            run = lambda: extract.extract_video_device(m, n, load, 512, prefetch=depth, load_batch=load_batch)
+            run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            feat, _ = run()
+            dt_s = time.perf_counter() - t0
+            ref = feat.copy() if ref is None else ref
+            rec[key] = dict(frames_per_s=round(n / dt_s, 1), ms_per_video=round(dt_s * 1e3, 1), same_features=bool(np.array_equal(ref, feat)))
+        return rec
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def png_decode_bench(dev, n=2560):
