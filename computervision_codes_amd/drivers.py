@@ -395,9 +395,12 @@ def spatial_transformer_test(argv=None) -> Dict[str, np.ndarray]:
         step = max(1, min(F.device_batch, 256))
         load = lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.img_size, F.img_size, workers=F.decode_workers,
                                                        decode=F.png_decode)
-        spans = [(s, min(len(ids_all), s + step)) for s in range(0, len(ids_all), step)]
-        for fr in extract.iter_chunks(spans, load):            # the next span is decoded while this one runs
-            chunks.append(model(fr)[3][0].float())
+        dev_dec = F.png_decode == "device"                     # (the device decoder wants >= 1024 frames per call; two loads run ahead)
+        lb = max(step, 1024 // step * step) if dev_dec else step
+        spans = [(s, min(len(ids_all), s + lb)) for s in range(0, len(ids_all), lb)]
+        for span in extract.iter_chunks(spans, load, 2 if dev_dec else 1):      # the next load is decoded while this one runs
+            for s in range(0, span.shape[0], step):
+                chunks.append(model(span[s:s + step])[3][0].float())
         feats_local[featfile.video_key(v, "transformer")] = torch.vstack(chunks).cpu().numpy()
     merged = extract.gather_feats(feats_local)
     if rank == 0:

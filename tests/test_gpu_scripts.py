@@ -177,7 +177,8 @@ def test_teacher_pipeline_scripts_chain_into_student_training(cuda, tmp_path):
     env = dict(os.environ, PYTHONPATH=ROOT, VERSION="T", IN_DIM="768", IM_SIZE="224", BACKBONE="swin_T_224_1k")
     base = tree / "0-5fold" / "data_feats"
     for t, k in (("i", 6), ("v", 10), ("t", 15)):
-        r = subprocess.run(["bash", "test_fold1_teacher.sh", "--data_dir", data], cwd=tree / "Scripts", env=dict(env, TASK=t),
+        extra = ["--png_decode", "device"] if t == "v" else []        # (one task through the device PNG decoder: same files downstream)
+        r = subprocess.run(["bash", "test_fold1_teacher.sh", "--data_dir", data] + extra, cwd=tree / "Scripts", env=dict(env, TASK=t),
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         feats = pickle.load(open(base / "run_T" / f"k1_{t}_feats.pkl", "rb"))            # run_<version as given>, NOT run_T_<task>
