@@ -114,8 +114,9 @@ def load_frames_device(data_dir: str, video: str, frame_ids, height: int = 256, 
                 y = x if (h0, w0) == (height, width) else ops.resize_bilinear_u8(x, height, width)
                 out[torch.tensor(idx, device=device)] = y
             return out
-        except pngdec.UnsupportedPng as e:
-            # a PNG flavour the device decoder does not cover (palette, grey, alpha, 16-bit, interlaced): this batch goes through Pillow; said once
+        except (pngdec.UnsupportedPng, pngdec.DecodeError) as e:
+            # a PNG flavour the device decoder does not cover (palette, grey, alpha, 16-bit, interlaced), or a stream it reports as bad (Pillow
+            # then has the last word on the file): this batch goes through Pillow; said once
             global _WARNED_PNG
             if not _WARNED_PNG:
                 print(f"[cholect] --png_decode device: {e}; such files are decoded by Pillow on the host", flush=True)

@@ -22,6 +22,10 @@ class UnsupportedPng(ValueError):
     pass
 
 
+class DecodeError(RuntimeError):
+    """the device decoder reported a bad stream (status codes of mt4_png_inflate / mt4_png_unfilter_rgb8)"""
+
+
 class MixedSizes(UnsupportedPng):
     """the files of one call do not share a frame size (the caller groups them)"""
 
@@ -162,7 +166,7 @@ def _decode_streams(streams, offs, lens, n, h, w, dev, timings=None) -> torch.Te
         timings["inflate_ms"], timings["unfilter_ms"] = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
     if int(st.abs().max()) != 0:
         bad = int(torch.nonzero(st)[0])
-        raise RuntimeError(f"PNG decode failed: frame {bad} of the batch, code {int(st[bad])} (include/mt4hip.h: mt4_png_inflate)")
+        raise DecodeError(f"PNG decode failed: frame {bad} of the batch, code {int(st[bad])} (include/mt4hip.h: mt4_png_inflate)")
     return out
 
 
