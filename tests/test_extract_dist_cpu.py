@@ -82,3 +82,21 @@ def test_world2_gloo_extraction_equals_single_process(tmp_path):
     assert list(got) == list(single)
     for k in single:
         assert np.array_equal(got[k], single[k])
+
+
+def test_iter_chunks_yields_spans_in_order_without_a_gpu():
+    """`extract.iter_chunks` on a host without a GPU: no helper threads, every span loaded in order exactly once (the GPU path with helper
+    threads is covered by tests/test_gpu_models.py)"""
+    import torch
+    from computervision_codes_amd import extract
+    asked = []
+
+    def load(s, e):
+        asked.append((s, e))
+        return torch.arange(s, e)
+    spans = [(0, 4), (4, 8), (8, 9)]
+    for depth in (0, 1, 2, True):
+        asked.clear()
+        got = [t.tolist() for t in extract.iter_chunks(spans, load, depth)]
+        assert asked == spans and got == [[0, 1, 2, 3], [4, 5, 6, 7], [8]]
+    assert list(extract.iter_chunks([], load, 2)) == []
