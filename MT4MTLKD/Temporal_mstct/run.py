@@ -11,6 +11,6 @@ if __name__ == "__main__":
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+        dist.init_process_group(os.environ.get("MT4_DIST_BACKEND", "nccl"))   # RCCL; "gloo" = several ranks on one GPU (tests)
     mstct_run(sys.argv[1:])

@@ -429,7 +429,14 @@ def mstct_test(argv=None):
     out_feats, out_preds = {}, {}
     gi = {"i": 0, "v": 1, "t": 2, "ivt": 3}[F.loss_type]
     graphed = None                                                                         # full chunks: one hipGraph replay each (~100 launches, launch-bound)
-    for key, f in feats.items():
+    # under torchrun (`Scripts/train_fold1.sh` with NGPU > 1 runs `run.py -t -e`) whole videos are sharded over the ranks like the spatial
+    # extractors' (no data-path collective), the per-rank dicts meet in one host-side gather and rank 0 alone writes the two files
+    rank, world = _dist()
+    keys = list(feats.keys())
+    mine = set(extract.shard_videos(keys, [feats[k].shape[0] for k in keys], rank, world))
+    for ki, (key, f) in enumerate(feats.items()):
+        if ki not in mine:
+            continue
         fs, ps = [], []
         for s in range(0, f.shape[0], 256):                                                # non-overlapping 256-frame chunks
             x = torch.from_numpy(f[s:s + 256]).unsqueeze(0).cuda()
@@ -443,8 +450,14 @@ def mstct_test(argv=None):
             ps.append(o[gi][0][0].float().cpu())                                           # raw logits [T,K]
             fs.append(o[3][1][0].transpose(0, 1).float().cpu())                            # concat feature [T,2048]
         out_feats[key], out_preds[key] = torch.vstack(fs).numpy(), torch.vstack(ps).numpy()
-    featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type, "feats"), out_feats)
-    featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type, "pred"), out_preds)
+    out_feats, out_preds = extract.gather_feats(out_feats), extract.gather_feats(out_preds)
+    out_feats, out_preds = {k: out_feats[k] for k in keys}, {k: out_preds[k] for k in keys}      # file order = input order, whatever the sharding
+    try:
+        if rank == 0:
+            featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type, "feats"), out_feats)
+            featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type, "pred"), out_preds)
+    finally:
+        _barrier()                                                                         # the files exist before any rank goes on to the next stage
     return out_feats, out_preds
 
 

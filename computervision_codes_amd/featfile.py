@@ -43,10 +43,14 @@ def _canon(a) -> np.ndarray:
 def write_feats(path: str, feats: Mapping[str, np.ndarray]) -> None:
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     payload = {str(k): _canon(v) for k, v in feats.items()}
-    tmp = path + ".tmp"
-    with open(tmp, "wb") as f:
-        pickle.dump(payload, f)
-    os.replace(tmp, path)
+    tmp = f"{path}.{os.getpid()}.tmp"          # per-process name: two writers of one path never share a half-written file
+    try:
+        with open(tmp, "wb") as f:
+            pickle.dump(payload, f)
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
 
 
 def read_feats(path: str) -> Dict[str, np.ndarray]:

@@ -650,7 +650,96 @@ def gen_q2l_train(name):
         torch.set_grad_enabled(False)
 
 
+Q2L_TRAIN_ALL_CASES = {
+    # `Spatial_transformer/run.py -t --loss_type all` (`:183-197`): the Res -> Swin direction of MT4MTL-KD (BASELINE configs[4])
+    "q2l_train_swinT_all": dict(backbone="swin_T_224_1k", img=224, hidden=768, teacher_dim=512, B=2, seed=811, lr=0.05, rates=(1.0, 0.7, 0.4), temp=4.0),
+}
+
+
+def q2l_train_all_inputs(cfg):
+    img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["img"], cfg["img"], seed=cfg["seed"]))
+    labels = [torch.from_numpy((synth.uniform01(cfg["seed"], 900 + i, cfg["B"] * k) < 0.2).reshape(cfg["B"], k).astype(np.int64))
+              for i, k in enumerate((6, 10, 15, 100))]
+    tpred = [synth.synthetic_features(cfg["B"], k, seed=cfg["seed"] + 10 + i)[0] * 2.0 for i, k in enumerate((6, 10, 15))]
+    tfeat = [synth.synthetic_features(cfg["B"], cfg["teacher_dim"], seed=cfg["seed"] + 20 + i)[0] for i in range(3)]
+    return img, labels, tpred, tfeat
+
+
+def gen_q2l_train_all(name):
+    """The reference `Qeruy2Label(loss_type='all')` in train() mode (four decoders over the shared transformer, KD mixing on), the loss of
+    `Spatial_transformer/run.py:164-167,183-197` (4 x BCE, 3 x DistillKL `:284-295`, 3 x MSE, `--rates`) and torch.optim.SGD (`:360`) for one
+    step; random modules neutral as in `gen_q2l_train`."""
+    from oracle import q2l_train as o_qt
+    from oracle import spatial_cnn_train as o_ct
+    cfg = Q2L_TRAIN_ALL_CASES[name]
+    torch.set_grad_enabled(True)
+    try:
+        m = _ref_q2l(cfg["backbone"], cfg["img"], cfg["hidden"], "all", teacher_dim=cfg["teacher_dim"])
+        m.train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        table = shapes.q2l_param_shapes(cfg["backbone"], cfg["img"], cfg["hidden"], "all", teacher_dim=cfg["teacher_dim"])
+        _check_params(table, m, name, buffers_ok=shapes.SWIN_BUFFER_SUFFIXES)
+        sd = synth.fill_from_shapes(table, seed=cfg["seed"])
+        missing = m.load_state_dict(sd, strict=False)
+        ali = dict(shapes.q2l_state_dict_aliases(cfg["hidden"]))
+        assert not missing.unexpected_keys and all(k.endswith(shapes.SWIN_BUFFER_SUFFIXES) or k in ali for k in missing.missing_keys)
+        img, labels, tpred, tfeat = q2l_train_all_inputs(cfg)
+        opt = torch.optim.SGD(m.parameters(), lr=cfg["lr"], weight_decay=1e-5)
+        (cam_i, li), (cam_v, lv), (cam_t, lt), (feat, livt) = m(img, *tfeat)
+        f_i = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(o_ct.TOOL_W))
+        f_v = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(o_ct.VERB_W))
+        f_t = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(o_ct.TARGET_W))
+        f_ivt = torch.nn.BCEWithLogitsLoss()
+        hard = f_i(li, labels[0].float()) + f_v(lv, labels[1].float()) + f_t(lt, labels[2].float()) + f_ivt(livt, labels[3].float())
+        soft = sum(o_ct.distill_kl(l, torch.sigmoid(tp), cfg["temp"]) for l, tp in zip((li, lv, lt), tpred)) / 3
+        kd = sum(torch.nn.functional.mse_loss(c, f) for c, f in zip((cam_i, cam_v, cam_t), tfeat)) / 3
+        r = cfg["rates"]
+        loss = r[0] * hard + r[1] * soft + r[2] * kd
+        for p_ in m.parameters():
+            p_.grad = None
+        loss.backward()
+        grads = {k: (p_.grad.clone() if p_.grad is not None else None) for k, p_ in m.named_parameters()}
+        opt.step()
+        new_ref = {k: v.detach().clone() for k, v in m.named_parameters()}
+        keys = [k for k, _ in table]
+        assert all(grads[k] is not None for k in keys), [k for k in keys if grads[k] is None][:5]
+        new_o, terms_o, g_o = o_qt.train_step_all(sd, img, labels, tpred, tfeat, cfg["backbone"], cfg["img"], cfg["hidden"], cfg["lr"], 1e-5, r, cfg["temp"])
+        assert abs(terms_o["loss"] - float(loss)) < 2e-5 * max(1, abs(float(loss))), (terms_o["loss"], float(loss))
+        worst = 0.0
+        for k in keys:
+            e = _rel(new_o[k].float(), new_ref[k].float())
+            worst = max(worst, e)
+            assert e < 2e-4, (name, k, e)
+        _, _, g64 = o_qt.train_step_all_f64(sd, img, labels, tpred, tfeat, cfg["backbone"], cfg["img"], cfg["hidden"], cfg["lr"], 1e-5, r, cfg["temp"])
+        outd = {"cfg": np.array(repr(cfg)), "loss": np.array(float(loss)), "hard": np.array(float(hard)), "soft": np.array(float(soft)),
+                "kd": np.array(float(kd)), "logit_i": li.detach().numpy(), "logit_v": lv.detach().numpy(), "logit_t": lt.detach().numpy(),
+                "logit_ivt": livt.detach().numpy(), "feat": feat.detach().numpy(), "kd_i": cam_i.detach().numpy(),
+                "grad_norms": np.array([float(grads[k].norm()) for k in keys], dtype=np.float64),
+                "grad_cond": np.array([float((grads[k].double() - g64[k]).abs().max() / max(float(g64[k].abs().max()), 1e-30)) for k in keys],
+                                      dtype=np.float64)}
+        t = "decoder_i.transformer."
+        samp = ["backbone.0.patch_embed.proj.weight", "backbone.0.layers.0.blocks.1.attn.relative_position_bias_table",
+                "backbone.0.layers.2.blocks.5.mlp.fc2.weight", "backbone.0.norm.bias",
+                "decoder_i.input_proj.weight", "decoder_v.query_embed.weight", "decoder_t.fc.W", "decoder_ivt.fc.b", "decoder_ivt.input_proj.bias",
+                t + "encoder.layers.0.self_attn.in_proj_weight", t + "encoder.layers.0.linear1.weight", t + "encoder.layers.0.norm2.weight",
+                t + "decoder.layers.0.multihead_attn.out_proj.weight", t + "decoder.layers.1.linear2.weight", t + "decoder.norm.weight",
+                "wi.weight", "wv.bias", "mt.weight", "mi.bias"]
+        for k in samp:
+            flat = (new_ref[k].float() - sd[k].float()).flatten()
+            outd["delta::" + k] = flat[:: max(1, flat.numel() // 2048)].numpy()
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **outd)
+        print(name, "ok: loss", float(loss), "hard", float(hard), "soft", float(soft), "kd", float(kd), "worst oracle-vs-ref rel", worst,
+              "grad_cond median", float(np.median(outd["grad_cond"])), "max", float(outd["grad_cond"].max()))
+    finally:
+        torch.set_grad_enabled(False)
+
+
 GENERATORS = {}
+GENERATORS.update({k: gen_q2l_train_all for k in Q2L_TRAIN_ALL_CASES})
 GENERATORS.update({k: gen_q2l_train for k in Q2L_TRAIN_CASES})
 GENERATORS.update({k: gen_mstct_train for k in MSTCT_TRAIN_CASES})
 GENERATORS.update({k: gen_tenco for k in TENCO_CASES})

@@ -92,12 +92,14 @@ def _mha(sd, p, q, k, v, nhead, attn_mask):
     return F.linear(a, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
 
 
-def decoder_logits(sd: SD, p: str, src, pos, tx=None, nhead=4):
-    """`Decoder.forward` (`network.py:163-171`) in train mode: logits [B, K]"""
+def decoder_logits(sd: SD, p: str, src, pos, tx=None, nhead=4, tp=None, want_feat=False, mkey=""):
+    """`Decoder.forward` (`network.py:163-171`) in train mode: logits [B, K] (want_feat: and the pooled encoder memory [B, d], `:170`).
+    tp: prefix of the transformer's parameters when it is shared (`loss_type all`: decoder_i.transformer., `network.py:66-73`);
+    mkey: prefix of this decoder's dropout-mask keys ('ivt/' ...)"""
     tx = tx or {}
-    g = lambda k: tx.get(k)
+    g = lambda k: tx.get(mkey + k)
     x = F.conv2d(src, sd[p + "input_proj.weight"], sd[p + "input_proj.bias"])
-    t = p + "transformer."
+    t = tp or (p + "transformer.")
     bs, c, h, w = x.shape
     L = h * w
     s = x.flatten(2).permute(2, 0, 1)
@@ -132,7 +134,10 @@ def decoder_logits(sd: SD, p: str, src, pos, tx=None, nhead=4):
             t2 = t2 * _rows(g(f"dec{li}.d3"), bs, K)
         tgt = o._ln(sd, d + ".norm3", tgt + t2)
     hs = o._ln(sd, t + "decoder.norm", tgt).transpose(0, 1)          # [B,K,d]
-    return (sd[p + "fc.W"] * hs).sum(-1) + sd[p + "fc.b"]
+    logits = (sd[p + "fc.W"] * hs).sum(-1) + sd[p + "fc.b"]
+    if want_feat:
+        return logits, memory.mean(dim=0)                            # AdaptiveAvgPool2d(1) over the h*w memory rows -> [B, d]
+    return logits
 
 
 def forward_train(sd: SD, img, backbone: str, img_size: int, hidden: int, task: str, masks: Optional[dict] = None):
@@ -157,3 +162,63 @@ def train_step(sd: SD, img, labels, backbone, img_size, hidden, task, lr, weight
 
 def train_step_f64(sd, img, labels, backbone, img_size, hidden, task, lr, weight_decay=1e-5, masks=None):
     return train_step({k: v.double() for k, v in sd.items()}, img.double(), labels, backbone, img_size, hidden, task, lr, weight_decay, masks)
+
+
+# ------------------------------------------------------------------------------------------------ loss_type all
+TASKS_ALL = ("i", "v", "t", "ivt")
+
+
+def forward_train_all(sd: SD, img, backbone: str, img_size: int, hidden: int, teacher_feat, masks: Optional[dict] = None):
+    """`Qeruy2Label.forward` with `loss_type all` in train mode (`network.py:82-126`): four decoders over ONE shared transformer (parameters
+    under decoder_i.transformer.*), feat = decoder_ivt's pooled memory, the KD mixing on it.  masks["tx"] keys carry the decoder's prefix
+    ('i/enc.attn', ..., 'ivt/dec1.d3').  Returns (logits dict, cams (i, v, t), feat)."""
+    from .spatial_cnn import kd_branch
+    masks = masks or {}
+    src = swin_features(sd, img, backbone, img_size, "backbone.0.", masks.get("droppath"))
+    pos = o.sine_position_encoding(hidden, img_size // 32, img_size // 32).to(src.dtype).repeat(src.shape[0], 1, 1, 1)
+    logits, feat = {}, None
+    for task in TASKS_ALL:
+        logits[task], feat = decoder_logits(sd, f"decoder_{task}.", src, pos, masks.get("tx"), tp="decoder_i.transformer.", want_feat=True,
+                                            mkey=task + "/")
+    cams = kd_branch(sd, feat, *teacher_feat)
+    return logits, cams, feat
+
+
+def loss_all(logits, cams, labels, teacher_pred, teacher_feat, rates, temp):
+    """`Spatial_transformer/run.py:164-167,183-197`: hard = sum of the four BCEs (pos_weight on i / v / t, `:339-342`), soft = mean DistillKL
+    against sigmoid(teacher logits), kd = mean MSE(cam, teacher feature)"""
+    from .spatial_cnn_train import distill_kl
+    dt = logits["i"].dtype
+    hard = {t: F.binary_cross_entropy_with_logits(logits[t], y.to(dt), pos_weight=(torch.tensor(POS_W[t], dtype=dt) if t in POS_W else None))
+            for t, y in zip(TASKS_ALL, labels)}
+    soft = [distill_kl(logits[t], torch.sigmoid(tp.to(dt)), temp) for t, tp in zip(("i", "v", "t"), teacher_pred)]
+    kdl = [F.mse_loss(c, f.to(dt)) for c, f in zip(cams, teacher_feat)]
+    hard_loss = hard["i"] + hard["v"] + hard["t"] + hard["ivt"]
+    soft_loss = (soft[0] + soft[1] + soft[2]) / 3
+    kd_loss = (kdl[0] + kdl[1] + kdl[2]) / 3
+    loss = rates[0] * hard_loss + rates[1] * soft_loss + rates[2] * kd_loss
+    terms = dict(loss=float(loss.detach()), hard=float(hard_loss.detach()), soft=float(soft_loss.detach()), kd=float(kd_loss.detach()),
+                 **{"hard_" + t: float(v.detach()) for t, v in hard.items()})
+    return loss, terms
+
+
+def train_step_all(sd: SD, img, labels, teacher_pred, teacher_feat, backbone, img_size, hidden, lr, weight_decay=1e-5, rates=(1.0, 0.0, 0.1), temp=4.0,
+                   masks=None):
+    """one SGD step of `run.py -t --loss_type all` (`:150-229`; the shared transformer is ONE parameter set: its gradient is the sum over the
+    four decoders and it steps once, as `model.parameters()` lists it once).  labels (y_i, y_v, y_t, y_ivt) multi-hot; teacher_pred 3 x raw
+    logits; teacher_feat 3 x [B, teacher_dim].  Returns (new_sd, loss terms, grads)."""
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    logits, cams, _ = forward_train_all(params, img, backbone, img_size, hidden, [t.to(img.dtype) for t in teacher_feat], masks)
+    loss, terms = loss_all(logits, cams, labels, teacher_pred, [t.to(img.dtype) for t in teacher_feat], rates, temp)
+    names = list(params)
+    grads = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)
+    g = {k: (gr if gr is not None else torch.zeros_like(params[k])) for k, gr in zip(names, grads)}
+    used = {k for k, gr in zip(names, grads) if gr is not None}
+    new = {k: (params[k].detach() - lr * (g[k] + weight_decay * params[k].detach())) if k in used else params[k].detach().clone() for k in names}
+    return new, terms, g
+
+
+def train_step_all_f64(sd, img, labels, teacher_pred, teacher_feat, backbone, img_size, hidden, lr, weight_decay=1e-5, rates=(1.0, 0.0, 0.1), temp=4.0,
+                       masks=None):
+    return train_step_all({k: v.double() for k, v in sd.items()}, img.double(), labels, [t.double() for t in teacher_pred],
+                          [t.double() for t in teacher_feat], backbone, img_size, hidden, lr, weight_decay, rates, temp, masks)
