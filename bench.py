@@ -36,12 +36,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1336, help="frames per GPU per step (1336: layer3/4 tile counts land on whole rounds of 256 CUs)")
+    ap.add_argument("--batch", type=int, default=2672, help="frames per stream per step (multiples of 1336: layer3/4 tile counts land on whole rounds of 256 CUs)")
     ap.add_argument("--network", default="resnet50")
     ap.add_argument("--height", type=int, default=224)
     ap.add_argument("--width", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU; every stream gets --batch frames of a step")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams per GPU; every stream gets --batch frames of a step (round 3: one stream over 2672 "
+                    "frames = two streams of 1336 within 1 %, profiles/r03_stream_skew_ab.txt -- the launches of two parts do not overlap usefully)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-temporal", action="store_true")
     ap.add_argument("--no-ddp-train", action="store_true", help="N > 1: skip the data-parallel training sub-record")
@@ -107,6 +108,17 @@ def host_cores():
         return os.cpu_count() or 1
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
 def cpu_baseline_spatial(network, h, w, seed):
     """CPU oracle (port of the reference arithmetic) on the host cores, bounded sample."""
     from computervision_codes_amd import shapes, synth
@@ -125,7 +137,7 @@ def cpu_baseline_spatial(network, h, w, seed):
             dt = time.perf_counter() - t0
             if dt > 12.0 or n >= 30:
                 break
-    return dict(value=round(bs * n / dt, 2), unit="frames/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=round(bs * n / dt, 2), unit="frames/s", cores=torch.get_num_threads(), kind="port", cpu=cpu_model(), os_cpu_count=os.cpu_count(),
                 sample=f"{n} batches of {bs} frames {h}x{w}, torch-CPU fp32 oracle, eval, no_grad")
 
 
@@ -694,29 +706,41 @@ def main():
         conv_ms = sum(per_launch)
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_MFMA_TFLOPS
         achieved = flops_frame * a.batch / (conv_ms * 1e-3) / 1e12
-        # HBM bytes of the same launches from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/collect_traffic.py),
-        # collected offline with the command recorded in profiles/README.md and committed; null when not collected for this config
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
+        # HBM bytes and MFMA-busy share of the same launches from rocprofv3 PMC passes (tools/collect_traffic.py, tools/collect_mfma_util.py;
+        # commands in profiles/README.md), collected OFFLINE and committed: a figure is published only while the sources of the measured
+        # kernels are the ones it was collected on (`kernels_sha`), and the line says which collection it is; null otherwise
+        from computervision_codes_amd.srcdigest import CONV_SOURCES, TCN_SOURCES, kernels_digest
+
+        def committed(fname, field, sources, keys):
+            """-> (value per frame or video unit, source string)"""
+            path = os.path.join(ROOT, "profiles", fname)
             try:
-                rec = json.load(open(tfile)).get(f"{a.network}_{a.dtype}_b{a.batch}_{a.height}x{a.width}")
-                traffic = rec["hbm_bytes_per_step"] * max(1, a.streams) if rec else None   # PMC figure is per stream part
+                data = json.load(open(path))
             except Exception:
-                traffic = None
-        mfma_util = None   # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GPU cycles) of the same launches (tools/collect_mfma_util.py), offline like traffic
-        ufile = os.path.join(ROOT, "profiles", "mfma_util.json")
-        if os.path.exists(ufile):
-            try:
-                rec = json.load(open(ufile)).get(f"{a.network}_{a.dtype}_b{a.batch}_{a.height}x{a.width}")
-                mfma_util = rec["mfma_util"] if rec else None
-            except Exception:
-                mfma_util = None
+                return None, "not collected"
+            for key, scale in keys:
+                rec = data.get(key)
+                if rec is None or field not in rec:
+                    continue
+                now = kernels_digest(sources)
+                if rec.get("kernels_sha") != now:
+                    return None, f"stale: profiles/{fname}[{key}] was collected on kernel sources {rec.get('kernels_sha')}, this library is built from {now}"
+                return rec[field] * scale, f"committed PMC pass profiles/{fname}[{key}] ({rec.get('collected', 'this round')}) @kernels {now}; offline, not measured in this run"
+            return None, "not collected for this configuration"
+
+        cfg = f"{a.network}_{a.dtype}_b{{}}_{a.height}x{a.width}"
+        # (per-frame figures: the conv launches' traffic scales with the frame count; the 1336-frame collection serves any multiple of it)
+        keys = [(cfg.format(a.batch), max(1, a.streams))] + ([(cfg.format(1336), nstep / 1336.0)] if a.batch % 1336 == 0 else [])
+        traffic, traffic_source = committed("traffic.json", "hbm_bytes_per_step", CONV_SOURCES, keys)
+        mfma_util, mfma_util_source = committed("mfma_util.json", "mfma_util", CONV_SOURCES, [(k, 1.0) for k, _ in keys])
         roofline = dict(bound="mfma", kernel="conv launches of one step (igemm_conv_kernel, conv3x3_patch_kernel, stem_pool_kernel, bottleneck64_fused_kernel)", achieved=round(achieved, 2),
-                        peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic, mfma_util_pmc=mfma_util,
-                        launches_per_step=len(per_launch), conv_ms_per_step=round(conv_ms, 4),
+                        peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,
+                        mfma_util_pmc=mfma_util, mfma_util_source=mfma_util_source,
+                        launches_per_step=len(per_launch), conv_ms_per_step=round(conv_ms, 4), ms_per_step=round(ms_per_step, 4),
+                        frames_in_conv_ms=a.batch,
                         gflop_per_frame=round(flops_frame / 1e9, 3), traffic_unit="HBM bytes per step (all conv launches)",
-                        note="launch durations from a single-stream pass over one stream's part of the step (HIP events on the launch stream)")
+                        note="launch durations from a single-stream pass over one stream's part of the step (HIP events on the launch stream); "
+                             "with --streams 1 that is the whole step: conv_ms_per_step <= ms_per_step, the rest is preprocess + avgpool + heads")
         if a.per_layer:
             plan = model.conv_plan(a.height, a.width)
             groups = model.launch_groups(a.height, a.width)
@@ -746,6 +770,18 @@ def main():
         }
         if world == 1 and not a.no_temporal:
             res["temporal"] = temporal_bench(dev, do_cpu=not a.no_cpu_baseline)
+            # the per-video latency half of the metric, where the driver's parsed record keeps it
+            t256, t2000 = res["temporal"]["tenco4_T256"], res["temporal"]["tenco4_T2000"]
+            tcn_traffic, tcn_src = committed("traffic.json", "hbm_bytes_per_video", TCN_SOURCES, [("tenco4_f32_T256", 1.0)])
+            roofline["temporal"] = dict(
+                kernel="tcn_conv_kernel / igemm_conv_kernel launches of one Temporal_tenco forward (4 stages, D = 512), hipGraph replay",
+                tenco4_T256_ms=t256["ms_per_video"], tenco4_T256_bf16_ms=t256["ms_per_video_bf16"], tenco4_T2000_ms=t2000["ms_per_video"],
+                tenco4_T2000_bf16_ms=t2000["ms_per_video_bf16"], bound="hbm", algorithmic_MB_T256=t256["algorithmic_MB"],
+                hbm_frac_T256=t256["hbm_frac"], f32_mfma_frac_T256=t256["f32_mfma_frac"], hbm_frac_T2000=t2000["hbm_frac"],
+                f32_mfma_frac_T2000=t2000["f32_mfma_frac"], videos_per_s=res["temporal"].get("tenco4_throughput"),
+                traffic_MB_T256=round(tcn_traffic / 1e6, 1) if tcn_traffic else None,
+                traffic_ratio_T256=round(tcn_traffic / 1e6 / t256["algorithmic_MB"], 2) if tcn_traffic else None, traffic_source=tcn_src,
+                mstct_T256_ms=res["temporal"]["mstct_T256"]["ms_per_window"])
             if dtype == torch.bfloat16 and a.network == "resnet50":
                 res["native_256x448"] = native_resolution_bench(dev, model, a.streams)
                 res["student_resnet18"] = student_resnet18_bench(dev, a.streams)

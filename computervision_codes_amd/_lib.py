@@ -174,3 +174,4 @@ def check(code: int, what: str = "") -> None:
     if code != 0:
         msg = lib.mt4_strerror(code).decode()
         raise Mt4Error(f"{what or 'mt4 call'} failed: {msg} (code {code}, hip error {lib.mt4_last_hip_error()})")
+

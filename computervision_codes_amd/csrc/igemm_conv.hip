@@ -1380,7 +1380,8 @@ constexpr TileCfg kTiles[] = {
     {256, 64}, {256, 128}, {256, 256}, {256, 64}, {256, 128}, {256, 128},                            // 21-26: conv3x3_patch_kernel
     {256, 64}, {512, 64}, {128, 64}, {128, 128}, {256, 64}, {256, 128},                              // 27-32: conv3x3_patch_kernel
     {256, 64}, {256, 64},                                                                            // 33 / 34: stem patch kernel, persistent form
-    {32, 32}, {32, 64}, {32, 32}, {32, 32}};                                                         // 35-38: generic kernel, K-split groups (4, 4, 8, 4 with 3 stages)
+    {32, 32}, {32, 64}, {32, 32}, {32, 32},                                                          // 35-38: generic kernel, K-split groups (4, 4, 8, 4 with 3 stages)
+    {64, 64}, {64, 64}, {64, 64}, {64, 128}};                                                        // 39-42: K-split groups on the 64-row tiles (2, 4, 2 with 3 stages, 2): whole-video TCN layers
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <typename T, int BM, int BN, int WM_, int WN_, int STAGES, bool OUT_F32, int KS = 1>
@@ -1488,6 +1489,10 @@ int launch_dtype(const ConvK& k, int tile, bool fast, hipStream_t s) {
         case 36: return launch_tile<T, 32, 64, 1, 4, 2, OUT_F32, 4>(k, fast, s);
         case 37: return launch_tile<T, 32, 32, 1, 2, 2, OUT_F32, 8>(k, fast, s);   // 8 groups of 2 waves
         case 38: return launch_tile<T, 32, 32, 2, 2, 3, OUT_F32, 4>(k, fast, s);   // 4 groups, 3 stages each
+        case 39: return launch_tile<T, 64, 64, 2, 2, 2, OUT_F32, 2>(k, fast, s);   // 2 groups of 4 waves
+        case 40: return launch_tile<T, 64, 64, 2, 2, 2, OUT_F32, 4>(k, fast, s);   // 4 groups of 4 waves
+        case 41: return launch_tile<T, 64, 64, 2, 2, 3, OUT_F32, 2>(k, fast, s);   // 2 groups, 3 stages each
+        case 42: return launch_tile<T, 64, 128, 2, 2, 2, OUT_F32, 2>(k, fast, s);  // 2 groups of 4 waves
     }
     return MT4_EINVAL;
 }

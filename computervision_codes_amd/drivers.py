@@ -481,7 +481,9 @@ SWIN_PRETRAIN_FILES = {"swin_L_384_22k": "swin_large_patch4_window12_384_22k.pth
 
 
 def spatial_transformer_train(argv=None) -> Dict[str, float]:
-    """`Spatial_transformer/run.py -t` (:150-229, 296-470) for the single-task teachers of the recipe (`Scripts/train_fold1.sh:12`): shuffled
+    """`Spatial_transformer/run.py -t` (:150-229, 296-470): the single-task teachers of the recipe (`Scripts/train_fold1.sh:12`, --loss_type
+    i | v | t) and the four-decoder distillation variant (--loss_type all, `run.py:183-197`: hard + DistillKL + feature-MSE terms with --rates,
+    teacher predictions / features from the files `dataloader.py:216-238` reads, zeros at validation `:240-246`).  Shuffled
     frames of all training videos in batches of --batch, the train transform at img_size x img_size (`dataloader.py:154-161`), DropPath and
     the transformer's dropout drawn per step on the device, SGD without momentum (`run.py:360`), LinearLR warm-up -> ExponentialLR per
     epoch, validation mAP of the task's head every --val_interval epochs with `_latest.pth` / best `.pth` (`weight_mgt`, :265-277).
@@ -509,20 +511,29 @@ def spatial_transformer_train(argv=None) -> Dict[str, float]:
     p.add_argument("--drop_path_rate", type=float, default=0.1)          # `swin_transformer.py:488`
     p.add_argument("--operand_dtype", type=str, default="fp32", choices=["fp32", "bf16"],
                    help="bf16: the nn.Linear GEMMs on bf16 operand copies (fp32 activations, accumulation and master weights)")
+    p.add_argument("--rates", type=float, nargs="+", default=[1, 0, 0.1])          # `run.py:66`
+    p.add_argument("--temp", type=int, default=4)                                 # `run.py:70`
+    p.add_argument("--teacher_dim", type=int, default=512)                        # `run.py:82`
+    # the reference's dataloader reads args.teacher_pred_version / teacher_feat_version (`dataloader.py:217-238`) though its run.py declares
+    # neither flag; same names and defaults as the student's `Spatial_cnn/run.py`
+    p.add_argument("--teacher_feat_version", type=str, default="Q2L")
+    p.add_argument("--teacher_pred_version", type=str, default="Q2LMSTCT")
     F, _ = p.parse_known_args(argv)
-    if F.loss_type not in ("i", "v", "t"):
-        raise StageNotBuilt("Spatial_transformer/run.py -t --loss_type all: the recipe trains single-task teachers (Scripts/train_fold1.sh:12, "
-                            "--loss_type i | v | t); the four-decoder KD variant of run.py:183-196 is not built.")
+    if F.loss_type not in ("i", "v", "t", "all"):
+        raise ValueError("--loss_type i | v | t | all (`Spatial_transformer/run.py:168-197`)")
+    single = F.loss_type != "all"
+    F.student_dim = F.hidden_dim                                             # `run.py:93`
     rank, world = _dist()
     kfold = F.kfold if "crossval" in F.dataset_variant else 0
     modelname = f"{F.model}_l{F.dataset_variant}_cholect{kfold}"
-    model_dir = f"./__checkpoint__/run_{F.version}_{F.loss_type}"            # `run.py:87-88`
+    model_dir = f"./__checkpoint__/run_{F.version}" + (f"_{F.loss_type}" if single else "")   # `run.py:86-88`
     logfile = os.path.join(model_dir, modelname + ".log")
     ckpt, latest = os.path.join(model_dir, modelname + ".pth"), os.path.join(model_dir, modelname + "_latest.pth")
     val_interval = F.epochs - 1 if F.val_interval == -1 else F.val_interval
     tr = Q2LTrainer(F.backbone, F.img_size, F.hidden_dim, F.loss_type, lr=F.initial_learning_rates[2], weight_decay=F.weight_decay,
-                    drop_path_rate=F.drop_path_rate, operand_dtype=torch.bfloat16 if F.operand_dtype == "bf16" else torch.float32)
-    table = shapes.q2l_param_shapes(F.backbone, F.img_size, F.hidden_dim, F.loss_type)
+                    drop_path_rate=F.drop_path_rate, operand_dtype=torch.bfloat16 if F.operand_dtype == "bf16" else torch.float32,
+                    teacher_dim=F.teacher_dim, rates=F.rates, temp=float(F.temp))
+    table = shapes.q2l_param_shapes(F.backbone, F.img_size, F.hidden_dim, F.loss_type, teacher_dim=F.teacher_dim)
     sd = synth.fill_from_shapes(table, seed=F.seed)          # deterministic synthetic start when no pretrained file is on disk
     # `build_backbone` (`backbone.py:188-196`): the upstream Swin checkpoint ../Pretrain/<file> ('model' entry, `head.*` dropped) into the backbone
     swin_file = os.path.join("..", "Pretrain", SWIN_PRETRAIN_FILES.get(F.backbone, ""))
@@ -540,6 +551,9 @@ def spatial_transformer_train(argv=None) -> Dict[str, float]:
     train_videos, val_videos, _ = cholect.split_videos(F.dataset_variant, kfold)
     labels = {v: cholect.load_labels(F.data_dir, v) for v in train_videos + val_videos}
     samples = [(v, i) for v in train_videos for i in range(len(labels[v]["ivt"]))]
+    tdir = lambda ver, task, kind: featfile.feats_path("..", ver, kfold, task, kind)
+    tpred = {} if single else {t: featfile.read_feats(tdir(F.teacher_pred_version, t, "pred")) for t in "ivt"}
+    tfeat = {} if single else {t: featfile.read_feats(tdir(F.teacher_feat_version, t, "feats")) for t in "ivt"}
     order_rng, aug_rng = random.Random(F.seed), random.Random(F.seed * 1000003 + rank)
     eval_args = argparse.Namespace(**vars(F))
     best, last, step_no = 0.0, {}, 0
@@ -555,9 +569,16 @@ def spatial_transformer_train(argv=None) -> Dict[str, float]:
             batch = order[bi * F.batch:(bi + 1) * F.batch]
             frames = np.concatenate([load_train_frames_u8(F.data_dir, v, [labels[v]["ivt"][i, 0]], F.img_size, F.img_size, aug_rng,
                                                           F.augmentation_list) for v, i in batch])
-            lab = torch.from_numpy(np.stack([labels[v][F.loss_type][i, 1:] for v, i in batch]))
             masks = tr.draw_masks_device(len(batch), F.seed * 1000003 + rank, step_no)
-            tot += tr.train_step(torch.from_numpy(frames).cuda(), lab, masks)
+            if single:
+                lab = torch.from_numpy(np.stack([labels[v][F.loss_type][i, 1:] for v, i in batch]))
+                tot += tr.train_step(torch.from_numpy(frames).cuda(), lab, masks)
+            else:
+                lab = [torch.from_numpy(np.stack([labels[v][k][i, 1:] for v, i in batch])) for k in ("i", "v", "t", "ivt")]
+                key = lambda v: featfile.video_key(v)
+                tp = [torch.from_numpy(np.stack([tpred[t][key(v)][i] for v, i in batch]).astype(np.float32)) for t in "ivt"]
+                tf = [torch.from_numpy(np.stack([tfeat[t][key(v)][i] for v, i in batch]).astype(np.float32)) for t in "ivt"]
+                tot += tr.train_step(torch.from_numpy(frames).cuda(), lab, masks, teacher_pred=tp, teacher_feat=tf)["loss"]
             step_no += 1
         last = {"loss": tot / steps, "lr": tr.lr}
         if rank == 0:
@@ -567,15 +588,17 @@ def spatial_transformer_train(argv=None) -> Dict[str, float]:
             torch.save(state, latest)
             model = build_q2l(eval_args, dtype=torch.float32).eval()
             model.load_state_dict(state)
-            m = Recognition({"i": 6, "v": 10, "t": 15}[F.loss_type])
-            gi = "ivt".index(F.loss_type)
+            vt = F.loss_type if single else "ivt"                  # the head the validation mAP is taken on (`run.py:443-450`)
+            m = Recognition({"i": 6, "v": 10, "t": 15, "ivt": 100}[vt])
+            gi = ("i", "v", "t", "ivt").index(vt)
             for v in val_videos:
-                lv = labels[v][F.loss_type]
+                lv = labels[v][vt]
                 vb = max(F.batch, min(getattr(F, "device_batch", F.batch), 128))     # validation passes in device batches (results do not depend on it)
                 for s0 in range(0, len(lv), vb):
                     fr = cholect.load_frames_device(F.data_dir, v, lv[s0:s0 + vb, 0], F.img_size, F.img_size,
                                                     workers=getattr(F, "decode_workers", 0), decode=getattr(F, "png_decode", "host"))
-                    m.update(lv[s0:s0 + vb, 1:], _sigmoid(model(fr)[gi][1]))
+                    zt = [] if single else [torch.zeros((fr.shape[0], F.teacher_dim), device=fr.device)] * 3   # (`dataloader.py:240-246`: zeros off the train split)
+                    m.update(lv[s0:s0 + vb, 1:], _sigmoid(model(fr, *zt)[gi][1]))
                 m.video_end()
             score = float(m.compute_video_AP()["mAP"]) if val_videos else 0.0
             last["val_mAP"] = score
@@ -583,7 +606,7 @@ def spatial_transformer_train(argv=None) -> Dict[str, float]:
                 best = max(best, score)
                 torch.save(state, ckpt)
                 _log(logfile, f">>> Saving checkpoint for epoch {epoch + 1} at {ckpt}, time {time.ctime()} ")
-            _log(logfile, f"\t\t\t\t\t\t\t video-wise | eta {time.time() - t0:.2f} secs | mAP => {F.loss_type}: [{score:.5f}] ")
+            _log(logfile, f"\t\t\t\t\t\t\t video-wise | eta {time.time() - t0:.2f} secs | mAP => {vt}: [{score:.5f}] ")
         _barrier()
     return last
 

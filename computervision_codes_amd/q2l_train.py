@@ -1,7 +1,10 @@
 """One training step of the Swin + Query2Label teacher on MI355X: forward (train mode), BCE-with-logits(pos_weight), backward and SGD, as
 `Spatial_transformer/run.py:150-229` does with torch autograd over `Spatial_transformer/network.py:82-128` -- here as explicit HIP launches.
 Single-task teachers (`--loss_type i|v|t`: what `Scripts/train_fold1.sh:12-14` trains): one `Decoder` over the backbone, the loss is that
-head's BCE alone (`run.py:168-182`).
+head's BCE alone (`run.py:168-182`).  `--loss_type all` (`run.py:183-197`, the Res -> Swin direction of MT4MTL-KD): four `Decoder`s over ONE
+shared `Transformer` (`network.py:66-73`: its parameters exist once, their gradient is the sum over the four passes), the always-on KD mixing
+on decoder_ivt's pooled memory (`network.py:98-124`; `mt4_kd_mix` / `mt4_kd_mix_bwd_f32`), loss = rates[0] * (4 x BCE) + rates[1] * mean
+DistillKL + rates[2] * mean MSE (`mt4_distill_kl_f32`, `mt4_mse_f32`).
 
 * every nn.Linear / 1x1 conv / the 4x4 patch-embedding conv: `mt4_conv_nhwc` forward, the same kernel with transposed weights for data
   gradients, `mt4_wgrad_conv1d_f32` + `mt4_colsum_f32` for parameter gradients;
@@ -31,7 +34,8 @@ from .spatial_cnn_train import TARGET_W, TOOL_W, VERB_W
 from .tenco_train import allreduce_sum_flat
 
 F32 = torch.float32
-NCLS = {"i": 6, "v": 10, "t": 15}
+NCLS = {"i": 6, "v": 10, "t": 15, "ivt": 100}
+TASKS_ALL = ("i", "v", "t", "ivt")
 POS_W = {"i": TOOL_W, "v": VERB_W, "t": TARGET_W}                                   # `Spatial_transformer/run.py:312-316,339-341`
 NHEAD, FFN = 4, 8192                                                               # `transformer.py:347-359` (build_transformer)
 
@@ -139,10 +143,13 @@ class FlatParams:
 class Q2LTrainer:
     def __init__(self, backbone: str = "swin_L_384_22k", img_size: int = 384, hidden_dim: int = 1536, loss_type: str = "i", lr: float = 0.01,
                  weight_decay: float = 1e-5, drop_path_rate: float = 0.1, device: str = "cuda", process_group=None,
-                 operand_dtype: torch.dtype = torch.float32):
-        if loss_type not in NCLS:
-            raise NotImplementedError("the teacher recipe trains single-task heads: loss_type i | v | t (Scripts/train_fold1.sh:12-14)")
-        self.backbone, self.S, self.d, self.task, self.K = backbone, int(img_size), int(hidden_dim), loss_type, NCLS[loss_type]
+                 operand_dtype: torch.dtype = torch.float32, teacher_dim: int = 512, rates=(1.0, 0.0, 0.1), temp: float = 4.0):
+        if loss_type not in ("i", "v", "t", "all"):
+            raise ValueError("loss_type: i | v | t | all (Spatial_transformer/run.py:168-197)")
+        self.backbone, self.S, self.d, self.loss_type = backbone, int(img_size), int(hidden_dim), loss_type
+        self.tasks = TASKS_ALL if loss_type == "all" else (loss_type,)
+        self.task, self.K = self.tasks[0], NCLS[self.tasks[0]]          # (single-task mode: the one decoder)
+        self.teacher_dim, self.rates, self.temp = int(teacher_dim), tuple(float(r) for r in rates), float(temp)   # `run.py:66,70` (--rates default 1 0 0.1)
         self.cfg = SWIN_CFG[backbone]
         assert self.d == self.cfg["embed_dim"] * 8, "hidden_dim is the backbone's final width (backbone.py:188-201)"
         self.lr, self.wd, self.dev, self.pg = lr, weight_decay, torch.device(device), process_group
@@ -153,10 +160,9 @@ class Q2LTrainer:
         self._c16: Dict[tuple, tuple] = {}
         self._dy16 = None
         self.exchange = True
-        self._table = q2l_param_shapes(backbone, self.S, self.d, loss_type)
+        self._table = q2l_param_shapes(backbone, self.S, self.d, loss_type, teacher_dim=self.teacher_dim)
         nblk = sum(self.cfg["depths"])
         self.drop_probs = [drop_path_rate * i / max(1, nblk - 1) for i in range(nblk)]     # `swin_transformer.py:517` (linspace 0 .. rate)
-        self.KP = _r4(self.K)
 
     # ------------------------------------------------------------------ parameters
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -189,10 +195,16 @@ class Q2LTrainer:
                 st["merge"] = dict(q=q, row_map=_merge_row_map(res).to(self.dev))
             self.stages.append(st)
         fp.vec(pre + "norm.weight", (d,)); fp.vec(pre + "norm.bias", (d,))
-        dq = f"decoder_{self.task}."
-        fp.lin("in_proj", dq + "input_proj.weight", dq + "input_proj.bias", d, d)
-        fp.vec(dq + "query_embed.weight", (self.K, d)); fp.vec(dq + "fc.W", (self.K, d)); fp.vec(dq + "fc.b", (self.K,))
-        t = dq + "transformer."
+        for task in self.tasks:
+            dq, K = f"decoder_{task}.", NCLS[task]
+            fp.lin("in_proj." + task, dq + "input_proj.weight", dq + "input_proj.bias", d, d)
+            fp.vec(dq + "query_embed.weight", (K, d)); fp.vec(dq + "fc.W", (K, d)); fp.vec(dq + "fc.b", (K,))
+        if self.loss_type == "all":              # KD adaptors (`network.py:75-80`): Conv1d(k = 1) on [B, C, 1] = linear layers
+            for n in ("wi", "wv", "wt"):
+                fp.lin(n, n + ".weight", n + ".bias", self.teacher_dim, d)
+            for n in ("mi", "mv", "mt"):
+                fp.lin(n, n + ".weight", n + ".bias", d, self.teacher_dim, need_dgrad=False)
+        t = self.tprefix = f"decoder_{self.tasks[0]}.transformer."     # the ONE Transformer (`named_parameters()` lists it under its first owner)
         layers = [("enc", t + "encoder.layers.0", "self_attn", ("norm1", "norm2"))] + \
                  [(f"dec{i}", f"{t}decoder.layers.{i}", "multihead_attn", ("norm2", "norm3")) for i in range(2)]
         for tag, lp, att, norms in layers:
@@ -211,13 +223,20 @@ class Q2LTrainer:
         self.layer_norms = {tag: norms for tag, _, _, norms in layers}
         hh = self.S // 32
         self.pos = sine_position_rows(d, hh, hh).to(self.dev, F32)
-        self.pos_w = torch.tensor(POS_W[self.task], dtype=F32, device=self.dev)
+        self.pos_w = {t: torch.tensor(POS_W[t], dtype=F32, device=self.dev) for t in self.tasks if t in POS_W}     # ivt: plain BCE (`run.py:342`)
         self._graphs: Dict[tuple, object] = {}
         return self
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
+        """the reference's parameter names and shapes; loss_type all: followed by the shared transformer's three alias entries per tensor
+        (decoder_v / _t / _ivt.transformer.*), as the reference module's own `state_dict()` lists them (`run.py:266-277` saves that)"""
         out = self.fp._export("p")
-        return {k: out[k] for k, _ in self._table}
+        sd = {k: out[k] for k, _ in self._table}
+        if self.loss_type == "all":
+            from .shapes import q2l_state_dict_aliases
+            for alias, src in q2l_state_dict_aliases(self.d):
+                sd[alias] = sd[src]
+        return sd
 
     def grads(self) -> Dict[str, torch.Tensor]:
         return self.fp._export("g")
@@ -225,10 +244,14 @@ class Q2LTrainer:
     # ------------------------------------------------------------------ randomness
     def mask_specs(self, b: int):
         """(key, shape) of every nn.Dropout(0.1) draw of the Q2L transformer in a step, row layout (rows image-major)"""
-        L, K, d = (self.S // 32) ** 2, self.K, self.d
-        specs = [("enc.attn", (b, NHEAD, L, L)), ("enc.d1", (b * L, d)), ("enc.ffn", (b * L, FFN)), ("enc.d2", (b * L, d))]
-        for i in range(2):
-            specs += [(f"dec{i}.attn", (b, NHEAD, K, L)), (f"dec{i}.d2", (b * K, d)), (f"dec{i}.ffn", (b * K, FFN)), (f"dec{i}.d3", (b * K, d))]
+        L, d = (self.S // 32) ** 2, self.d
+        specs = []
+        for task in self.tasks:               # loss_type all: every decoder pass draws its own masks, keys 'i/enc.attn' ... 'ivt/dec1.d3'
+            K, pk = NCLS[task], (task + "/" if self.loss_type == "all" else "")
+            specs += [(pk + "enc.attn", (b, NHEAD, L, L)), (pk + "enc.d1", (b * L, d)), (pk + "enc.ffn", (b * L, FFN)), (pk + "enc.d2", (b * L, d))]
+            for i in range(2):
+                specs += [(f"{pk}dec{i}.attn", (b, NHEAD, K, L)), (f"{pk}dec{i}.d2", (b * K, d)), (f"{pk}dec{i}.ffn", (b * K, FFN)),
+                          (f"{pk}dec{i}.d3", (b * K, d))]
         return specs
 
     def draw_masks(self, b: int, generator: Optional[torch.Generator] = None) -> dict:
@@ -419,18 +442,8 @@ class Q2LTrainer:
         return self._bwd(dfd, sv["x"], fp.L[tag + ".l1"], residual=residual)
 
     # ------------------------------------------------------------------ forward + backward (enqueue only)
-    def _fwd_bwd(self, img: torch.Tensor, z: torch.Tensor, masks: Optional[dict]):
-        """img uint8 NHWC or normalised float32 NCHW; z [B, K] multi-hot fp32.  Returns the per-column loss sums [K]."""
-        fp, B, d, K = self.fp, img.shape[0], self.d, self.K
-        masks = masks or {}
-        dps = masks.get("droppath")
-        tx = masks.get("tx") or {}
-        tm = lambda k: tx.get(k)
-        pre = "backbone.0."
-        self.G.zero_()
-        self._c16.clear()
-        self._dy16 = None
-        # ---- backbone forward
+    def _backbone_fwd(self, img, B, dps):
+        fp, pre = self.fp, "backbone.0."
         rows = ops.patchify(img, 4, F32, IMAGENET_MEAN, IMAGENET_STD)
         pe = self._fwd(rows, fp.L["pe"])
         x = self._ln(pe, pre + "patch_embed.norm")
@@ -449,11 +462,29 @@ class Q2LTrainer:
                 sts.update(xm=xm, xmn=xmn, m_in=x.shape[0])
                 x = self._fwd(xmn, fp.L[mg["q"] + "red"])
             saved.append(sts)
-        x_last = x
         feats = self._ln(x, pre + "norm")                                                    # [B*L, d] rows of the reference's [B,d,h,h]
-        # ---- decoder forward
+        return feats, dict(rows=rows, pe=pe, saved=saved, x_last=x)
+
+    def _backbone_bwd(self, dfeats, bb, B):
+        fp, pre = self.fp, "backbone.0."
+        g = self._ln_bwd(dfeats, bb["x_last"], pre + "norm")
+        for si in range(len(self.stages) - 1, -1, -1):
+            st, sts = self.stages[si], bb["saved"][si]
+            if "merge" in st:
+                mg, res = st["merge"], st["res"]
+                dxmn = self._bwd(g, sts["xmn"], fp.L[mg["q"] + "red"])
+                dxm = self._ln_bwd(dxmn, sts["xm"], mg["q"] + "norm")
+                g = ops.scatter_rows(dxm, mg["row_map"], l_out=(res // 2) ** 2, l_in=res * res, group=4, m_in=sts["m_in"])
+            for blk, (sv, dp) in zip(reversed(st["blocks"]), reversed(sts["blocks"])):
+                g = self._block_bwd(g, sv, st, blk, B, dp)
+        dpe = self._ln_bwd(g, bb["pe"], pre + "patch_embed.norm")
+        self._bwd(dpe, bb["rows"], fp.L["pe"], need_dx=False)
+
+    def _decoder_fwd(self, task, feats, B, tm):
+        """`Decoder.forward` (`network.py:163-171`) of one task over the shared transformer: logits [B, K]; everything the backward needs"""
+        fp, d, K = self.fp, self.d, NCLS[task]
         L = feats.shape[0] // B
-        s0 = self._fwd(feats, fp.L["in_proj"])
+        s0 = self._fwd(feats, fp.L["in_proj." + task])
         sp = ops.add_rowbcast(s0, self.pos)
         o, enc_att = self._mha_fwd("enc", sp, sp, s0, B, L, L, tm("enc.attn"))
         if tm("enc.d1") is not None:
@@ -465,7 +496,7 @@ class Q2LTrainer:
         u2 = ops.axpby_(s1, f2, 1.0, 1.0)
         memory = self._ln(u2, lp + ".norm2")
         mem_pos = ops.add_rowbcast(memory, self.pos)
-        query = fp.V[f"decoder_{self.task}.query_embed.weight"]
+        query = fp.V[f"decoder_{task}.query_embed.weight"]
         tgt = torch.zeros((B * K, d), dtype=F32, device=self.dev)
         dec_saved = []
         for i in range(2):
@@ -480,59 +511,102 @@ class Q2LTrainer:
             ub = ops.axpby_(t1, f2, 1.0, 1.0)
             tgt = self._ln(ub, lpd + ".norm3")
             dec_saved.append(dict(att=att, ua=ua, ffn=ffn, ub=ub))
-        tnorm = f"decoder_{self.task}.transformer.decoder.norm"
-        hs = self._ln(tgt, tnorm)
-        Wk, bk = fp.V[f"decoder_{self.task}.fc.W"], fp.V[f"decoder_{self.task}.fc.b"]
+        hs = self._ln(tgt, self.tprefix + "decoder.norm")
+        Wk, bk = fp.V[f"decoder_{task}.fc.W"], fp.V[f"decoder_{task}.fc.b"]
         logits = ops.groupwise_linear(hs, Wk.p, bk.p, B, K)                                   # [B, K]
-        # ---- loss + its gradient
-        dy = torch.zeros((B, K), dtype=F32, device=self.dev)
-        col_loss = torch.zeros(K, dtype=F32, device=self.dev)
-        ops.bce_logits_pw(logits, z, self.pos_w, self._col_scale(B), dy, col_loss)
-        # ---- decoder backward
-        dhs = ops.groupwise_linear_bwd(dy, hs, Wk.p, Wk.g, bk.g)
-        dtgt = self._ln_bwd(dhs, tgt, tnorm)
-        dmem = None                                                                           # gradient w.r.t. the encoder memory
+        return logits, dict(feats=feats, L=L, enc_att=enc_att, u1=u1, enc_ffn=enc_ffn, u2=u2, memory=memory, dec=dec_saved, tgt=tgt, hs=hs)
+
+    def _decoder_bwd(self, task, dy, sv, B, tm, dmem_extra=None):
+        """gradients of one decoder pass from dy = dL/dlogits [B, K] (+ dmem_extra = dL/dmemory rows from the KD branch): parameter gradients
+        are ADDED (the shared transformer collects all four passes); returns dL/dfeats"""
+        fp, K, L = self.fp, NCLS[task], sv["L"]
+        query = fp.V[f"decoder_{task}.query_embed.weight"]
+        Wk, bk = fp.V[f"decoder_{task}.fc.W"], fp.V[f"decoder_{task}.fc.b"]
+        dhs = ops.groupwise_linear_bwd(dy, sv["hs"], Wk.p, Wk.g, bk.g)
+        dtgt = self._ln_bwd(dhs, sv["tgt"], self.tprefix + "decoder.norm")
+        dmem = dmem_extra                                                                     # gradient w.r.t. the encoder memory
         for i in (1, 0):
-            tag, lpd, sv = f"dec{i}", self.layer_prefix[f"dec{i}"], dec_saved[i]
-            dub = self._ln_bwd(dtgt, sv["ub"], lpd + ".norm3")
-            dt1 = self._ffn_bwd(tag, dub, sv["ffn"], tm(tag + ".ffn"), tm(tag + ".d3"), residual=dub)
-            dua = self._ln_bwd(dt1, sv["ua"], lpd + ".norm2")
+            tag, lpd, ds = f"dec{i}", self.layer_prefix[f"dec{i}"], sv["dec"][i]
+            dub = self._ln_bwd(dtgt, ds["ub"], lpd + ".norm3")
+            dt1 = self._ffn_bwd(tag, dub, ds["ffn"], tm(tag + ".ffn"), tm(tag + ".d3"), residual=dub)
+            dua = self._ln_bwd(dt1, ds["ua"], lpd + ".norm2")
             do = ops.mul_add(dua, tm(tag + ".d2")) if tm(tag + ".d2") is not None else dua
-            dqin, dkin, dvin = self._mha_bwd(tag, do, sv["att"], B, K, L)
+            dqin, dkin, dvin = self._mha_bwd(tag, do, ds["att"], B, K, L)
             ops.sum_over_batch(dqin, query.g, B, accumulate=True)                             # query embedding: added to every image's queries
             dtgt = ops.axpby_(dua, dqin, 1.0, 1.0)                                            # previous tgt: residual path + through q
             dm = ops.axpby_(dkin, dvin, 1.0, 1.0)                                             # memory: through k (memory + pos) and v
             dmem = dm if dmem is None else ops.axpby_(dm, dmem, 1.0, 1.0)
-        # ---- encoder backward
         lp = self.layer_prefix["enc"]
-        du2 = self._ln_bwd(dmem, u2, lp + ".norm2")
-        ds1 = self._ffn_bwd("enc", du2, enc_ffn, tm("enc.ffn"), tm("enc.d2"), residual=du2)
-        du1 = self._ln_bwd(ds1, u1, lp + ".norm1")
+        du2 = self._ln_bwd(dmem, sv["u2"], lp + ".norm2")
+        ds1 = self._ffn_bwd("enc", du2, sv["enc_ffn"], tm("enc.ffn"), tm("enc.d2"), residual=du2)
+        du1 = self._ln_bwd(ds1, sv["u1"], lp + ".norm1")
         do = ops.mul_add(du1, tm("enc.d1")) if tm("enc.d1") is not None else du1
-        dq_in, dk_in, dv_in = self._mha_bwd("enc", do, enc_att, B, L, L)
+        dq_in, dk_in, dv_in = self._mha_bwd("enc", do, sv["enc_att"], B, L, L)
         ds0 = ops.axpby_(du1, dv_in, 1.0, 1.0)
         ops.axpby_(dq_in, ds0, 1.0, 1.0)
         ops.axpby_(dk_in, ds0, 1.0, 1.0)
-        dfeats = self._bwd(ds0, feats, fp.L["in_proj"])
-        # ---- backbone backward
-        g = self._ln_bwd(dfeats, x_last, pre + "norm")
-        for si in range(len(self.stages) - 1, -1, -1):
-            st, sts = self.stages[si], saved[si]
-            if "merge" in st:
-                mg, res = st["merge"], st["res"]
-                dxmn = self._bwd(g, sts["xmn"], fp.L[mg["q"] + "red"])
-                dxm = self._ln_bwd(dxmn, sts["xm"], mg["q"] + "norm")
-                g = ops.scatter_rows(dxm, mg["row_map"], l_out=(res // 2) ** 2, l_in=res * res, group=4, m_in=sts["m_in"])
-            for blk, (sv, dp) in zip(reversed(st["blocks"]), reversed(sts["blocks"])):
-                g = self._block_bwd(g, sv, st, blk, B, dp)
-        dpe = self._ln_bwd(g, pe, pre + "patch_embed.norm")
-        self._bwd(dpe, rows, fp.L["pe"], need_dx=False)
-        return col_loss
+        return self._bwd(ds0, sv["feats"], fp.L["in_proj." + task])
 
-    def _col_scale(self, B: int) -> torch.Tensor:
-        key = ("cs", B)
+    def _fwd_bwd(self, img: torch.Tensor, z: torch.Tensor, masks: Optional[dict], tp=None, tf=None):
+        """img uint8 NHWC or normalised float32 NCHW; z [B, sum K] multi-hot fp32 (the tasks' label blocks side by side); loss_type all: tp = 3 x
+        raw teacher logits, tf = 3 x teacher features [B, teacher_dim].  Returns (per-column BCE sums [sum K], soft sum [1], kd sum [1])."""
+        fp, B, d = self.fp, img.shape[0], self.d
+        masks = masks or {}
+        tx = masks.get("tx") or {}
+        allm = self.loss_type == "all"
+        self.G.zero_()
+        self._c16.clear()
+        self._dy16 = None
+        feats, bb = self._backbone_fwd(img, B, masks.get("droppath"))
+        # ---- decoders forward
+        tms = {t: (lambda k, pk=(t + "/" if allm else ""): tx.get(pk + k)) for t in self.tasks}
+        logits, svs = {}, {}
+        for t in self.tasks:
+            logits[t], svs[t] = self._decoder_fwd(t, feats, B, tms[t])
+        self.last_logits = logits
+        # ---- losses + their gradients (`run.py:164-197`)
+        r0, r1, r2 = self.rates if allm else (1.0, 0.0, 0.0)
+        col_loss = torch.zeros(z.shape[1], dtype=F32, device=self.dev)
+        soft = torch.zeros(1, dtype=F32, device=self.dev)
+        kdl = torch.zeros(1, dtype=F32, device=self.dev)
+        dys, o = {}, 0
+        for t in self.tasks:
+            K = NCLS[t]
+            dys[t] = torch.zeros((B, K), dtype=F32, device=self.dev)
+            ops.bce_logits_pw(logits[t], z[:, o:o + K].contiguous(), self.pos_w.get(t), self._col_scale(B, K, r0), dys[t], col_loss[o:o + K])
+            o += K
+        dmem_kd = None
+        if allm:
+            for t, tpn in zip(("i", "v", "t"), tp):
+                ops.distill_kl(logits[t], tpn, dys[t], soft, self.temp, r1 / 3.0, accumulate=True)
+            # KD mixing on decoder_ivt's pooled memory (`network.py:96-124`): feat [B, d]
+            mem, L = svs["ivt"]["memory"], svs["ivt"]["L"]
+            feat = ops.global_avgpool(mem.view(B, L, 1, d))
+            self.last_feat = feat
+            teas = [self._fwd(tn, fp.L[m]) for m, tn in zip(("mi", "mv", "mt"), tf)]
+            mixed = ops.kd_mix(feat, *teas)
+            cams = [self._fwd(mx, fp.L[w]) for w, mx in zip(("wi", "wv", "wt"), mixed)]
+            self.last_cams = cams
+            dcams = [ops.mse(c, tn, kdl, r2 / 3.0) for c, tn in zip(cams, tf)]
+            gs = [self._bwd(dc, mx, fp.L[w]) for w, dc, mx in zip(("wi", "wv", "wt"), dcams, mixed)]
+            ds_kd, dtau = ops.kd_mix_bwd(feat, teas, gs)
+            for n, (m, tn) in enumerate(zip(("mi", "mv", "mt"), tf)):
+                dte = dtau[:, n:n + 1].expand(B, d).contiguous()                              # d(tea_n)[b][:] = dtau[b][n]
+                self._bwd(dte, tn, fp.L[m], need_dx=False)
+            dmem_kd = ops.avgpool_bwd(ds_kd, B, L, d).view(B * L, d)
+        # ---- decoders backward -> dL/dfeats (summed over the passes), backbone backward
+        dfeats = None
+        for t in reversed(self.tasks):
+            df = self._decoder_bwd(t, dys[t], svs[t], B, tms[t], dmem_extra=dmem_kd if t == "ivt" else None)
+            dfeats = df if dfeats is None else ops.axpby_(df, dfeats, 1.0, 1.0)
+            svs[t] = None
+        self._backbone_bwd(dfeats, bb, B)
+        return col_loss, soft, kdl
+
+    def _col_scale(self, B: int, K: int, r0: float = 1.0) -> torch.Tensor:
+        key = ("cs", B, K, r0)
         if key not in self._graphs:
-            self._graphs[key] = torch.full((self.K,), 1.0 / (B * self.K), dtype=F32, device=self.dev)
+            self._graphs[key] = torch.full((K,), r0 / (B * K), dtype=F32, device=self.dev)
         return self._graphs[key]
 
     # ------------------------------------------------------------------ one step
@@ -547,16 +621,37 @@ class Q2LTrainer:
         return out
 
     @ops.with_latency_tiles
-    def train_step(self, img: torch.Tensor, labels: torch.Tensor, masks: Optional[dict] = None, apply_update: bool = True) -> float:
-        """img: uint8 NHWC [B,S,S,3] or normalised float32 NCHW [B,3,S,S] on the GPU; labels [B,K] multi-hot of the task.  Returns the loss."""
+    def train_step(self, img: torch.Tensor, labels, masks: Optional[dict] = None, apply_update: bool = True, teacher_pred=None, teacher_feat=None):
+        """img: uint8 NHWC [B,S,S,3] or normalised float32 NCHW [B,3,S,S] on the GPU.  Single task: labels [B,K] multi-hot of the task, returns
+        the loss.  loss_type all: labels (y_i, y_v, y_t, y_ivt), teacher_pred 3 x raw logits [B,K], teacher_feat 3 x [B,teacher_dim]
+        (`run.py:152-157`), returns the dict of loss terms (`run.py:199-214`)."""
         B = img.shape[0]
-        z = labels.to(self.dev, F32).contiguous()
-        assert img.is_cuda and tuple(z.shape) == (B, self.K)
-        col_loss = self._fwd_bwd(img, z, self._prep_masks(masks))
-        loss = float(col_loss.sum().item()) / (B * self.K)
+        if self.loss_type != "all":
+            z = labels.to(self.dev, F32).contiguous()
+            assert img.is_cuda and tuple(z.shape) == (B, self.K)
+            col_loss, _, _ = self._fwd_bwd(img, z, self._prep_masks(masks))
+            loss = float(col_loss.sum().item()) / (B * self.K)
+            if apply_update:
+                self.apply_update()
+            return loss
+        z = torch.cat([l.to(self.dev, F32) for l in labels], 1).contiguous()
+        tp = [t.to(self.dev, F32).contiguous() for t in teacher_pred]
+        tf = [t.to(self.dev, F32).contiguous() for t in teacher_feat]
+        assert img.is_cuda and tuple(z.shape) == (B, sum(NCLS[t] for t in self.tasks)) and all(t.shape == (B, self.teacher_dim) for t in tf)
+        col_loss, soft, kdl = self._fwd_bwd(img, z, self._prep_masks(masks), tp, tf)
+        cl, sk = col_loss.cpu(), torch.cat([soft, kdl]).cpu()
+        r0, r1, r2 = self.rates
+        terms, o, hard = {}, 0, 0.0
+        for t in self.tasks:                         # (the kernels scale the GRADIENT by the rates; the sums they return are unscaled)
+            K = NCLS[t]
+            terms["hard_" + t] = float(cl[o:o + K].sum() / (B * K))
+            hard += terms["hard_" + t]
+            o += K
+        terms.update(hard=hard, soft=float(sk[0]) / 3.0, kd=float(sk[1]) / 3.0)
+        terms["loss"] = r0 * terms["hard"] + r1 * terms["soft"] + r2 * terms["kd"]
         if apply_update:
             self.apply_update()
-        return loss
+        return terms
 
     def apply_update(self):
         scale = allreduce_sum_flat(self.G, self.pg) if self.exchange else 1.0

@@ -54,6 +54,7 @@ class VideoNas:
                                    num_i=num_i, num_v=num_v, num_t=num_t)
         self._sd: Dict[str, torch.Tensor] = {}
         self._p: Dict[str, torch.Tensor] = {}
+        self.tile = 0            # implicit-GEMM path: 0 = the library's choice per launch; a tile id forces it (tools/tcn_long_sweep.py)
 
     # ------------------------------------------------------------------ nn.Module-like surface
     def eval(self):
@@ -109,13 +110,13 @@ class VideoNas:
 
     # ------------------------------------------------------------------ forward
     def _c1(self, x, name, residual=None, relu=False):
-        return ops.conv_nhwc(x, self._p[name + ".w"], self._p[name + ".b"], kh=1, kw=1, residual=residual, relu=relu)
+        return ops.conv_nhwc(x, self._p[name + ".w"], self._p[name + ".b"], kh=1, kw=1, residual=residual, relu=relu, tile=self.tile)
 
     def _layer(self, x, prefix, d):
         p = self._p
         h = ops.conv_nhwc(x, p[prefix + ".conv_dilated.w"], p[prefix + ".conv_dilated.b"], kh=1, kw=3, pad=(0, d), dil=(1, d),
-                          relu=True)
-        return ops.conv_nhwc(h, p[prefix + ".conv_1x1.w"], p[prefix + ".conv_1x1.b"], kh=1, kw=1, residual=x)
+                          relu=True, tile=self.tile)
+        return ops.conv_nhwc(h, p[prefix + ".conv_1x1.w"], p[prefix + ".conv_1x1.b"], kh=1, kw=1, residual=x, tile=self.tile)
 
     def _stage(self, x, prefix, n):
         for i in range(n):

@@ -189,3 +189,93 @@ def test_q2l_bf16_operand_step_vs_reference_fixture(cuda):
         t2, _, _ = _trainer(dict(cfg, lr=2e-3), operand_dtype=dt)
         curves.append([t2.train_step(img.to(cuda), y, masks=masks) for _ in range(4)])
     assert all(abs(a - b) <= 1e-2 * abs(a) for a, b in zip(*curves)), curves
+
+
+# ------------------------------------------------------------------------------------------------ --loss_type all (run.py:183-197)
+def _inputs_all(cfg):
+    img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["img"], cfg["img"], seed=cfg["seed"]))
+    labels = [torch.from_numpy((synth.uniform01(cfg["seed"], 900 + i, cfg["B"] * k) < 0.2).reshape(cfg["B"], k).astype(np.int64))
+              for i, k in enumerate((6, 10, 15, 100))]
+    tpred = [synth.synthetic_features(cfg["B"], k, seed=cfg["seed"] + 10 + i)[0] * 2.0 for i, k in enumerate((6, 10, 15))]
+    tfeat = [synth.synthetic_features(cfg["B"], cfg["teacher_dim"], seed=cfg["seed"] + 20 + i)[0] for i in range(3)]
+    return img, labels, tpred, tfeat
+
+
+def _trainer_all(cfg, **kw):
+    from computervision_codes_amd.q2l_train import Q2LTrainer
+    table = shapes.q2l_param_shapes(cfg["backbone"], cfg["img"], cfg["hidden"], "all", teacher_dim=cfg["teacher_dim"])
+    sd = synth.fill_from_shapes(table, seed=cfg["seed"])
+    tr = Q2LTrainer(cfg["backbone"], cfg["img"], cfg["hidden"], "all", lr=cfg["lr"], weight_decay=1e-5, teacher_dim=cfg["teacher_dim"],
+                    rates=cfg["rates"], temp=cfg["temp"], **kw).load_state_dict(sd)
+    return tr, sd, table
+
+
+def test_q2l_train_all_step_vs_reference_autograd(cuda):
+    """`Spatial_transformer/run.py -t --loss_type all`: four decoders over the shared transformer + KD mixing, 4 x BCE + 3 x DistillKL + 3 x MSE
+    with --rates.  Against the fixture captured from the reference `Qeruy2Label` + torch autograd + torch.optim.SGD: the module outputs 1e-3,
+    every loss term 1e-4, every parameter's gradient norm 2e-4 (floor 1e-6 of the largest), sampled SGD deltas 2e-4."""
+    z, cfg = load_golden("q2l_train_swinT_all")
+    tr, sd, table = _trainer_all(cfg)
+    img, labels, tpred, tfeat = _inputs_all(cfg)
+    terms = tr.train_step(img.to(cuda), labels, apply_update=False, teacher_pred=tpred, teacher_feat=tfeat)
+    for k in ("loss", "hard", "soft", "kd"):
+        assert abs(terms[k] - float(z[k])) < 1e-4 * max(1.0, abs(float(z[k]))), (k, terms[k], float(z[k]))
+    for t in ("i", "v", "t", "ivt"):
+        assert (tr.last_logits[t].cpu() - torch.from_numpy(z["logit_" + t])).abs().max().item() < 1e-3, t
+    assert (tr.last_feat.cpu() - torch.from_numpy(z["feat"])).abs().max().item() < 1e-3
+    assert (tr.last_cams[0].cpu() - torch.from_numpy(z["kd_i"])).abs().max().item() < 1e-3
+    grads = tr.grads()
+    names = [k for k, _ in table]
+    floor = 1e-6 * float(z["grad_norms"].max())
+    for k, ref in zip(names, z["grad_norms"]):
+        gn = float(grads[k].norm())
+        assert abs(gn - ref) <= 2e-4 * max(ref, floor), (k, gn, ref)
+    rt = tr.state_dict()                                  # the table's entries first, then the shared transformer's aliases (reference state_dict())
+    ali = shapes.q2l_state_dict_aliases(cfg["hidden"])
+    assert list(rt) == names + [a for a, _ in ali] and all(torch.equal(rt[k], sd[k]) for k in names) and all(rt[a] is rt[s_] for a, s_ in ali)
+    tr.apply_update()
+    new = tr.state_dict()
+    for key in z.files:
+        if key.startswith("delta::"):
+            k = key[len("delta::"):]
+            flat = (new[k].float() - sd[k].float()).flatten()
+            got, ref = flat[:: max(1, flat.numel() // 2048)], torch.from_numpy(z[key])
+            ulp = 2.0 ** -22 * sd[k].float().abs().max().item()
+            # 2e-4 of the delta, widened by how far the REFERENCE's own fp32 gradient of this tensor is from the float64 gradient of the same
+            # step (`grad_cond`, captured with the fixture: bias gradients are sums over all B x L rows with cancellation; 3e-4 for
+            # decoder_ivt.input_proj.bias, 4e-5 median)
+            cond = float(z["grad_cond"][names.index(k)])
+            assert (got - ref).abs().max().item() <= (2e-4 + 2.0 * cond) * ref.abs().max().item() + ulp, (k, (got - ref).abs().max().item(), ref.abs().max().item(), cond)
+
+
+def test_q2l_train_all_with_random_draws_vs_oracle(cuda):
+    """the same step with DropPath and per-decoder dropout draws ('i/enc.attn' ... 'ivt/dec1.d3'): every gradient tensor and the updated
+    parameters against the CPU oracle on the same draws; then two steps lower the loss of the batch"""
+    from oracle import q2l_train as o_qt
+    cfg = dict(backbone="swin_T_224_1k", img=224, hidden=768, teacher_dim=512, B=2, seed=812, lr=0.05, rates=(1.0, 0.5, 0.3), temp=4.0)
+    tr, sd, table = _trainer_all(cfg, drop_path_rate=0.4)
+    img, labels, tpred, tfeat = _inputs_all(cfg)
+    masks = tr.draw_masks(cfg["B"], torch.Generator().manual_seed(6))
+    assert set(k.split("/")[0] for k in masks["tx"]) == {"i", "v", "t", "ivt"} and tuple(masks["tx"]["ivt/dec0.d2"].shape) == (2 * 100, 768)
+    new_o, terms_o, g_o = o_qt.train_step_all(sd, img, labels, tpred, tfeat, cfg["backbone"], cfg["img"], cfg["hidden"], cfg["lr"], 1e-5, cfg["rates"],
+                                              cfg["temp"], masks)
+    terms = tr.train_step(img.to(cuda), labels, masks=masks, apply_update=False, teacher_pred=tpred, teacher_feat=tfeat)
+    for k in ("loss", "hard", "soft", "kd", "hard_i", "hard_ivt"):
+        assert abs(terms[k] - terms_o[k]) < 1e-4 * max(1.0, abs(terms_o[k])), (k, terms[k], terms_o[k])
+    grads = tr.grads()
+    gmax = max(float(v.abs().max()) for v in g_o.values())
+    # elementwise, max-abs: 1e-3 of the tensor's largest entry (single-task test: 3e-4).  The shared transformer's tensors collect four decoder
+    # passes in the opposite order of autograd's accumulation, and one FFN ReLU gate within a rounding error of zero moves a whole row of
+    # linear1's gradient (measured worst: 5.2e-4 on decoder.layers.1.linear1.weight); a wrong or misplaced mask would show as O(0.1)
+    for k, _ in table:
+        ref = g_o[k]
+        err = (grads[k] - ref).abs().max().item()
+        assert err <= 1e-3 * max(ref.abs().max().item(), 1e-4 * gmax), (k, err, ref.abs().max().item())
+    tr.apply_update()
+    new = tr.state_dict()
+    for k, _ in table:
+        assert (new[k] - new_o[k]).abs().max().item() <= 2e-5 * max(1.0, new_o[k].abs().max().item()), k
+    tr2, _, _ = _trainer_all(dict(cfg, lr=1e-3))
+    l0 = tr2.train_step(img.to(cuda), labels, teacher_pred=tpred, teacher_feat=tfeat)["loss"]
+    l1 = tr2.train_step(img.to(cuda), labels, teacher_pred=tpred, teacher_feat=tfeat)["loss"]
+    assert l1 < l0

@@ -341,3 +341,36 @@ def test_q2l_teacher_train_driver_runs_and_feeds_test_py(cuda, tmp_path):
     assert log.count("Traning | lr:") == 2 and "mAP => t:" in log and f"backbone: {len(up) - 2} tensors from" in log
     feats = pickle.load(open(tree / "0-5fold" / "data_feats" / "run_T" / "k1_t_feats.pkl", "rb"))
     assert list(feats) == [v[3:] for v in vids] and feats["79"].shape == (2, 768) and np.isfinite(feats["79"]).all()
+
+
+def test_q2l_all_train_driver_reads_teacher_files_and_checkpoints(cuda, tmp_path):
+    """`Spatial_transformer/run.py -t --loss_type all` (`run.py:183-197`, the Res -> Swin direction): teacher predictions / features come from
+    the files `dataloader.py:216-238` reads, the checkpoint directory carries no task suffix (`run.py:86-88`), the saved state dict lists the
+    shared transformer under all four decoders like the reference's, validation feeds zero teacher features and scores the triplet head."""
+    from computervision_codes_amd import featfile
+    tree = tmp_path / "MT4MTLKD"
+    shutil.copytree(os.path.join(ROOT, "MT4MTLKD"), tree)
+    data = str(tmp_path / "CholecT45")
+    vids = _make_dataset(data, n_frames=2, h=40, w=56)
+    rng = np.random.default_rng(7)
+    TD = 64
+    for t, k in (("i", 6), ("v", 10), ("t", 15)):
+        featfile.write_feats(str(tree / "0-5fold" / "data_feats" / "run_TP" / f"k1_{t}_pred.pkl"), {v[-2:]: rng.standard_normal((2, k)).astype(np.float32) for v in vids})
+        featfile.write_feats(str(tree / "0-5fold" / "data_feats" / "run_TF" / f"k1_{t}_feats.pkl"), {v[-2:]: rng.standard_normal((2, TD)).astype(np.float32) for v in vids})
+    r = subprocess.run([sys.executable, "run.py", "-t", "--img_size", "224", "--backbone", "swin_T_224_1k", "--hidden_dim", "768", "--loss_type", "all",
+                        "--teacher_dim", str(TD), "--teacher_pred_version", "TP", "--teacher_feat_version", "TF", "--rates", "1", "1", "1", "--temp", "4",
+                        "--epochs", "2", "--batch", "16", "-l", "1e-2", "5e-3", "1e-5", "--version", "R2S", "--val_interval", "1", "--data_dir", data,
+                        "--kfold", "1"],
+                       cwd=tree / "Spatial_transformer", env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = tree / "Spatial_transformer" / "__checkpoint__" / "run_R2S"
+    table = shapes.q2l_param_shapes("swin_T_224_1k", 224, 768, "all", teacher_dim=TD)
+    ali = shapes.q2l_state_dict_aliases(768)
+    sd = torch.load(d / "rendezvous_lcholect45-crossval_cholect1_latest.pth", map_location="cpu")
+    assert list(sd.keys()) == [k for k, _ in table] + [a for a, _ in ali] and all(tuple(sd[k].shape) == tuple(s) for k, s in table)
+    assert all(torch.equal(sd[a], sd[s_]) for a, s_ in ali) and all(torch.isfinite(v).all() for v in sd.values())
+    sd0 = synth.fill_from_shapes(table, seed=47)
+    for k in ("decoder_i.transformer.encoder.layers.0.linear1.weight", "decoder_ivt.fc.W", "wi.weight", "mt.weight"):
+        assert not torch.equal(sd[k], sd0[k]), k
+    log = open(d / "rendezvous_lcholect45-crossval_cholect1.log").read()
+    assert log.count("Traning | lr:") == 2 and "mAP => ivt:" in log

@@ -206,3 +206,31 @@ def test_q2l_train_oracle_matches_reference_step():
             ref = torch.from_numpy(z[key])
             ulp = 2.0 ** -22 * sd[kname].abs().max().item()
             assert (flat[:: max(1, flat.numel() // 2048)] - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + ulp, kname
+
+
+def test_q2l_train_all_oracle_matches_reference_step():
+    """one `Spatial_transformer/run.py -t --loss_type all` step (`:183-197`: four decoders over the shared transformer, KD mixing, 4 x BCE +
+    3 x DistillKL + 3 x MSE with --rates) vs the fixture captured from the reference Qeruy2Label + torch autograd + SGD"""
+    from oracle import q2l_train as o_qt
+    z, cfg = load_golden("q2l_train_swinT_all")
+    table = shapes.q2l_param_shapes(cfg["backbone"], cfg["img"], cfg["hidden"], "all", teacher_dim=cfg["teacher_dim"])
+    sd = synth.fill_from_shapes(table, seed=cfg["seed"])
+    img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["img"], cfg["img"], seed=cfg["seed"]))
+    labels = [torch.from_numpy((synth.uniform01(cfg["seed"], 900 + i, cfg["B"] * k) < 0.2).reshape(cfg["B"], k).astype(np.int64))
+              for i, k in enumerate((6, 10, 15, 100))]
+    tpred = [synth.synthetic_features(cfg["B"], k, seed=cfg["seed"] + 10 + i)[0] * 2.0 for i, k in enumerate((6, 10, 15))]
+    tfeat = [synth.synthetic_features(cfg["B"], cfg["teacher_dim"], seed=cfg["seed"] + 20 + i)[0] for i in range(3)]
+    with torch.enable_grad():
+        new, terms, g = o_qt.train_step_all(sd, img, labels, tpred, tfeat, cfg["backbone"], cfg["img"], cfg["hidden"], cfg["lr"], 1e-5, cfg["rates"],
+                                            cfg["temp"])
+    for k in ("loss", "hard", "soft", "kd"):
+        assert abs(terms[k] - float(z[k])) < 2e-5 * max(1.0, abs(float(z[k]))), k
+    for kname, ref in zip([k_ for k_, _ in table], z["grad_norms"]):
+        assert abs(float(g[kname].norm()) - ref) <= 1e-4 * max(ref, 1e-6 * float(z["grad_norms"].max())), kname
+    for key in z.files:
+        if key.startswith("delta::"):
+            kname = key[len("delta::"):]
+            flat = (new[kname] - sd[kname]).flatten()
+            ref = torch.from_numpy(z[key])
+            ulp = 2.0 ** -22 * sd[kname].abs().max().item()
+            assert (flat[:: max(1, flat.numel() // 2048)] - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + ulp, kname

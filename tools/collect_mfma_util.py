@@ -8,6 +8,11 @@ per dispatch summed over the 8 XCDs (value / launch duration = 18.3-19.4 cycles 
 duration in shader-clock cycles is value / 8.  utilisation = busy / (1024 SIMDs x cycles)."""
 import collections, csv, glob, json, os, sys
 
+import importlib.util as _ilu
+_spec = _ilu.spec_from_file_location("srcdigest", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "computervision_codes_amd", "srcdigest.py"))
+_sd = _ilu.module_from_spec(_spec); _spec.loader.exec_module(_sd)
+KSHA = _sd.kernels_digest(_sd.CONV_SOURCES)          # the sources the profiled library was built from (bench.py nulls the figure when they change)
+
 CONV_KERNELS = ("igemm_conv_kernel", "conv3x3_patch_kernel", "stem_patch_kernel", "stem_pool_kernel", "bottleneck64_fused_kernel")   # every conv launch of a step
 
 N_SIMD = 256 * 4
@@ -41,7 +46,7 @@ for i, r in enumerate(last):
     rows.append(dict(launch=i, kernel=r["_name"].split("(")[0][-60:], mfma_busy_cycles=busy, gpu_cycles=cyc, grbm_rows=len(gui),
                      sq_busy_cycles=sum(r.get("SQ_BUSY_CYCLES", [0.0])), mfma_util=round(busy / (N_SIMD * cyc), 4)))
 data = json.load(open(out_path)) if os.path.exists(out_path) else {}
-data[key] = dict(mfma_util=round(busy_t / (N_SIMD * cyc_t), 4), mfma_busy_cycles=busy_t, gpu_cycles=cyc_t, launches=per_step,
+data[key] = dict(mfma_util=round(busy_t / (N_SIMD * cyc_t), 4), mfma_busy_cycles=busy_t, gpu_cycles=cyc_t, launches=per_step, kernels_sha=KSHA,
                  steps_profiled=n // per_step, per_launch=rows,
                  note="conv launches of one step; utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)")
 json.dump(data, open(out_path, "w"), indent=1)

@@ -4,6 +4,11 @@ usage: python tools/collect_tcn_traffic.py <fetch_dir> <write_dir> <key> [out=pr
 Per MI355X_MICROARCH.md (HBM): KiB units; FETCH_SIZE counts half the bytes of a wide coalesced stream on gfx950 (doubled here)."""
 import csv, glob, json, os, sys
 
+import importlib.util as _ilu
+_spec = _ilu.spec_from_file_location("srcdigest", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "computervision_codes_amd", "srcdigest.py"))
+_sd = _ilu.module_from_spec(_spec); _spec.loader.exec_module(_sd)
+KSHA = _sd.kernels_digest(_sd.TCN_SOURCES)          # the sources the profiled library was built from (bench.py nulls the figure when they change)
+
 KERNELS = ("tcn_conv_kernel", "fpn_topdown_kernel", "igemm_conv_kernel")
 
 
@@ -30,7 +35,7 @@ out_path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os
 fe, n1 = last_forward(fetch_dir, "FETCH_SIZE")
 wr, n2 = last_forward(write_dir, "WRITE_SIZE")
 data = json.load(open(out_path)) if os.path.exists(out_path) else {}
-data[key] = {"hbm_bytes_per_video": 2.0 * fe * 1024 + wr * 1024, "read_bytes": 2.0 * fe * 1024, "write_bytes": wr * 1024, "launches": n1,
+data[key] = {"hbm_bytes_per_video": 2.0 * fe * 1024 + wr * 1024, "read_bytes": 2.0 * fe * 1024, "write_bytes": wr * 1024, "launches": n1, "kernels_sha": KSHA,
              "note": "all launches of one forward (graph replay); read = 2 x FETCH_SIZE (gfx950 half-count), KiB units"}
 json.dump(data, open(out_path, "w"), indent=1)
 print(key, data[key])
