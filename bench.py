@@ -199,6 +199,19 @@ def temporal_bench(dev, do_cpu):
                     n += 1
                 rec["cpu_ms_per_video"] = round((time.perf_counter() - t0) / n * 1e3, 2)
         out[name] = rec
+    # throughput of the same head: B videos of 256 frames per forward (frames of different videos never meet: a video's rows are bit-identical
+    # whatever rides along), hipGraph replay
+    thr = {}
+    args = types.SimpleNamespace(fpn=True, output=False, hier=False, mask=True)
+    sd = synth.fill_from_shapes(shapes.tenco_shapes(11, 10, 3, 512, 512, 100, fpn=True), seed=47)
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        m = VideoNas(args, 11, 10, 3, 512, 512, 100, dtype=dt).eval().load_state_dict(sd)
+        for B in (8, 32):
+            xb = torch.stack([synth.synthetic_features(256, 512, seed=47 + i)[0] for i in range(8)]).repeat(B // 8, 1, 1).to(dev).contiguous()
+            g = GraphedForward(lambda xx: m(xx, False), [xb])
+            ms = _time_call(lambda: g(xb), iters=10)
+            thr[f"B{B}_T256_{tag}"] = dict(videos_per_s=round(B / ms * 1e3, 1), ms_per_forward=round(ms, 4))
+    out["tenco4_throughput"] = thr
     # MS-TCT teacher, one 256-frame window, D=2048 (Temporal_mstct/run.py:306-313)
     a = types.SimpleNamespace(loss_type="ivt")
     sd = synth.fill_from_shapes(shapes.mstct_shapes(2048, (256, 384, 576, 864), 2, 8, 512, "ivt"), seed=47)

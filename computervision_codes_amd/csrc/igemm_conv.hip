@@ -1806,6 +1806,17 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
             const int kt = tile == 11 ? (ksm == 2 ? 35 : ksm == 3 ? 38 : 37) : 36;
             if ((long long)cdiv(k.M, kTiles[kt - 1].bm) * cdiv(k.Cout, kTiles[kt - 1].bn) <= 256) tile = kt;
         }
+        // a whole video (T ~ 2000 frames x 512 channels: `Temporal_tenco/run.py:369-379` runs batch 1 on full videos): 64 x 64 tiles are one
+        // round of the 256 CUs and pull the fewest operand bytes per CU ((BM + BN) x K, minimal for square tiles); what they lack is waves to
+        // hide the per-K-step DMA round trip -- K-split groups supply them.  Same-box sweep, 4-stage head, T = 2000, hipGraph replay
+        // (tools/tcn_long_sweep.py): fp32 2.35 ms (32 x 32, 4-stage ring) -> 2.13 (two groups) -> 2.04 (four groups, tile 40);
+        // bf16 1.00 -> 0.83 (tile 40) -> 0.74 (two groups with 3-stage rings, tile 41).  At T = 1000 (128 such tiles: half the chip) the
+        // small tiles stay, bf16 on the 4-stage 32 x 64 ring (0.74 -> 0.69 ms)
+        if (latency && fast && k.nsteps >= 8 && MT4_ENV_INT("MT4_KSPLIT", 1) && (tile == 5 || tile == 6 || tile == 10 || tile == 11 || tile == 3 || tile == 9)) {
+            const long long t64 = (long long)cdiv(k.M, 64) * cdiv(k.Cout, 64);
+            if (t64 >= 192 && t64 <= 512) tile = d->dtype == MT4_F32 ? 40 : 41;
+            else if (d->dtype == MT4_BF16 && tile == 11 && (long long)cdiv(k.M, 32) * cdiv(k.Cout, 64) >= 256) tile = 10;
+        }
     }
     if (d->dtype == MT4_F32) return launch_dtype<float, true>(k, tile, fast, s);
     if (d->out_dtype == MT4_F32) return launch_dtype<u16, true>(k, tile, fast, s);

@@ -14,12 +14,14 @@ ap.add_argument("--T", type=int, default=256)
 ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
 ap.add_argument("--config", default="tenco4", choices=["tenco4", "config1"])
 ap.add_argument("--replays", type=int, default=50)
+ap.add_argument("--tile", type=int, default=0, help="implicit-GEMM path: force this tile id (0 = the library's choice)")
 a = ap.parse_args()
 num_R, dim = (3, 512) if a.config == "tenco4" else (0, 2048)
 fpn = num_R > 0
 args = types.SimpleNamespace(fpn=fpn, output=False, hier=False, mask=True)
 sd = synth.fill_from_shapes(shapes.tenco_shapes(11, 10, num_R, 512, dim, 100, fpn=fpn), seed=47)
 m = VideoNas(args, 11, 10, num_R, 512, dim, 100, dtype=torch.float32 if a.dtype == "f32" else torch.bfloat16).eval().load_state_dict(sd)
+m.tile = a.tile
 x = synth.synthetic_features(a.T, dim, seed=47).cuda()
 g = GraphedForward(lambda xx: m(xx, False), [x])
 torch.cuda.synchronize()
