@@ -63,7 +63,7 @@ def time_conv_kernels(model, frames, iters=3):
     recorded on the stream the kernels are launched on (torch's current stream), one event pair per launch."""
     from computervision_codes_amd import ops
     pairs = []
-    names = ("conv_nhwc", "conv3x3_expand", "bottleneck_fused", "bottleneck_fused_next", "stem_maxpool")
+    names = ("conv_nhwc", "conv3x3_expand", "bottleneck_fused", "bottleneck_fused_next", "stem_maxpool", "chain_gemm")
     origs = {n: getattr(ops, n) for n in names}
 
     def wrap(fn):
@@ -746,7 +746,7 @@ def main():
         keys = [(cfg.format(a.batch), max(1, a.streams))] + ([(cfg.format(1336), nstep / 1336.0)] if a.batch % 1336 == 0 else [])
         traffic, traffic_source = committed("traffic.json", "hbm_bytes_per_step", CONV_SOURCES, keys)
         mfma_util, mfma_util_source = committed("mfma_util.json", "mfma_util", CONV_SOURCES, [(k, 1.0) for k, _ in keys])
-        roofline = dict(bound="mfma", kernel="conv launches of one step (igemm_conv_kernel, conv3x3_patch_kernel, stem_pool_kernel, bottleneck64_fused_kernel)", achieved=round(achieved, 2),
+        roofline = dict(bound="mfma", kernel="conv launches of one step (igemm_conv_kernel, conv3x3_patch_kernel, stem_pool_kernel, bottleneck64_fused_kernel, chain_gemm_kernel)", achieved=round(achieved, 2),
                         peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,
                         mfma_util_pmc=mfma_util, mfma_util_source=mfma_util_source,
                         launches_per_step=len(per_launch), conv_ms_per_step=round(conv_ms, 4), ms_per_step=round(ms_per_step, 4),
@@ -762,8 +762,10 @@ def main():
             for g, ms in zip(groups, per_launch):
                 fl = sum(2 * a.batch * plan[i]["Ho"] * plan[i]["Wo"] * plan[i]["Cout"] * plan[i]["Cin"] * plan[i]["kh"] * plan[i]["kw"] for i in g)
                 blk = lambda nm: nm.rsplit(".", 1)[0]
-                if len(g) == 2:
+                if len(g) == 2 and blk(plan[g[0]]["name"]) == blk(plan[g[1]]["name"]):
                     gname = plan[g[0]]["name"] + " + " + ("downsample" if plan[g[1]]["name"].endswith(".ds") else plan[g[1]]["name"].rsplit(".", 1)[1])
+                elif len(g) == 2:
+                    gname = plan[g[0]]["name"] + " + " + plan[g[1]]["name"]
                 else:
                     gname = blk(plan[g[0]]["name"]) + (" + " + plan[g[-1]]["name"] if blk(plan[g[-1]]["name"]) != blk(plan[g[0]]["name"]) else "")
                 rec = dict(plan[g[0]]) if len(g) == 1 else dict(name=gname + " (one launch)", fused=[plan[i]["name"] for i in g])

@@ -121,6 +121,7 @@ SIGNATURES = {
     "mt4_bottleneck_pack_bf16": (C.c_int, [_vp] * 4 + [_i32, _vp, _vp]),
     "mt4_bottleneck_fused_bf16": (C.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
     "mt4_pack_fragments_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "mt4_chain_gemm_bf16": (C.c_int, [_vp, C.c_int64, C.c_int64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "mt4_bottleneck_next_packed_bytes": (C.c_int64, []),
     "mt4_bottleneck_pack_next_bf16": (C.c_int, [_vp, _vp, _vp]),
     "mt4_bottleneck_fused_next_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
@@ -161,7 +162,7 @@ def _load() -> C.CDLL:
     return lib
 
 
-ABI_VERSION = 7         # what mt4_abi_version() of a matching libmt4hip.so returns (csrc/misc_kernels.hip)
+ABI_VERSION = 8         # what mt4_abi_version() of a matching libmt4hip.so returns (csrc/misc_kernels.hip)
 lib = _load()
 if lib.mt4_abi_version() != ABI_VERSION:      # a stale libmt4hip.so next to newer Python: fail at import, not in the first launch
     raise ImportError(f"libmt4hip.so reports ABI {lib.mt4_abi_version()}, this package binds ABI {ABI_VERSION}: rebuild (make -C computervision_codes_amd/csrc)")

@@ -184,6 +184,38 @@ def pack_fragments(w_packed: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def chain_gemm_supported(k1: int, n1: int, n2: int, conv: bool) -> bool:
+    """shapes `chain_gemm` runs (`mt4_chain_gemm_bf16`)"""
+    return k1 in (128, 256) and n1 >= 256 and n1 % 128 == 0 and n2 in (128, 256) and (conv or n2 == k1)
+
+
+def chain_gemm(x2d: torch.Tensor, w1_frag: torch.Tensor, b1: torch.Tensor, w2_frag: torch.Tensor, b2: torch.Tensor, *, r1: Optional[torch.Tensor] = None,
+               r2: Optional[torch.Tensor] = None, y1: Optional[torch.Tensor] = None, y2: Optional[torch.Tensor] = None):
+    """Two dependent 1x1 convolutions / linear layers in one launch (`mt4_chain_gemm_bf16`), bit-identical to the two `conv_nhwc` launches.
+    r1 given (Bottleneck form): H = relu(x W1^T + b1 + r1) is stored (returned first: the block output), y2 = relu(H W2^T + b2).
+    r2 given (MLP form): y2 = gelu(x W1^T + b1) W2^T + b2 + r2, H never exists.  x2d [M, K1] bf16 (row pitch = its stride);
+    w1_frag / w2_frag = `pack_fragments` of the packed [N1, K1] / [N2, N1] matrices.  Returns (y1 or None, y2)."""
+    _need_cuda(x2d, w1_frag, b1, w2_frag, b2, r1, r2, y1, y2)
+    assert x2d.dim() == 2 and x2d.dtype == torch.bfloat16 and x2d.stride(1) == 1 and (r1 is None) != (r2 is None)
+    m, k1 = x2d.shape
+    n1, n2 = w1_frag.shape[0], w2_frag.shape[0]
+    assert tuple(w1_frag.shape) == (n1, k1) and tuple(w2_frag.shape) == (n2, n1) and w1_frag.dtype == w2_frag.dtype == torch.bfloat16
+    assert b1.dtype == b2.dtype == torch.float32 and b1.numel() == n1 and b2.numel() == n2
+    conv = r1 is not None
+    if conv:
+        assert r1.dtype == torch.bfloat16 and r1.is_contiguous() and r1.numel() == m * n1
+        y1 = torch.empty((m, n1), dtype=torch.bfloat16, device=x2d.device) if y1 is None else y1
+        assert y1.dtype == torch.bfloat16 and y1.is_contiguous() and y1.numel() == m * n1
+    else:
+        assert r2.dtype == torch.bfloat16 and r2.is_contiguous() and r2.numel() == m * n2 and y1 is None
+    y2 = torch.empty((m, n2), dtype=torch.bfloat16, device=x2d.device) if y2 is None else y2
+    assert y2.dtype == torch.bfloat16 and y2.is_contiguous() and y2.numel() == m * n2
+    check(lib.mt4_chain_gemm_bf16(x2d.data_ptr(), x2d.stride(0), m, k1, w1_frag.data_ptr(), b1.data_ptr(), n1, r1.data_ptr() if conv else None,
+                                  y1.data_ptr() if conv else None, 1 if conv else 2, w2_frag.data_ptr(), b2.data_ptr(), n2,
+                                  None if conv else r2.data_ptr(), 1 if conv else 0, y2.data_ptr(), _stream()), "mt4_chain_gemm_bf16")
+    return y1, y2
+
+
 def conv3x3_expand(x: torch.Tensor, w2_packed: torch.Tensor, b2: torch.Tensor, w3_frag: torch.Tensor, b3: torch.Tensor, residual: torch.Tensor,
                    out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """conv2 (3x3, 128 -> 128, + bn2 + ReLU) and conv3 (1x1, + bn3 + residual + ReLU) of a stride-1 Bottleneck in one launch

@@ -51,6 +51,9 @@ class VideoNas:
         self.fuse_next_block = not os.environ.get("MT4_NO_NEXT_FUSE")   # layer2.0's conv1 behind the last layer1 block, in its launch
         self.fuse_downsample = not os.environ.get("MT4_NO_DS_FUSE")   # strided Bottlenecks: conv3 + downsample branch as one GEMM (bf16)
         self.fuse_bottleneck = not os.environ.get("MT4_NO_BNECK_FUSE")   # layer1 Bottlenecks in one launch each (bf16 ResNet-50)
+        # conv3 (+ bn3 + add + ReLU) of an identity Bottleneck and conv1 (+ bn1 + ReLU) of the block behind it in ONE launch (`ops.chain_gemm`,
+        # K-chunk accumulation: the 4 x planes map is written once and not read back; bit-identical): the layers it is used in (bf16 ResNet-50)
+        self.chain_layers = tuple(int(c) for c in os.environ.get("MT4_CHAIN", "3") if c in "23")
 
     def train(self, mode: bool = True):
         self.training = bool(mode)
@@ -129,8 +132,10 @@ class VideoNas:
                     p[q + "conv3ds"] = (torch.cat([w3, wd], 1).contiguous(), (b3 + bd).contiguous())
                     if li == 2:      # its conv1 rides behind the last layer1 block (ops.bottleneck_fused_next)
                         p[q + "conv1next"] = ops.bottleneck_pack_next(p[q + "conv1"])
-                if bottleneck and li == 2 and (q + "ds") not in p and self.dtype == torch.bfloat16:   # conv3 behind conv2 in one launch (ops.conv3x3_expand)
+                if bottleneck and li in (2, 3) and (q + "ds") not in p and self.dtype == torch.bfloat16:   # conv3 behind conv2 in one launch (ops.conv3x3_expand) / in front of the next conv1 (ops.chain_gemm)
                     p[q + "conv3frag"] = ops.pack_fragments(p[q + "conv3"][0])
+                if bottleneck and li in (2, 3, 4) and self.dtype == torch.bfloat16:
+                    p[q + "conv1frag"] = ops.pack_fragments(p[q + "conv1"][0])
         ws, bs, self._head_slices, o = [], [], {}, 0
         for task, k in _HEADS:
             if self.loss_type in (task, "all"):
@@ -195,7 +200,19 @@ class VideoNas:
                 if bottleneck:  # resnet.py:101-121 (stride on the 3x3)
                     o = pending if pending is not None else self._conv(x, q + "conv1", 1)
                     pending = None
-                    if (q + "conv3frag") in self._p and self.fuse_expand and not self.fuse_next_conv:
+                    nq = f"{pre}layer{li}.{bi + 1}." if bi + 1 < n else (f"{pre}layer{li + 1}.0." if li < last else None)
+                    if (li in self.chain_layers and nq is not None and o_buf is None and self.dtype == torch.bfloat16 and (q + "conv3frag") in self._p
+                            and (nq + "conv1frag") in self._p and not self.fuse_next_conv
+                            and ops.chain_gemm_supported(self._p[q + "conv3frag"].shape[1], self._p[q + "conv3frag"].shape[0], self._p[nq + "conv1frag"].shape[0], True)):
+                        # conv2, then conv3 + add + ReLU and the NEXT block's conv1 + ReLU in one launch: this block's output map is written once
+                        # (the next block's residual) and never read back
+                        o = self._conv(o, q + "conv2", 3, stride=s, pad=1)
+                        bb, hh, ww, cc = o.shape
+                        y1, t1 = ops.chain_gemm(o.view(-1, cc), self._p[q + "conv3frag"], self._p[q + "conv3"][1], self._p[nq + "conv1frag"],
+                                                self._p[nq + "conv1"][1], r1=idt)
+                        x, pending = y1.view(bb, hh, ww, -1), t1.view(bb, hh, ww, -1)
+                        continue
+                    if (q + "conv3frag") in self._p and li == 2 and self.fuse_expand and not self.fuse_next_conv:
                         # conv2 and conv3 (+ residual) of a layer2 identity block in one launch: the 128-channel map stays in LDS (bit-identical;
                         # None where the patch kernel does not run -- small batches)
                         (w2, b2), b3 = self._p[q + "conv2"], self._p[q + "conv3"][1]
@@ -255,39 +272,53 @@ class VideoNas:
         return plan
 
     def launch_groups(self, h: int, w: int):
-        """indices into `conv_plan(h, w)` per kernel launch of one forward at bench batch sizes, in launch order: one conv per launch, except (bf16
-        ResNet-50) the layer1 Bottlenecks (one `mt4_bottleneck_fused_bf16` launch each, the last one carrying layer2.0's conv1), conv3 + downsample
-        of the strided blocks (one GEMM) and conv2 + conv3 of layer2's identity blocks (`mt4_conv_desc.fuse_expand`)"""
+        """indices into `conv_plan(h, w)` per kernel launch of one forward at bench batch sizes, in launch order (the walk of `_layers`): one conv
+        per launch, except (bf16 ResNet-50) the layer1 Bottlenecks (one `mt4_bottleneck_fused_bf16` launch each, the last one carrying layer2.0's
+        conv1), conv3 + downsample of the strided blocks (one GEMM), conv2 + conv3 of layer2's identity blocks (`mt4_conv_desc.fuse_expand`) and
+        conv3 + the next block's conv1 in the layers of `chain_layers` (`mt4_chain_gemm_bf16`)"""
         plan = self.conv_plan(h, w)
-        fused = self.network == "resnet50" and self.fuse_bottleneck and self.dtype == torch.bfloat16
-        ds_fused = self.network == "resnet50" and self.fuse_downsample and self.dtype == torch.bfloat16
-        next_fused = fused and ds_fused and self.fuse_next_block
-        groups, i = [], 0
-        while i < len(plan):
-            name = plan[i]["name"]
-            if ds_fused and name.endswith(".ds") and not name.startswith("layer1."):   # plan order ds, conv1, conv2, conv3 -> launches conv1, conv2, conv3 + ds
-                if next_fused and name.startswith("layer2."):
-                    groups[-1].append(i + 1)          # layer2.0.conv1 ran in the launch of the last layer1 block
+        idx = {rec["name"]: i for i, rec in enumerate(plan)}
+        r50 = self.network == "resnet50" and self.dtype == torch.bfloat16
+        if not r50:
+            return [[i] for i in range(len(plan))]
+        fused1 = self.fuse_bottleneck
+        ds_fused = self.fuse_downsample
+        groups = [[idx["stem"]]]
+        pending = False                      # the conv1 of the block about to run was part of the previous launch
+        depths = _DEPTHS[self.network]
+        planes = (64, 128, 256, 512)
+        for li, n in enumerate(depths, start=1):
+            for bi in range(n):
+                q = f"layer{li}.{bi}."
+                has_ds = (q + "ds") in idx
+                nq = f"layer{li}.{bi + 1}." if bi + 1 < n else (f"layer{li + 1}.0." if li < 4 else None)
+                if li == 1 and fused1:
+                    g = ([idx[q + "ds"]] if has_ds else []) + [idx[q + "conv1"], idx[q + "conv2"], idx[q + "conv3"]]
+                    if bi == n - 1 and ds_fused and self.fuse_next_block:
+                        g.append(idx["layer2.0.conv1"])
+                        pending = True
+                    groups.append(g)
+                    continue
+                if has_ds and ds_fused:
+                    if not pending:
+                        groups.append([idx[q + "conv1"]])
+                    pending = False
+                    groups += [[idx[q + "conv2"]], [idx[q + "conv3"], idx[q + "ds"]]]
+                    continue
+                if has_ds:
+                    groups.append([idx[q + "ds"]])
+                if not pending:
+                    groups.append([idx[q + "conv1"]])
+                pending = False
+                nplanes = planes[li - 1] if bi + 1 < n else (planes[li] if li < 4 else 0)
+                if (li in self.chain_layers and nq is not None and not has_ds and li in (2, 3)
+                        and ops.chain_gemm_supported(planes[li - 1], 4 * planes[li - 1], nplanes, True)):
+                    groups += [[idx[q + "conv2"]], [idx[q + "conv3"], idx[nq + "conv1"]]]
+                    pending = True
+                elif li == 2 and not has_ds and self.fuse_expand and not self.fuse_next_conv:
+                    groups.append([idx[q + "conv2"], idx[q + "conv3"]])
                 else:
-                    groups.append([i + 1])
-                groups += [[i + 2], [i + 3, i]]
-                i += 4
-                continue
-            if (ds_fused and self.fuse_expand and not self.fuse_next_conv and name.startswith("layer2.") and name.endswith(".conv2")
-                    and not name.startswith("layer2.0.")):      # conv2 + conv3 of layer2's identity blocks (ops.conv3x3_expand; large batches)
-                groups.append([i, i + 1])
-                i += 2
-                continue
-            if fused and name.startswith("layer1."):
-                blk = name.split(".")[1]
-                j = i
-                while j < len(plan) and plan[j]["name"].startswith(f"layer1.{blk}."):
-                    j += 1
-                groups.append(list(range(i, j)))
-                i = j
-            else:
-                groups.append([i])
-                i += 1
+                    groups += [[idx[q + "conv2"]], [idx[q + "conv3"]]]
         return groups
 
     def _finish(self, feat: torch.Tensor):

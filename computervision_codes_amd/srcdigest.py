@@ -4,7 +4,7 @@ of the library it runs, and says which collection it is.  No torch import: the c
 import hashlib
 import os
 
-CONV_SOURCES = ("igemm_conv.hip", "bottleneck_fused.hip", "mt4_common.h")            # every conv launch of the spatial extractor
+CONV_SOURCES = ("igemm_conv.hip", "bottleneck_fused.hip", "chain_gemm.hip", "mt4_common.h")            # every conv launch of the spatial extractor
 TCN_SOURCES = ("tcn_kernels.hip", "igemm_conv.hip", "mt4_common.h")                  # the launches of a Temporal_tenco forward (fpn_topdown lives in tcn_kernels.hip)
 
 

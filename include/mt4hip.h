@@ -30,8 +30,9 @@ extern "C" {
 #define MT4_F32 0
 #define MT4_BF16 1
 
-/* 6 in this revision (5 -> 6: mt4_stem_maxpool_bf16, mt4_bottleneck_fused_next_bf16, mt4_pack_fragments_bf16, the x2 / fuse_expand fields at the
- * end of mt4_conv_desc).  A binding checks it once at load (computervision_codes_amd/_lib.py: ABI_VERSION). */
+/* 8 in this revision (5 -> 6: mt4_stem_maxpool_bf16, mt4_bottleneck_fused_next_bf16, mt4_pack_fragments_bf16, the x2 / fuse_expand fields at the
+ * end of mt4_conv_desc; 6 -> 7: mt4_copy_spans_u8; 7 -> 8: mt4_chain_gemm_bf16).  A binding checks it once at load
+ * (computervision_codes_amd/_lib.py: ABI_VERSION). */
 int mt4_abi_version(void);
 const char* mt4_strerror(int code);
 /* last hipError_t (as int) seen by this thread inside the library, 0 if none */
@@ -149,6 +150,18 @@ int mt4_bottleneck_fused_next_bf16(const void* x, void* y_even, void* t_next, co
 /* a packed bf16 matrix [rows][row_elems] in MFMA fragment order: [rows / 16][row_elems / 32][lane (r16, q)] x 16 bytes =
  * w[tile * 16 + r16][step * 32 + 8 q .. + 8), so that a wave's load of one fragment is 1 KB contiguous (rows % 16 == 0, row_elems % 32 == 0) */
 int mt4_pack_fragments_bf16(const void* w_packed, int32_t rows, int32_t row_elems, void* out, void* stream);
+/* Two dependent 1x1 convolutions / linear layers in one launch, the map between them never read back (bf16 operands, fp32 accumulate, K-chunk
+ * accumulation: the N1 channels are produced 128 at a time and each chunk is at once the next GEMM's K range):
+ *   H  = act1(x . w1^T + b1 [+ r1])   [M][N1]   (stored to y1 when given)
+ *   y2 = act2(H . w2^T + b2 [+ r2])   [M][N2]
+ * Bottleneck form -- conv3 + bn3 + add + ReLU of one block and conv1 + bn1 + ReLU of the next (`Spatial_transformer/models/resnet.py:101-121`):
+ *   r1 = the block input, y1 = the block output (the next block's residual), act1 = act2 = 1 (ReLU), r2 = NULL.
+ * MLP form -- Swin's Mlp + shortcut (`swin_transformer.py:15-31,267-269`): r1 = y1 = NULL, act1 = 2 (GELU, erf), r2 = the shortcut, act2 = 0.
+ * x [M][x_ld] bf16 (row pitch x_ld >= K1 elements), w1_frag / w2_frag = mt4_pack_fragments_bf16 of the packed [N1][K1] / [N2][N1] matrices,
+ * b1 / b2 fp32.  K1 = 128 or 256, N1 a multiple of 128 (>= 256), N2 = 128 or 256 (MLP form: N2 == K1); MT4_EUNSUPPORTED otherwise.
+ * Both results are bit-identical to the two stand-alone mt4_conv_nhwc launches. */
+int mt4_chain_gemm_bf16(const void* x, int64_t x_ld, int64_t M, int32_t K1, const void* w1_frag, const float* b1, int32_t N1, const void* r1, void* y1,
+                        int32_t act1, const void* w2_frag, const float* b2, int32_t N2, const void* r2, int32_t act2, void* y2, void* stream);
 /* elements per packed weight row for a given geometry (Kpad above) */
 int64_t mt4_conv_packed_k(int32_t Cin, int32_t KH, int32_t KW, int32_t dtype);
 

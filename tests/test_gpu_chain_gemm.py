@@ -1,0 +1,72 @@
+"""GPU: `mt4_chain_gemm_bf16` -- two dependent 1x1 convolutions / linear layers in one launch (K-chunk accumulation) -- against the two
+stand-alone `mt4_conv_nhwc` launches it replaces: BIT-IDENTICAL in both forms (Bottleneck: conv3 + bn3 + add + ReLU -> next conv1 + bn1 + ReLU,
+`Spatial_transformer/models/resnet.py:101-121`; MLP: fc1 + GELU + fc2 + shortcut, `swin_transformer.py:15-31,267-269`), every supported shape,
+ragged row counts; and against torch fp32 on the same bf16 operands."""
+import numpy as np
+import pytest
+import torch
+
+from computervision_codes_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    n = int(np.prod(shape))
+    return torch.from_numpy(((synth.uniform01(seed, 7, n) * 2 - 1) * scale).astype(np.float32).reshape(shape))
+
+
+def _operands(cuda, m, k1, n1, n2, seed):
+    from computervision_codes_amd import ops
+    bf = torch.bfloat16
+    x = _rand((m, k1), seed).to(cuda).to(bf)
+    w1 = _rand((n1, k1, 1, 1), seed + 1, k1 ** -0.5).to(cuda)
+    w2 = _rand((n2, n1, 1, 1), seed + 2, n1 ** -0.5).to(cuda)
+    b1, b2 = _rand((n1,), seed + 3, 0.2).to(cuda), _rand((n2,), seed + 4, 0.2).to(cuda)
+    w1p, w2p = ops.pack_conv_weight(w1, None, bf), ops.pack_conv_weight(w2, None, bf)
+    return x, w1p, b1, w2p, b2
+
+
+@pytest.mark.parametrize("m,k1,n1,n2", [(196 * 5, 256, 1024, 256), (1000, 128, 512, 128), (784 * 2 + 3, 128, 512, 256), (130, 256, 512, 128), (1, 256, 256, 256)])
+def test_bottleneck_form_is_bit_identical_to_two_launches(cuda, m, k1, n1, n2):
+    from computervision_codes_amd import ops
+    x, w1p, b1, w2p, b2 = _operands(cuda, m, k1, n1, n2, 11)
+    r1 = _rand((m, n1), 16).to(cuda).to(torch.bfloat16)
+    y_ref = ops.conv_nhwc(x.view(1, 1, m, k1), w1p, b1, kh=1, kw=1, residual=r1.view(1, 1, m, n1), relu=True)
+    t_ref = ops.conv_nhwc(y_ref, w2p, b2, kh=1, kw=1, relu=True)
+    y1, y2 = ops.chain_gemm(x, ops.pack_fragments(w1p), b1, ops.pack_fragments(w2p), b2, r1=r1)
+    assert torch.equal(y1.view(-1), y_ref.view(-1)) and torch.equal(y2.view(-1), t_ref.view(-1))
+    # and the arithmetic itself: fp32 torch on the same bf16 operands, the intermediate rounded to bf16 where the launch stores it
+    w1 = w1p[:, :k1].float().cpu()
+    w2 = w2p[:, :n1].float().cpu()
+    h = torch.relu(x.float().cpu() @ w1.t() + b1.cpu() + r1.float().cpu()).to(torch.bfloat16)
+    assert (y1.float().cpu() - h.float()).abs().max().item() <= 2 ** -7 * max(1.0, h.float().abs().max().item())
+    t = torch.relu(y1.float().cpu() @ w2.t() + b2.cpu())
+    assert (y2.float().cpu() - t).abs().max().item() <= 2 ** -7 * max(1.0, t.abs().max().item())
+
+
+@pytest.mark.parametrize("m,c", [(9216 * 2, 128), (2304 + 77, 256), (1, 128)])
+def test_mlp_form_is_bit_identical_to_two_launches(cuda, m, c):
+    from computervision_codes_amd import ops
+    x, w1p, b1, w2p, b2 = _operands(cuda, m, c, 4 * c, c, 21)
+    sc = _rand((m, c), 26).to(cuda).to(torch.bfloat16)
+    h_ref = ops.linear(x, w1p, b1, act="gelu")
+    y_ref = ops.linear(h_ref, w2p, b2, residual=sc)
+    y1, y2 = ops.chain_gemm(x, ops.pack_fragments(w1p), b1, ops.pack_fragments(w2p), b2, r2=sc)
+    assert y1 is None and torch.equal(y2, y_ref)
+
+
+def test_row_pitch_and_argument_checks(cuda):
+    from computervision_codes_amd import _lib, ops
+    m, k1, n1, n2 = 300, 128, 512, 128
+    x, w1p, b1, w2p, b2 = _operands(cuda, m, k1, n1, n2, 31)
+    r1 = _rand((m, n1), 36).to(cuda).to(torch.bfloat16)
+    wide = torch.zeros((m, k1 + 64), dtype=torch.bfloat16, device=cuda)
+    wide[:, :k1] = x
+    a = ops.chain_gemm(x, ops.pack_fragments(w1p), b1, ops.pack_fragments(w2p), b2, r1=r1)
+    b = ops.chain_gemm(wide[:, :k1], ops.pack_fragments(w1p), b1, ops.pack_fragments(w2p), b2, r1=r1)      # a column slice: row pitch 192
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert not ops.chain_gemm_supported(512, 2048, 512, True) and ops.chain_gemm_supported(256, 1024, 256, True) and not ops.chain_gemm_supported(128, 512, 256, False)
+    x5, w1p5, b15, w2p5, b25 = _operands(cuda, 64, 512, 1024, 256, 41)
+    with pytest.raises(_lib.Mt4Error):
+        ops.chain_gemm(x5, ops.pack_fragments(w1p5), b15, ops.pack_fragments(w2p5), b25, r1=torch.zeros((64, 1024), dtype=torch.bfloat16, device=cuda))

@@ -13,7 +13,7 @@ _spec = _ilu.spec_from_file_location("srcdigest", os.path.join(os.path.dirname(o
 _sd = _ilu.module_from_spec(_spec); _spec.loader.exec_module(_sd)
 KSHA = _sd.kernels_digest(_sd.CONV_SOURCES)          # the sources the profiled library was built from (bench.py nulls the figure when they change)
 
-CONV_KERNELS = ("igemm_conv_kernel", "conv3x3_patch_kernel", "stem_patch_kernel", "stem_pool_kernel", "bottleneck64_fused_kernel")   # every conv launch of a step
+CONV_KERNELS = ("igemm_conv_kernel", "conv3x3_patch_kernel", "stem_patch_kernel", "stem_pool_kernel", "bottleneck64_fused_kernel", "chain_gemm_kernel")   # every conv launch of a step
 
 N_SIMD = 256 * 4
 N_XCD = 8
