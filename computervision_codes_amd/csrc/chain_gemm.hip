@@ -49,7 +49,10 @@ __device__ __forceinline__ float act(float v, int a) { return a == 1 ? fmaxf(v, 
 // NT2: N2 = 128 * NT2 (16-channel tiles per wave in GEMM2); NKS1 = K1 / 64; CONV: the Bottleneck form (r1 and y1 given, act1 = ReLU), else the MLP
 // form (no r1 / y1, act1 = GELU).  Everything a load is conditional on is a template parameter: a load behind a runtime condition makes hipcc
 // branch around it and drain the queue (cdna_hip_programming.md, projection-GEMM trap (c))
-template <int NT2, int NKS1, bool CONV>
+// NCHUNK = N1 / 128: the chunk loop is fully unrolled -- as a loop, hipcc waits vmcnt(0) at its header for the fragments requested an iteration
+// ago, which also drains the residual rows requested for the NEXT chunk and the stores of the previous one: every chunk then began with a full
+// memory round trip on all eight waves (first version: 65 us per 128-row tile against 14 us of MFMA time).  Straight-line code gets counted waits.
+template <int NT2, int NKS1, bool CONV, int NCHUNK>
 __global__ __launch_bounds__(512, 2) void chain_gemm_kernel(const ChainK a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -58,10 +61,11 @@ __global__ __launch_bounds__(512, 2) void chain_gemm_kernel(const ChainK a) {
     const int m0 = blockIdx.x * BM;
     constexpr int nks1 = NKS1;                    // 64-channel planes of X = K-steps of GEMM1
     constexpr int ACT1 = CONV ? 1 : 2;
-    const int nchunk = a.N1 / CH;
+    constexpr int nchunk = NCHUNK;
     const int mlast = a.M - 1;                    // rows past the end load the last row (never stored)
     char* const Xs = smem;
     char* const Hb = smem + nks1 * PLANE;         // two chunk images of 2 planes each
+    float* const B1s = (float*)(Hb + 4 * PLANE);  // b1, all N1 values (a load per chunk in front of its first MFMA would drain the queue)
     const long long n1b = (long long)a.N1 * 2, n2b = (long long)a.N2 * 2;
 
     // ---- the X tile: 16-byte pieces, coalesced (8 lanes = one 128-byte row segment), swizzle on the LDS side
@@ -80,29 +84,34 @@ __global__ __launch_bounds__(512, 2) void chain_gemm_kernel(const ChainK a) {
             *(uint4*)(Xs + plane * PLANE + row * 128 + ((ck ^ (row & 7)) << 4)) = xv[i];
         }
     }
-    // residual pieces of a chunk: thread t holds pieces t, t + 512, t + 1024, t + 1536 of the [2 planes][128 rows][8 chunks] image
-    uint4 rr[4];
-    auto load_r = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+    // residual pieces of a chunk: thread t holds pieces t, t + 512, t + 1024, t + 1536 of the [2 planes][128 rows][8 chunks] image (by value:
+    // an array captured by reference in these helpers stayed in scratch memory)
+    struct R4 { uint4 v0, v1, v2, v3; };
+    R4 rr;
+    auto load_r = [&](int c) __attribute__((always_inline)) -> R4 {
+        R4 r;
+        const char* base = a.r1 + (long long)(c * CH) * 2;
+        auto piece = [&](int i) __attribute__((always_inline)) -> uint4 {
             const int pid = tid + i * 512;
             const int plane = pid >> 10, row = (pid >> 3) & 127, ck = pid & 7;
-            rr[i] = *(const uint4*)(a.r1 + (long long)min(m0 + row, mlast) * n1b + (c * CH + plane * 64) * 2 + ck * 16);
-        }
+            return *(const uint4*)(base + (long long)min(m0 + row, mlast) * n1b + plane * 128 + ck * 16);
+        };
+        r.v0 = piece(0); r.v1 = piece(1); r.v2 = piece(2); r.v3 = piece(3);
+        return r;
     };
-    auto put_r = [&](int c) {
+    auto put_r = [&](int c, const R4& r) __attribute__((always_inline)) {
         char* hb = Hb + (c & 1) * (2 * PLANE);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        auto dst = [&](int i) __attribute__((always_inline)) -> uint4* {
             const int pid = tid + i * 512;
             const int plane = pid >> 10, row = (pid >> 3) & 127, ck = pid & 7;
-            *(uint4*)(hb + plane * PLANE + row * 128 + ((ck ^ (row & 7)) << 4)) = rr[i];
-        }
+            return (uint4*)(hb + plane * PLANE + row * 128 + ((ck ^ (row & 7)) << 4));
+        };
+        *dst(0) = r.v0; *dst(1) = r.v1; *dst(2) = r.v2; *dst(3) = r.v3;
     };
+    for (int i = tid; i < nchunk * (CH / 4); i += 512) *(float4*)(B1s + i * 4) = *(const float4*)(a.b1 + i * 4);
     if constexpr (CONV) {
-        load_r(0);
-        put_r(0);
-        load_r(min(1, nchunk - 1));
+        put_r(0, load_r(0));
+        rr = load_r(min(1, nchunk - 1));
     }
 
     // ---- weight fragments: wave w, chunk c -> GEMM1 channel tile c * 8 + w; GEMM2 channel tiles w * NT2 + t, K-steps 4 c .. 4 c + 3
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void chain_gemm_kernel(const ChainK a) {
     const char* const w1p = a.w1f + (long long)wave * f1_stride + lane * 16;
     const char* const w2p = a.w2f + (long long)(wave * NT2) * f2_stride + lane * 16;
     uint4 fa1[2 * NKS1];                                       // GEMM1 fragments of the chunk about to run
-    auto load_w1 = [&](int c) {
+    auto load_w1 = [&](int c) __attribute__((always_inline)) {
         const char* p = w1p + (long long)c * 8 * f1_stride;
 #pragma unroll
         for (int s = 0; s < 2 * NKS1; ++s) fa1[s] = *(const uint4*)(p + s * 1024);
@@ -131,12 +140,13 @@ __global__ __launch_bounds__(512, 2) void chain_gemm_kernel(const ChainK a) {
     const int frag_off = r16 * 128;
     const int sw0 = ((0 * 4 + q) ^ (r16 & 7)) << 4, sw1 = ((1 * 4 + q) ^ (r16 & 7)) << 4;   // (j * 16 + r16) & 7 == r16 & 7
 
+#pragma unroll
     for (int c = 0; c < nchunk; ++c) {
         char* const hb = Hb + (c & 1) * (2 * PLANE);
         // ---------------- GEMM1: acc1[channel 16 (c * 8 + wave) + 4 q + e][row j * 16 + r16]
         f32x4 acc1[8];
         {
-            const float4 b = *(const float4*)(a.b1 + (c * 8 + wave) * 16 + q * 4);
+            const float4 b = *(const float4*)(B1s + (c * 8 + wave) * 16 + q * 4);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc1[j] = (f32x4){b.x, b.y, b.z, b.w};
         }
@@ -146,13 +156,16 @@ __global__ __launch_bounds__(512, 2) void chain_gemm_kernel(const ChainK a) {
             const char* xp = Xs + ks * PLANE + frag_off;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                uint4 bx[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bx[j] = *(const uint4*)(xp + j * (16 * 128) + (kk ? sw1 : sw0));
                 const bf16x8_t A = __builtin_bit_cast(bf16x8_t, fa1[ks * 2 + kk]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, __builtin_bit_cast(bf16x8_t, bx[j]), acc1[j], 0, 0, 0);
+                for (int jh = 0; jh < 8; jh += 4) {       // row-tile fragments four at a time (all eight: 16 more live registers at the kernel's peak)
+                    uint4 bx[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bx[j] = *(const uint4*)(xp + (jh + j) * (16 * 128) + (kk ? sw1 : sw0));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc1[jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, __builtin_bit_cast(bf16x8_t, bx[j]), acc1[jh + j], 0, 0, 0);
+                }
                 if (ks == 0 && kk == 0) {
                     // GEMM2's fragments of this chunk: requested behind the first use of fa1 (in front of it the wait for fa1 -- requested a
                     // phase ago -- would drain these too), used after epilogue 1
@@ -186,8 +199,8 @@ __global__ __launch_bounds__(512, 2) void chain_gemm_kernel(const ChainK a) {
             }
         }
         if constexpr (CONV) {
-            put_r(c + 1);                            // the other image is free since Ba (past the last chunk: a spare copy nobody reads)
-            load_r(min(c + 2, nchunk - 1));
+            put_r(c + 1, rr);                        // the other image is free since Ba (past the last chunk: a spare copy nobody reads)
+            rr = load_r(min(c + 2, nchunk - 1));
         }
         __syncthreads();                             // Bb: H(c) complete
         // ---------------- the intermediate map to memory (conv case): whole 128-byte row segments per 8 lanes
@@ -281,27 +294,29 @@ extern "C" int mt4_chain_gemm_bf16(const void* x, int64_t x_ld, int64_t M, int32
     k.M = (int)M; k.K1 = K1; k.N1 = N1; k.N2 = N2; k.act1 = act1; k.act2 = act2;
     const int xs = (K1 / 64) * PLANE;
     const int out = BM * (N2 * 2 + 16);
-    const int lds = xs + 4 * PLANE > out ? xs + 4 * PLANE : out;
+    const int lds = xs + 4 * PLANE + N1 * 4 > out ? xs + 4 * PLANE + N1 * 4 : out;
     const int grid = (int)((M + BM - 1) / BM);
     const bool conv = r1 != nullptr;
     // Bottleneck form: r1 + y1, ReLU after both convs, no r2; MLP form: GELU between, shortcut r2, no activation behind
     if (conv != (y1 != nullptr) || act1 != (conv ? 1 : 2) || act2 != (conv ? 1 : 0) || conv == (r2 != nullptr)) return MT4_EUNSUPPORTED;
     if (K1 != 128 && K1 != 256) return MT4_EUNSUPPORTED;
-#define MT4_CHAIN_LAUNCH(NT2_, NKS1_, CONV_)                                                   \
+#define MT4_CHAIN_LAUNCH(NT2_, NKS1_, CONV_, NCH_)                                                 \
     do {                                                                                       \
-        auto fn = chain_gemm_kernel<NT2_, NKS1_, CONV_>;                                       \
+        auto fn = chain_gemm_kernel<NT2_, NKS1_, CONV_, NCH_>;                                 \
         MT4_RAISE_LDS(fn);                                                                     \
         hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, (hipStream_t)stream, k);            \
     } while (0)
+    const int nch = N1 / CH;
+    if (nch != 4 && nch != 8) return MT4_EUNSUPPORTED;
     if (conv) {
-        if (N2 == 256 && K1 == 256) MT4_CHAIN_LAUNCH(2, 4, true);
-        else if (N2 == 256) MT4_CHAIN_LAUNCH(2, 2, true);
-        else if (K1 == 256) MT4_CHAIN_LAUNCH(1, 4, true);
-        else MT4_CHAIN_LAUNCH(1, 2, true);
+        if (N2 == 256 && K1 == 256 && nch == 8) MT4_CHAIN_LAUNCH(2, 4, true, 8);          // ResNet-50 layer3: 256 -> 1024 -> 256
+        else if (N2 == 256 && K1 == 128 && nch == 4) MT4_CHAIN_LAUNCH(2, 2, true, 4);     // layer2.3 -> layer3.0: 128 -> 512 -> 256
+        else if (N2 == 128 && K1 == 128 && nch == 4) MT4_CHAIN_LAUNCH(1, 2, true, 4);     // layer2: 128 -> 512 -> 128
+        else return MT4_EUNSUPPORTED;
     } else {
-        if (N2 == 256 && K1 == 256) MT4_CHAIN_LAUNCH(2, 4, false);
-        else if (N2 == 128 && K1 == 128) MT4_CHAIN_LAUNCH(1, 2, false);
-        else return MT4_EUNSUPPORTED;          // (an MLP has N2 == K1)
+        if (N2 == 256 && K1 == 256 && nch == 8) MT4_CHAIN_LAUNCH(2, 4, false, 8);         // Swin-B stage 1: C = 256
+        else if (N2 == 128 && K1 == 128 && nch == 4) MT4_CHAIN_LAUNCH(1, 2, false, 4);    // Swin-B stage 0: C = 128
+        else return MT4_EUNSUPPORTED;
     }
 #undef MT4_CHAIN_LAUNCH
     return mt4_check_launch();

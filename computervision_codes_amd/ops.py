@@ -186,7 +186,7 @@ def pack_fragments(w_packed: torch.Tensor) -> torch.Tensor:
 
 def chain_gemm_supported(k1: int, n1: int, n2: int, conv: bool) -> bool:
     """shapes `chain_gemm` runs (`mt4_chain_gemm_bf16`)"""
-    return k1 in (128, 256) and n1 >= 256 and n1 % 128 == 0 and n2 in (128, 256) and (conv or n2 == k1)
+    return (k1, n1, n2) in ((256, 1024, 256), (128, 512, 128)) or (conv and (k1, n1, n2) == (128, 512, 256))
 
 
 def chain_gemm(x2d: torch.Tensor, w1_frag: torch.Tensor, b1: torch.Tensor, w2_frag: torch.Tensor, b2: torch.Tensor, *, r1: Optional[torch.Tensor] = None,

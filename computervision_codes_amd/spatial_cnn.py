@@ -53,7 +53,7 @@ class VideoNas:
         self.fuse_bottleneck = not os.environ.get("MT4_NO_BNECK_FUSE")   # layer1 Bottlenecks in one launch each (bf16 ResNet-50)
         # conv3 (+ bn3 + add + ReLU) of an identity Bottleneck and conv1 (+ bn1 + ReLU) of the block behind it in ONE launch (`ops.chain_gemm`,
         # K-chunk accumulation: the 4 x planes map is written once and not read back; bit-identical): the layers it is used in (bf16 ResNet-50)
-        self.chain_layers = tuple(int(c) for c in os.environ.get("MT4_CHAIN", "3") if c in "23")
+        self.chain_layers = tuple(int(c) for c in os.environ.get("MT4_CHAIN", "23") if c in "23")
 
     def train(self, mode: bool = True):
         self.training = bool(mode)

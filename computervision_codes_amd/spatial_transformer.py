@@ -168,6 +168,9 @@ class Qeruy2Label:
                     shift=shift, norm1=self._ln(q + "norm1"), norm2=self._ln(q + "norm2"),
                     qkv=self._lin(q + "attn.qkv.weight", q + "attn.qkv.bias"), proj=self._lin(q + "attn.proj.weight", q + "attn.proj.bias"),
                     fc1=self._lin(q + "mlp.fc1.weight", q + "mlp.fc1.bias"), fc2=self._lin(q + "mlp.fc2.weight", q + "mlp.fc2.bias"),
+                    # Mlp + shortcut in one launch where the block's width allows it (`ops.chain_gemm`, MLP form: the 4C-wide hidden map never
+                    # reaches memory; bit-identical to fc1 -> fc2): fragment-ordered copies of the two weight matrices
+                    mlp_frag=self._mlp_frag(q, self.cfg["embed_dim"] * 2 ** s),
                     bias=bias, mask=_shift_mask(res, ws, shift).to(dev) if shift > 0 else None,
                     # MFMA core (bf16, head dim 32): the (2ws-1)^2 table per head and the region ids of the window types; the
                     # kernel gathers bias and mask from them in LDS
@@ -213,6 +216,12 @@ class Qeruy2Label:
                 p[n] = (ops.pack_linear_weight(self._sd[n + ".weight"].to(dev), torch.float32), self._sd[n + ".bias"].to(dev).contiguous())
         self._p = p
 
+    def _mlp_frag(self, q: str, c: int):
+        import os
+        if self.dtype != torch.bfloat16 or os.environ.get("MT4_NO_MLP_CHAIN") or not ops.chain_gemm_supported(c, 4 * c, c, False):
+            return None
+        return ops.pack_fragments(self._lin(q + "mlp.fc1.weight", None)[0]), ops.pack_fragments(self._lin(q + "mlp.fc2.weight", None)[0])
+
     def _mfma_attn(self, stage: int) -> bool:
         c = self.cfg["embed_dim"] * 2 ** stage
         return self.dtype == torch.bfloat16 and c // self.cfg["num_heads"][stage] == 32
@@ -232,6 +241,8 @@ class Qeruy2Label:
                               q_stride=3 * c, k_stride=3 * c, v_stride=3 * c, scale=(c // nh) ** -0.5, bias=blk["bias"], mask=blk["mask"])
         x = ops.linear(a, *blk["proj"], residual=x, out_row_map=blk["row_map"])
         y = ops.layernorm(x, *blk["norm2"])
+        if blk["mlp_frag"] is not None:
+            return ops.chain_gemm(y, blk["mlp_frag"][0], blk["fc1"][1], blk["mlp_frag"][1], blk["fc2"][1], r2=x)[1]
         h = ops.linear(y, *blk["fc1"], act="gelu")
         return ops.linear(h, *blk["fc2"], residual=x)
 

@@ -158,7 +158,7 @@ int mt4_pack_fragments_bf16(const void* w_packed, int32_t rows, int32_t row_elem
  *   r1 = the block input, y1 = the block output (the next block's residual), act1 = act2 = 1 (ReLU), r2 = NULL.
  * MLP form -- Swin's Mlp + shortcut (`swin_transformer.py:15-31,267-269`): r1 = y1 = NULL, act1 = 2 (GELU, erf), r2 = the shortcut, act2 = 0.
  * x [M][x_ld] bf16 (row pitch x_ld >= K1 elements), w1_frag / w2_frag = mt4_pack_fragments_bf16 of the packed [N1][K1] / [N2][N1] matrices,
- * b1 / b2 fp32.  K1 = 128 or 256, N1 a multiple of 128 (>= 256), N2 = 128 or 256 (MLP form: N2 == K1); MT4_EUNSUPPORTED otherwise.
+ * b1 / b2 fp32.  (K1, N1, N2) = (256, 1024, 256) or (128, 512, 128), Bottleneck form also (128, 512, 256); MT4_EUNSUPPORTED otherwise.
  * Both results are bit-identical to the two stand-alone mt4_conv_nhwc launches. */
 int mt4_chain_gemm_bf16(const void* x, int64_t x_ld, int64_t M, int32_t K1, const void* w1_frag, const float* b1, int32_t N1, const void* r1, void* y1,
                         int32_t act1, const void* w2_frag, const float* b2, int32_t N2, const void* r2, int32_t act2, void* y2, void* stream);

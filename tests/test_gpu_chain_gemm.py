@@ -27,7 +27,7 @@ def _operands(cuda, m, k1, n1, n2, seed):
     return x, w1p, b1, w2p, b2
 
 
-@pytest.mark.parametrize("m,k1,n1,n2", [(196 * 5, 256, 1024, 256), (1000, 128, 512, 128), (784 * 2 + 3, 128, 512, 256), (130, 256, 512, 128), (1, 256, 256, 256)])
+@pytest.mark.parametrize("m,k1,n1,n2", [(196 * 5, 256, 1024, 256), (1000, 128, 512, 128), (784 * 2 + 3, 128, 512, 256), (130, 256, 1024, 256), (1, 128, 512, 128)])
 def test_bottleneck_form_is_bit_identical_to_two_launches(cuda, m, k1, n1, n2):
     from computervision_codes_amd import ops
     x, w1p, b1, w2p, b2 = _operands(cuda, m, k1, n1, n2, 11)
@@ -67,6 +67,44 @@ def test_row_pitch_and_argument_checks(cuda):
     b = ops.chain_gemm(wide[:, :k1], ops.pack_fragments(w1p), b1, ops.pack_fragments(w2p), b2, r1=r1)      # a column slice: row pitch 192
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert not ops.chain_gemm_supported(512, 2048, 512, True) and ops.chain_gemm_supported(256, 1024, 256, True) and not ops.chain_gemm_supported(128, 512, 256, False)
+    assert ops.chain_gemm_supported(128, 512, 256, True) and not ops.chain_gemm_supported(256, 512, 128, True)
     x5, w1p5, b15, w2p5, b25 = _operands(cuda, 64, 512, 1024, 256, 41)
     with pytest.raises(_lib.Mt4Error):
         ops.chain_gemm(x5, ops.pack_fragments(w1p5), b15, ops.pack_fragments(w2p5), b25, r1=torch.zeros((64, 1024), dtype=torch.bfloat16, device=cuda))
+
+
+def test_resnet50_trunk_with_chained_launches_is_bit_identical(cuda):
+    """ResNet-50 bf16 extraction with conv3 + next conv1 chained in layer3 / layers 2 and 3 against one launch per conv there: features and
+    logits equal bit for bit (ragged batch: the last row tile of every map is partial)"""
+    import types
+    from computervision_codes_amd import shapes
+    from computervision_codes_amd.spatial_cnn import VideoNas
+    args = types.SimpleNamespace(network="resnet50", loss_type="all", student_dim=2048, teacher_dim=1536, train=False)
+    sd = synth.fill_from_shapes(shapes.spatial_cnn_shapes("resnet50"), seed=3)
+    frames = synth.synthetic_frames(5, 224, 224, seed=9).to(cuda)
+    outs = []
+    for chain in ((), (3,), (2, 3)):
+        m = VideoNas(args=args, dtype=torch.bfloat16).eval().load_state_dict(sd)
+        m.chain_layers = chain
+        outs.append(m.extract_u8(frames))
+        assert len(m.launch_groups(224, 224)) == {(): 39, (3,): 35, (2, 3): 35}[chain]
+    for o in outs[1:]:
+        assert torch.equal(o[3][0], outs[0][3][0]) and all(torch.equal(a[1], b[1]) for a, b in zip(o, outs[0]))
+
+
+def test_swin_mlp_through_chain_gemm_is_bit_identical(cuda, monkeypatch):
+    """Swin-B/384 bf16: the Mlp + shortcut of stages 0 and 1 (C = 128 / 256) as one launch each against fc1 -> fc2"""
+    import types
+    from computervision_codes_amd import shapes
+    from computervision_codes_amd.spatial_transformer import build_q2l
+    args = types.SimpleNamespace(backbone="swin_B_384_22k", img_size=384, hidden_dim=1024, loss_type="t")
+    sd = synth.fill_from_shapes(shapes.q2l_param_shapes("swin_B_384_22k", 384, 1024, "t"), seed=5)
+    frames = synth.synthetic_frames(2, 384, 384, seed=6).to(cuda)
+    m = build_q2l(args, dtype=torch.bfloat16).eval().load_state_dict(sd)
+    assert m._stages[0]["blocks"][0]["mlp_frag"] is not None and m._stages[1]["blocks"][1]["mlp_frag"] is not None and m._stages[2]["blocks"][0]["mlp_frag"] is None
+    a = m(frames)
+    monkeypatch.setenv("MT4_NO_MLP_CHAIN", "1")
+    m2 = build_q2l(args, dtype=torch.bfloat16).eval().load_state_dict(sd)
+    assert m2._stages[0]["blocks"][0]["mlp_frag"] is None
+    b = m2(frames)
+    assert torch.equal(a[2][1], b[2][1]) and torch.equal(a[3][0], b[3][0])
