@@ -338,21 +338,41 @@ class SpatialCnnTrainer:
         tf = [t.to(dev, F32).contiguous() for t in teacher_feat]
         B = frames.shape[0]
         assert frames.is_cuda and tuple(z.shape) == (B, self.NH)
+        self.bucket_order = []            # gradient buckets in the order their all-reduce was issued this step (DDP)
         if use_graph:
-            key = (tuple(frames.shape), frames.dtype)
+            # data-parallel steps with bucket overlap: the backward is captured in SEGMENTS cut where a gradient bucket is complete
+            # (`_reduce_bucket`), and the bucket's all-reduce is issued between two replays -- one graph would leave ONE flat all-reduce
+            # behind the whole backward (171 MB for the ResNet-50 student)
+            seg = self.overlap and getattr(self, "exchange", True) and self._ddp_world() > 1
+            key = (tuple(frames.shape), frames.dtype, bool(seg))
             g = self._graphs.get(key)
             if g is None:
-                from .graph import GraphedForward
+                from .graph import GraphedForward, SegmentedGraph
                 keep = {n: (u.rmean.clone(), u.rvar.clone()) for n, u in self.units.items()}   # warm-up + capture runs must not count
                 self._capturing = True
                 try:
-                    g = self._graphs[key] = GraphedForward(lambda f, zz, *t: self._fwd_bwd(f, zz, t[:3], t[3:]), [frames, z, *tp, *tf])
+                    fn = lambda f, zz, *t: self._fwd_bwd(f, zz, t[:3], t[3:])
+                    if seg:
+                        def fn_cut(cut, *a):
+                            self._cut = cut
+                            try:
+                                return fn(*a)
+                            finally:
+                                self._cut = None
+                        g = SegmentedGraph(fn_cut, [frames, z, *tp, *tf])
+                    else:
+                        g = GraphedForward(fn, [frames, z, *tp, *tf])
+                    self._graphs[key] = g
                 finally:
                     self._capturing = False
+                    self._cut = None
                 for n, u in self.units.items():
                     u.rmean.copy_(keep[n][0])
                     u.rvar.copy_(keep[n][1])
-            col_loss, soft, kdl = g(frames, z, *tp, *tf)
+            if seg:
+                col_loss, soft, kdl = g(frames, z, *tp, *tf, on_cut=self._issue_bucket)
+            else:
+                col_loss, soft, kdl = g(frames, z, *tp, *tf)
         else:
             col_loss, soft, kdl = self._fwd_bwd(frames, z, tp, tf)
         for bn in self.nbt:
@@ -505,10 +525,18 @@ class SpatialCnnTrainer:
     def _reduce_bucket(self, name: str):
         """DDP overlap: the bucket's all-reduce is enqueued behind the kernels that wrote it and runs while the backward
         of the earlier layers continues; `apply_update` waits for all of them.  Not inside a hipGraph capture."""
-        if not self.overlap or self._capturing or not getattr(self, "exchange", True) or self._ddp_world() == 1:
+        if self._capturing:
+            if getattr(self, "_cut", None) is not None:     # segmented capture: the graph is cut here, the all-reduce is issued at replay
+                self._cut(name)
             return
+        if not self.overlap or not getattr(self, "exchange", True) or self._ddp_world() == 1:
+            return
+        self._issue_bucket(name)
+
+    def _issue_bucket(self, name: str):
         import torch.distributed as dist
         a, b = self._ranges[name]
+        self.bucket_order = getattr(self, "bucket_order", []) + [name]
         if b > a:
             self._pending.append(dist.all_reduce(self.G[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 

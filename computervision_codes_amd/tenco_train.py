@@ -172,16 +172,33 @@ class TencoTrainer:
         T, dev = x.shape[1], self.dev
         z = labels if torch.is_tensor(labels) else self.prepare_labels(labels)
         assert z.is_cuda and tuple(z.shape) == (T, NH) and z.dtype == torch.float32
+        self.bucket_order = []            # gradient buckets in the order their all-reduce was issued this step (DDP)
         if use_graph and not masks:
-            g = self._graphs.get(T)
+            # data-parallel steps with bucket overlap: the backward is captured in segments cut where a stage's gradients are complete, the
+            # stage's all-reduce is issued between two replays (`graph.SegmentedGraph`); otherwise one graph, one flat all-reduce behind it
+            seg = self.overlap and getattr(self, "exchange", True) and self._ddp_world() > 1
+            g = self._graphs.get((T, bool(seg)))
             if g is None:
-                from .graph import GraphedForward
+                from .graph import GraphedForward, SegmentedGraph
                 self._capturing = True
                 try:
-                    g = self._graphs[T] = GraphedForward(lambda xx, zz: self._fwd_bwd(xx, zz, None), [x, z])
+                    if seg:
+                        def fn_cut(cut, xx, zz):
+                            self._cut = cut
+                            try:
+                                return self._fwd_bwd(xx, zz, None)
+                            finally:
+                                self._cut = None
+                        g = SegmentedGraph(fn_cut, [x, z])
+                    else:
+                        g = GraphedForward(lambda xx, zz: self._fwd_bwd(xx, zz, None), [x, z])
+                    self._graphs[(T, bool(seg))] = g
                 finally:
                     self._capturing = False
-            col_loss = g(x, z)
+            if seg:
+                col_loss = g(x, z, on_cut=self._issue_bucket)
+            else:
+                col_loss = g(x, z)
         else:
             col_loss = self._fwd_bwd(x, z, masks)
         cl = col_loss.cpu()
@@ -293,12 +310,20 @@ class TencoTrainer:
 
     def _reduce_bucket(self, name: str):
         """DDP overlap: the bucket's all-reduce is enqueued behind the kernels that wrote it and runs while the backward of the
-        earlier stages continues; `apply_update` waits for all of them.  Eager steps only (inside a hipGraph capture the step keeps the single
-        flat all-reduce after the replay)."""
-        if not self.overlap or self._capturing or not getattr(self, "exchange", True) or self._ddp_world() == 1:
+        earlier stages continues; `apply_update` waits for all of them.  Under graph replay the backward is replayed in segments cut at these
+        points (`train_step`)."""
+        if self._capturing:
+            if getattr(self, "_cut", None) is not None:     # segmented capture: the graph is cut here, the all-reduce is issued at replay
+                self._cut(name)
             return
+        if not self.overlap or not getattr(self, "exchange", True) or self._ddp_world() == 1:
+            return
+        self._issue_bucket(name)
+
+    def _issue_bucket(self, name: str):
         import torch.distributed as dist
         a, b = self._ranges[name]
+        self.bucket_order = getattr(self, "bucket_order", []) + [name]
         if b > a:
             self._pending.append(dist.all_reduce(self.G[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 

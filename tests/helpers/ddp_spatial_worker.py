@@ -17,14 +17,17 @@ def batch(rank, B=2, H=64, W=64):
 
 
 if __name__ == "__main__":
-    out_dir, overlap = sys.argv[1], sys.argv[2] == "1"
+    out_dir, overlap = sys.argv[1], sys.argv[2] in ("1", "graph")
+    graph = sys.argv[2] == "graph"
     dist.init_process_group("gloo")
     rank = dist.get_rank()
     sd = synth.fill_from_shapes(shapes.spatial_cnn_shapes("resnet18"), seed=9)
     tr = SpatialCnnTrainer("resnet18", lr=0.05, overlap=overlap).load_state_dict(sd)
     fr, labels, tp, tf = batch(rank)
-    tr.train_step(fr.cuda(), labels, tp, tf)
+    tr.train_step(fr.cuda(), labels, tp, tf, use_graph=graph)     # graph: segmented replay, a bucket's all-reduce issued between two segments
     if rank == 0:
-        torch.save(tr.state_dict(), os.path.join(out_dir, f"ddp_overlap{int(overlap)}.pth"))
+        sd = tr.state_dict()
+        sd["__bucket_order__"] = list(getattr(tr, "bucket_order", []))
+        torch.save(sd, os.path.join(out_dir, f"ddp_overlap{sys.argv[2]}.pth"))
     dist.barrier()
     dist.destroy_process_group()

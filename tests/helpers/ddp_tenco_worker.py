@@ -24,12 +24,16 @@ def trainer():
 
 if __name__ == "__main__":
     out_dir = sys.argv[1]
+    graph = len(sys.argv) > 2 and sys.argv[2] == "graph"
     dist.init_process_group("gloo")
     rank = dist.get_rank()
     tr = trainer()
     x, labels = video(rank)
-    tr.train_step(x.cuda(), labels)
+    tr.train_step(x.cuda(), labels, use_graph=graph)      # graph: segmented replay, a stage's all-reduce issued between two segments
     if rank == 0:
-        torch.save(tr.state_dict(), os.path.join(out_dir, "ddp_tenco.pth"))
+        sd = tr.state_dict()
+        sd["__bucket_order__"] = list(getattr(tr, "bucket_order", []))
+        sd["__segments__"] = len(tr._graphs[(x.shape[1], True)].segments) if graph else 0
+        torch.save(sd, os.path.join(out_dir, "ddp_tenco.pth"))
     dist.barrier()
     dist.destroy_process_group()
