@@ -623,6 +623,17 @@ def ddp_train_bench(dev, dist, world, rank):
                                           overlap_fraction=round(1.0 - min(1.0, exposed / ar), 3) if ar > 0 else None,
                                           frames_per_rank=B, dtype="f32" if odt == torch.float32 else "bf16 GEMM operands, fp32 master weights / sums",
                                           mode="eager, bucketed all-reduce issued behind the backward")
+        # the same step under hipGraph replay: the backward replayed in segments cut where a bucket is complete, its all-reduce issued between
+        # two replays (graph.SegmentedGraph); exchange off = the single-graph replay
+        ms_g = timed(lambda: tr.train_step(frames, z, tp, tf, use_graph=True), iters)
+        tr.exchange = False
+        ms_g_local = timed(lambda: tr.train_step(frames, z, tp, tf, use_graph=True), iters)
+        tr.exchange = True
+        exposed = max(0.0, ms_g - ms_g_local)
+        out[f"spatial_{net}_b{B}" + ("_bf16" if odt == torch.bfloat16 else "") + "_graph"] = dict(
+            frames_per_s=round(world * B / ms_g * 1e3, 1), ms_per_step=round(ms_g, 3), ms_per_step_no_exchange=round(ms_g_local, 3),
+            overlap_fraction=round(1.0 - min(1.0, exposed / ar), 3) if ar > 0 else None,
+            mode="hipGraph replay in segments (one per gradient bucket), the bucket's all-reduce issued between replays")
         del tr
     T = 1000
     tr = TencoTrainer(lr=0.01, device=str(dev)).load_state_dict(synth.fill_from_shapes(shapes.tenco_shapes(), seed=47))
@@ -638,7 +649,7 @@ def ddp_train_bench(dev, dist, world, rank):
     out[f"tenco4_T{T}"] = dict(videos_per_s=round(world / ms * 1e3, 2), ms_per_step=round(ms, 3), ms_per_step_no_exchange=round(ms_local, 3),
                                allreduce_alone_ms=round(ar, 3), grad_MB=round(tr.G.numel() * 4 / 1e6, 1),
                                overlap_fraction=round(1.0 - min(1.0, exposed / ar), 3) if ar > 0 else None,
-                               mode="hipGraph replay of forward+backward, one flat all-reduce")
+                               mode="hipGraph replay in segments (heads, Rs.2, Rs.1, Rs.0, PG), a stage's all-reduce issued between replays")
     ms_e = timed(lambda: tr.train_step(xt, zl, use_graph=False), 10)                        # eager: per-stage buckets behind the backward
     tr.exchange = False
     ms_e_local = timed(lambda: tr.train_step(xt, zl, use_graph=False), 10)

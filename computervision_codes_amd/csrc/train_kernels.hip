@@ -92,6 +92,19 @@ __global__ __launch_bounds__(256) void wgrad_conv1d_f32_kernel(const float* __re
     }
 }
 
+// zero-fill as a KERNEL node: a hipMemsetAsync captured into one of several consecutive hipGraphs of a stream (graph.SegmentedGraph) left parts of
+// its range unwritten on replay (every fourth dword of the bias gradients, a different vector each run; the single-graph capture was fine), so
+// the zeroing in front of an atomic accumulation is a launch of our own
+__global__ void zero_f32_kernel(float* __restrict__ p, long long n) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 4 <= n) *(float4*)(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else
+        for (long long k = i; k < n; ++k) p[k] = 0.f;
+}
+static inline void zero_f32(float* p, long long n, hipStream_t s) {   // p 16-byte aligned
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, p, n);
+}
+
 extern "C" int mt4_wgrad_conv1d_f32(const float* dy, const float* x, float* dw_packed, int32_t B, int32_t T, int32_t Cout, int32_t Cin,
                                     int32_t taps, int32_t dil, int32_t pad, int32_t accumulate, void* stream) {
     mt4_clear_error();
@@ -107,7 +120,7 @@ extern "C" int mt4_wgrad_conv1d_f32(const float* dy, const float* x, float* dw_p
     const long long rps = ((M + splits - 1) / splits + 31) / 32 * 32;
     splits = (M + rps - 1) / rps;
     hipStream_t s = (hipStream_t)stream;
-    if (splits > 1 && !accumulate && hipMemsetAsync(dw_packed, 0, (size_t)Cout * Kpad * sizeof(float), s) != hipSuccess) return mt4_check_launch();
+    if (splits > 1 && !accumulate) zero_f32(dw_packed, (long long)Cout * Kpad, s);
     const dim3 grid(cdiv(Kpad, 64), cdiv(Cout, 64), (unsigned)splits);
     hipLaunchKernelGGL(wgrad_conv1d_f32_kernel, grid, dim3(256), 0, s, dy, x, dw_packed, B, T, Cout, Cin, taps, dil, pad, Kpad, accumulate, rps);
     return mt4_check_launch();
@@ -132,7 +145,10 @@ extern "C" int mt4_colsum_f32(const float* x, float* out, int64_t M, int32_t C, 
     mt4_clear_error();
     if (!x || !out || M <= 0 || C <= 0 || ld < C) return MT4_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate && hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s) != hipSuccess) return mt4_check_launch();
+    if (!accumulate) {
+        if ((uintptr_t)out & 15) return MT4_EALIGN;
+        zero_f32(out, C, s);
+    }
     long long slabs = (M + 63) / 64;                     // >= 16 rows per wave and slab
     const long long cap = (1024 + cdiv(C, 64) - 1) / cdiv(C, 64);
     if (slabs > cap) slabs = cap;
