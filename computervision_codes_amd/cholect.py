@@ -84,11 +84,15 @@ def load_frames_device(data_dir: str, video: str, frame_ids, height: int = 256, 
     of one native size go through one launch pair; a video mixing sizes falls back to one group per size.  workers > 1: the PNGs
     are decoded by that many threads (Pillow releases the GIL while it inflates; the reference's loader has 3 worker processes,
     `Spatial_cnn/test.py:240-241`)."""
+    import struct
+
     import torch
     from PIL import Image
 
-    from . import ops
+    from . import _lib, ops
 
+    if len(frame_ids) == 0:
+        return torch.empty((0, height, width, 3), dtype=torch.uint8, device=device)
     if decode == "device":
         # decode = "device": the files are only read; inflate + unfiltering run on the GPU (`pngdec.decode_batch`, 8-bit RGB non-interlaced PNGs --
         # what the dataset ships; anything else raises `pngdec.UnsupportedPng`).  Same bytes as the Pillow path.
@@ -114,9 +118,10 @@ def load_frames_device(data_dir: str, video: str, frame_ids, height: int = 256, 
                 y = x if (h0, w0) == (height, width) else ops.resize_bilinear_u8(x, height, width)
                 out[torch.tensor(idx, device=device)] = y
             return out
-        except (pngdec.UnsupportedPng, pngdec.DecodeError) as e:
-            # a PNG flavour the device decoder does not cover (palette, grey, alpha, 16-bit, interlaced), or a stream it reports as bad (Pillow
-            # then has the last word on the file): this batch goes through Pillow; said once
+        except (pngdec.UnsupportedPng, pngdec.DecodeError, _lib.Mt4Error, struct.error) as e:
+            # a PNG flavour the device decoder does not cover (palette, grey, alpha, 16-bit, interlaced, wider than 4096), a malformed chunk
+            # list, a stream it reports as bad, or a launch the library refuses (Pillow then has the last word on the file): this batch goes
+            # through Pillow; said once
             global _WARNED_PNG
             if not _WARNED_PNG:
                 print(f"[cholect] --png_decode device: {e}; such files are decoded by Pillow on the host", flush=True)

@@ -50,7 +50,15 @@ struct Bits {
 
 __device__ __forceinline__ void load_chunk(Bits& b, int lane) {
     b.chunk0 = b.dw & ~127;
-    const uint2 t = *(const uint2*)(b.base + b.chunk0 + 2 * lane);      // (the host pads the blob by 1 KB: reading past the last stream is in bounds)
+    // a chunk that STARTS behind the stream's last byte is never read: a stream with intact PNG chunks but a corrupt DEFLATE body (no CRC /
+    // Adler check here) would otherwise run the literal loops up to raw_len x 15 bits past its end -- far beyond the 1 KB pad behind the last
+    // stream of a batch.  The wave decodes zeros from there on and `bad` is reported at the next check (block header, match, flush point, end)
+    if (b.chunk0 > ((b.nbits >> 3) + b.mis + 3) >> 2) {
+        b.w0 = b.w1 = 0;
+        b.bad = 1;
+        return;
+    }
+    const uint2 t = *(const uint2*)(b.base + b.chunk0 + 2 * lane);      // (the host pads the blob by 1 KB: the last chunk of the last stream is in bounds)
     b.w0 = t.x; b.w1 = t.y;
 }
 
@@ -356,6 +364,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                     b.cnt -= (e >> 9);
                 }
                 if (pos >= limit && pos < raw_len) {        // flush point
+                    if (b.bad || bits_used(b) > b.nbits) { err = 1; break; }
                     __syncthreads();
                     flush_to(flushed + FLUSH);
                     __syncthreads();

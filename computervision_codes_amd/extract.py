@@ -37,34 +37,54 @@ def extract_video(frames: torch.Tensor, forward: Callable[[torch.Tensor], torch.
     return torch.vstack(out).numpy() if out else np.zeros((0, 0), np.float32)
 
 
+_POOLS: Dict[int, ThreadPoolExecutor] = {}          # helper threads by prefetch depth, kept for the life of the process: a thread's pinned staging
+                                                     # buffer (`pngdec._staging`, >= 64 MB per thread) is page-locked once, not once per video
+
+
 def iter_chunks(spans: Sequence[tuple], load_chunk: Callable[[int, int], torch.Tensor], prefetch=1):
     """Yield `load_chunk(s, e)` for every span in order.  With `prefetch` = k > 0 the next k spans are read and decoded on helper threads
     while the caller works on this one (the reference's DataLoader workers run ahead of the model the same way, `Spatial_cnn/test.py:240-241`);
     k = 2 lets the host part of one load (file reads, gathering the compressed bytes) overlap the device part of the load before it.
-    Device and stream are per-thread state: the helpers take the caller's, so whatever they launch is ordered before the caller's first
-    use of the frames."""
+    The helpers launch on a SIDE stream of their own (a loader that ends in a blocking status read -- the device PNG decoder -- then waits for
+    its own kernels only, not for every model pass the caller has queued); a chunk is handed over with an event the caller's stream waits on."""
     depth = int(prefetch)
     if depth <= 0 or len(spans) < 2 or not torch.cuda.is_available():
         for s, e in spans:
             yield load_chunk(s, e)
         return
     dev, cur = torch.cuda.current_device(), torch.cuda.current_stream()
+    side = torch.cuda.Stream()
 
     def ahead(s, e):
         torch.cuda.set_device(dev)
-        with torch.cuda.stream(cur):
-            return load_chunk(s, e)
+        with torch.cuda.stream(side):
+            fr = load_chunk(s, e)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return fr, ev
     depth = min(depth, len(spans))
-    pool = ThreadPoolExecutor(depth)
+    pool = _POOLS.get(depth)
+    if pool is None:
+        pool = _POOLS[depth] = ThreadPoolExecutor(depth, thread_name_prefix="mt4-load")
+    pending = [pool.submit(ahead, *spans[i]) for i in range(depth)]
     try:
-        pending = [pool.submit(ahead, *spans[i]) for i in range(depth)]
         for i in range(len(spans)):
-            fr = pending.pop(0).result()
+            fr, ev = pending.pop(0).result()
             if i + depth < len(spans):
                 pending.append(pool.submit(ahead, *spans[i + depth]))
+            cur.wait_event(ev)
+            if torch.is_tensor(fr) and fr.is_cuda:
+                fr.record_stream(cur)           # allocated on the side stream, consumed on the caller's
             yield fr
     finally:
-        pool.shutdown(wait=True)
+        for f in pending:                       # (the consumer stopped early: let the loads in flight finish before their buffers go)
+            f.cancel()
+        for f in pending:
+            if not f.cancelled():
+                try:
+                    f.result()
+                except Exception:
+                    pass
 
 
 def extract_video_device(model, n_frames: int, load_chunk: Callable[[int, int], torch.Tensor], device_batch: int = 512, streams: int = 1,

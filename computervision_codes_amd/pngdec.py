@@ -60,8 +60,15 @@ def parse_png(data: bytes) -> Tuple[int, int, bytes]:
     return width, height, z[2:]
 
 
+MAX_WIDTH = 4096                 # `mt4_png_unfilter_rgb8` keeps three rows of 3 W bytes in LDS (csrc/png_kernels.hip: UNF_MAXROW)
+MAX_RAW_BYTES = (1 << 31) - 256  # raw scanline bytes of one frame the kernels index with 32 bits
+MAX_STREAM_BYTES = 1 << 28       # compressed bytes of one frame: its bit count must stay below 2^31
+
+
 def _idat_spans(data: bytes) -> Tuple[int, int, List[Tuple[int, int]]]:
-    """(width, height, [(offset, length) of every IDAT payload]) -- `parse_png` without copying the payloads"""
+    """(width, height, [(offset, length) of every IDAT payload]) -- `parse_png` without copying the payloads.  Everything the device decoder
+    cannot take is an `UnsupportedPng` HERE, before any launch or allocation sized by the header: malformed chunk headers, sizes beyond the
+    kernels' limits, streams too long for their 32-bit bit counter."""
     if len(data) < 33 or data[:8] != _SIG:
         raise UnsupportedPng("not a PNG file")
     pos = 8
@@ -72,9 +79,13 @@ def _idat_spans(data: bytes) -> Tuple[int, int, List[Tuple[int, int]]]:
         if pos + 12 + n > len(data):
             raise UnsupportedPng("truncated chunk")
         if typ == b"IHDR":
+            if n < 13:
+                raise UnsupportedPng("IHDR shorter than 13 bytes")
             width, height, depth, ctype, comp, filt, inter = struct.unpack_from(">IIBBBBB", data, pos + 8)
             if depth != 8 or ctype != 2 or comp != 0 or filt != 0 or inter != 0:
                 raise UnsupportedPng(f"bit depth {depth}, colour type {ctype}, interlace {inter}: only 8-bit RGB, non-interlaced")
+            if not (0 < width <= MAX_WIDTH) or height <= 0 or height * (1 + 3 * width) > MAX_RAW_BYTES:
+                raise UnsupportedPng(f"frame {width} x {height}: the device decoder takes widths up to {MAX_WIDTH} and < 2 GiB of scanlines")
         elif typ == b"IDAT":
             if n:
                 spans.append((pos + 8, n))
@@ -83,6 +94,8 @@ def _idat_spans(data: bytes) -> Tuple[int, int, List[Tuple[int, int]]]:
         pos += 12 + n
     if width is None or not spans:
         raise UnsupportedPng("no IHDR / IDAT")
+    if sum(l for _, l in spans) >= MAX_STREAM_BYTES:
+        raise UnsupportedPng("zlib stream of 256 MB or more")
     return width, height, spans
 
 
@@ -102,6 +115,8 @@ def decode_batch(files: Sequence[bytes], device="cuda", timings: dict = None, wo
     """PNG files (bytes) of ONE frame size -> uint8 [N,H,W,3] on the device, equal to `np.asarray(PIL.Image.open(f).convert('RGB'))`.
     Raises `UnsupportedPng` before any launch if a file is not 8-bit RGB / non-interlaced or the sizes differ, `RuntimeError` if a
     stream is corrupt.  The IDAT payloads are gathered straight into one pinned buffer (one copy on the host, `workers` threads)."""
+    if len(files) == 0:
+        raise UnsupportedPng("empty batch")
     metas = [_idat_spans(f) for f in files]
     w, h = metas[0][0], metas[0][1]
     if any((m[0], m[1]) != (w, h) for m in metas):
@@ -176,6 +191,8 @@ def decode_files(paths: Sequence[str], device="cuda", timings: dict = None, work
     payloads are packed into contiguous zlib streams on the device (`mt4_copy_spans_u8`).  The host only walks the chunk lists."""
     import os
     n = len(paths)
+    if n == 0:
+        raise UnsupportedPng("empty batch")
     sizes = np.array([os.path.getsize(p) for p in paths], dtype=np.int64)
     foff = np.zeros(n, dtype=np.int64)
     foff[1:] = np.cumsum((sizes[:-1] + 15) // 16 * 16)

@@ -108,3 +108,36 @@ def test_png_decode_files_from_disk_equals_decode_batch(cuda, tmp_path):
     odd.write_bytes(_png(_frames(1, 64, 96, 5, "photo")[0]))
     with pytest.raises(pngdec.MixedSizes):
         pngdec.decode_files(paths[:3] + [str(odd)], cuda)
+
+
+def test_corrupt_stream_last_in_the_batch_is_reported_without_reading_past_the_blob(cuda):
+    """A frame whose PNG chunks are intact but whose DEFLATE body is damaged, placed LAST in the batch (behind it only the 1 KB pad): the
+    decoder must report it (`DecodeError`, the caller's signal to hand the batch to Pillow) -- it stops taking input at the stream's end
+    (`load_chunk`) instead of running its literal loops megabytes past the blob.  Several damage patterns, incl. a stream cut to a fraction of
+    its length with the chunk header rewritten to match (the symbols keep coming from beyond the end)."""
+    import struct
+    import zlib
+    from computervision_codes_amd import pngdec
+    frames = _frames(3, 120, 160, 5, "photo")
+    good = [_png(f) for f in frames]
+
+    def rebuild(f, mutate):
+        """the file with its (single) IDAT payload replaced by mutate(payload), length and CRC fields consistent"""
+        i = f.index(b"IDAT") - 4
+        n = struct.unpack(">I", f[i:i + 4])[0]
+        payload = mutate(bytes(f[i + 8:i + 8 + n]))
+        chunk = b"IDAT" + payload
+        return f[:i] + struct.pack(">I", len(payload)) + chunk + struct.pack(">I", zlib.crc32(chunk)) + f[i + 12 + n:]
+
+    def flip(p):
+        q = bytearray(p)
+        for k in range(40, len(q), 97):
+            q[k] ^= 0xA5
+        return bytes(q)
+    for mutate in (flip, lambda p: p[:len(p) // 3], lambda p: p[:64]):
+        bad = rebuild(good[2], mutate)
+        assert pngdec._idat_spans(bad)[:2] == (160, 120)                 # the chunk walk finds nothing wrong
+        with pytest.raises(pngdec.DecodeError):
+            pngdec.decode_batch([good[0], good[1], bad], cuda)
+    out = pngdec.decode_batch(good, cuda)                                # and the decoder is fine afterwards
+    assert np.array_equal(out.cpu().numpy(), np.stack(frames))

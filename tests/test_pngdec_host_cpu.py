@@ -43,3 +43,32 @@ def test_unsupported_files_are_refused():
     good = _png(np.zeros((4, 4, 3), np.uint8))
     with pytest.raises(pngdec.UnsupportedPng):
         pngdec.parse_png(good[:40])
+
+
+def _rewrite_ihdr(f, width=None, ihdr_len=None):
+    """a copy of PNG file `f` with the IHDR width replaced (CRC left stale: the chunk walk does not check it) or the IHDR chunk cut short"""
+    import struct
+    b = bytearray(f)
+    assert b[12:16] == b"IHDR"
+    if width is not None:
+        b[16:20] = struct.pack(">I", width)
+    if ihdr_len is not None:                       # keep ihdr_len data bytes of the 13, fix the length field
+        body = bytes(b[16:16 + ihdr_len])
+        b = bytearray(b[:8]) + struct.pack(">I", ihdr_len) + b"IHDR" + body + bytes(b[16 + 13:])
+    return bytes(b)
+
+
+def test_sizes_beyond_the_kernels_limits_and_malformed_headers_are_unsupported_not_errors():
+    """what the device decoder cannot take is refused by the HOST walk, as `UnsupportedPng` (the caller's signal to fall back to Pillow), before
+    any allocation sized by the header: width > 4096 (LDS row buffers of the unfilter kernel), a crafted giant frame, an IHDR shorter than 13
+    bytes, an empty batch"""
+    pngdec = _load()
+    f = _png(np.zeros((5, 7, 3), np.uint8))
+    assert pngdec._idat_spans(f)[:2] == (7, 5)
+    for bad in (_rewrite_ihdr(f, width=4097), _rewrite_ihdr(f, width=0), _rewrite_ihdr(f, width=0x7FFFFFFF), _rewrite_ihdr(f, ihdr_len=9)):
+        with pytest.raises(pngdec.UnsupportedPng):
+            pngdec._idat_spans(bad)
+    with pytest.raises(pngdec.UnsupportedPng):
+        pngdec.decode_batch([], "cpu")
+    with pytest.raises(pngdec.UnsupportedPng):
+        pngdec.decode_files([], "cpu")
