@@ -92,8 +92,7 @@ struct ConvK {
     int w_row_bytes;        // nsteps*128
     int nt_epi;             // residual rows are loaded and bf16 output rows stored non-temporally (each is touched once by this launch;
                             // same-box A/B on the ResNet-50 bench: +2.6 % frames/s).  MT4_NO_NT=1 switches it off
-    // FUSE: the 1x1 conv that FOLLOWS this launch's output (the next bottleneck's conv1, resnet.py:101-103) runs in this launch's
-    // epilogue on the tile's bf16 result while it is still in LDS: y2 = relu(f_w . y + f_bias), [M][f_cout]
+    // f_*: the conv3 that the EXPAND form of the 3x3 patch kernel runs behind its own conv (mt4_conv_desc.fuse_expand)
     // DUAL: a second K source behind the first (a 1x1 conv, stride 1): the block input x2 [B][H2][W2][C2] gathered at stride x2_s (the
     // downsample branch of a strided Bottleneck, resnet.py:116-119): y = act([W | W2] . [x ; x2(s*ho, s*wo)] + bias) in ONE accumulator chain
     const char* x2;
@@ -110,11 +109,9 @@ struct ConvK {
 // tile through its own operand stages and the partial tiles are added in LDS in the fixed order g = 0, 1, ... before the epilogue
 // (deterministic, independent of the batch).  For launches with few tiles and a long K (a TCN layer over one short video: 128 workgroups,
 // 48 K-steps) the K loop -- one barrier and one DMA round trip per step -- is the launch's critical path; this cuts it KS-fold.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool FAST, bool OUT_F32, int KS = 1, bool FUSE = false, bool DUAL = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool FAST, bool OUT_F32, int KS = 1, bool DUAL = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel(const ConvK a) {
-    static_assert(!DUAL || (FAST && sizeof(T) == 2 && KS == 1 && !FUSE), "the second K source exists on the bf16 LDS-DMA path");
-    static_assert(!FUSE || (sizeof(T) == 2 && !OUT_F32 && KS == 1 && BN == 256 && BM == 256 && WAVES_M * WAVES_N == 16),
-                  "the fused following 1x1 conv exists for the bf16 256x256 tile of 16 waves");
+    static_assert(!DUAL || (FAST && sizeof(T) == 2 && KS == 1), "the second K source exists on the bf16 LDS-DMA path");
     constexpr int ES = (int)sizeof(T);
     constexpr int ROWS = BM + BN;
     constexpr int NWG = WAVES_M * WAVES_N;  // waves of one group
@@ -579,48 +576,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel
                     const u32x4 ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
                     if (a.nt_epi) __builtin_nontemporal_store(ov, (u32x4*)(a.y + o * 2));
                     else *(uint4*)(a.y + o * 2) = make_uint4(ov.x, ov.y, ov.z, ov.w);
-                    if constexpr (FUSE) {
-                        // the same 8 bf16 values as the B operand of the following conv: K-step rc / 8 (64 channels = 128 bytes), chunk rc % 8,
-                        // XOR-swizzled like the operand stages
-                        char* yb = smem + BMP * ROWB;
-                        *(uint4*)(yb + (rc >> 3) * (BMP * 128) + lrow * 128 + (((rc & 7) ^ (lrow & 7)) << 4)) = make_uint4(ov.x, ov.y, ov.z, ov.w);
-                    }
-                }
-            }
-            if constexpr (FUSE) {
-                // ---- the following 1x1 conv on this pass's 64 pixels: D2[n2][pixel] = sum_c f_w[n2][c] * y[pixel][c], c over the 256 channels
-                // = 4 K-steps.  16 waves = 4 pixel tiles x 4 channel-tile groups; a wave's channel tiles are ntg, ntg + 4, ...  The K order
-                // (K-step ascending, kk 0 then 1) and the bias-initialised accumulator are those of the stand-alone launch: bit-identical.
-                __syncthreads();
-                const char* yb = smem + BMP * ROWB;
-                const int mt2 = wave & 3, ntg = wave >> 2;
-                const int prow = mt2 * 16 + r16;                                   // pixel row of this pass (lrow)
-                const int m2 = m0 + mt2 * WM + p * WMP + r16;                      // its tile row: (lrow / WMP) * WM + p * WMP + lrow % WMP
-                for (int nt = ntg; nt * 16 < a.f_cout; nt += 4) {
-                    const int n2 = nt * 16 + q * 4;
-                    f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (a.f_bias && n2 < a.f_cout) { const float4 t4 = *(const float4*)(a.f_bias + n2); acc2 = (f32x4){t4.x, t4.y, t4.z, t4.w}; }
-                    const char* wr = a.f_w + (long long)min(nt * 16 + r16, a.f_cout - 1) * a.f_w_row_bytes + q * 16;
-                    uint4 fwv[8];
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) fwv[ks * 2 + kk] = *(const uint4*)(wr + ks * 128 + kk * 64);
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) {
-                            const uint4 fxv = *(const uint4*)(yb + ks * (BMP * 128) + prow * 128 + (((kk * 4 + q) ^ (prow & 7)) << 4));
-                            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fwv[ks * 2 + kk]), __builtin_bit_cast(bf16x8_t, fxv),
-                                                                           acc2, 0, 0, 0);
-                        }
-                    if (m2 < a.M && n2 < a.f_cout) {
-                        if (a.f_relu) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc2[e] = fmaxf(acc2[e], 0.f);
-                        }
-                        *(uint2*)(a.f_y + ((long long)m2 * a.f_cout + n2) * 2) = make_uint2(pack_bf16x2(acc2[0], acc2[1]), pack_bf16x2(acc2[2], acc2[3]));
-                    }
                 }
             }
         }
@@ -1433,21 +1388,6 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     }
 }
 
-// tile 17 (bf16 256 x 256, 16 waves) with the following 1x1 conv fused into its epilogue (ConvK::f_w)
-int launch_fused_next1x1(const ConvK& k, hipStream_t s) {
-    constexpr int BM = 256, BN = 256, stage = (BM + BN) * 128;
-    ConvK kk = k;
-    kk.n_tiles = 1;
-    kk.total_tiles = cdiv(k.M, BM);
-    kk.nt_epi = 0;                        // the output is re-read at once (residual of the next block): keep it cacheable
-    constexpr int ybuf_end = 64 * (BN * 4 + 16) + 4 * 64 * 128;   // epilogue staging of one pass + the bf16 tile of the pass
-    const int lds = (k.nsteps > 1 ? 2 * stage : stage) > ybuf_end ? (k.nsteps > 1 ? 2 * stage : stage) : ybuf_end;
-    auto fn = igemm_conv_kernel<u16, BM, BN, 4, 4, 2, true, false, 1, true>;
-    MT4_RAISE_LDS(fn);
-    hipLaunchKernelGGL(fn, dim3(kk.total_tiles), dim3(1024), lds, s, kk);
-    return mt4_check_launch();
-}
-
 // tile 17 (bf16 256 x 256, 16 waves) with the second K source (ConvK::x2)
 int launch_dual(const ConvK& k, hipStream_t s) {
     constexpr int BM = 256, BN = 256, stage = (BM + BN) * 128;
@@ -1456,7 +1396,7 @@ int launch_dual(const ConvK& k, hipStream_t s) {
     kk.total_tiles = cdiv(k.M, BM) * kk.n_tiles;
     kk.nt_epi = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
     if ((long long)k.M * k.Cout * 2 < (long long)MT4_ENV_INT("MT4_NT_MIN_MB", 200) * 1000000LL) kk.nt_epi = 0;
-    auto fn = igemm_conv_kernel<u16, BM, BN, 4, 4, 2, true, false, 1, false, true>;
+    auto fn = igemm_conv_kernel<u16, BM, BN, 4, 4, 2, true, false, 1, true>;
     MT4_RAISE_LDS(fn);
     hipLaunchKernelGGL(fn, dim3(kk.total_tiles), dim3(1024), 2 * stage, s, kk);
     return mt4_check_launch();
@@ -1726,17 +1666,7 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
         k.f_w = (const char*)d->fuse_w; k.f_bias = d->fuse_bias; k.f_y = (char*)d->fuse_y; k.f_cout = d->fuse_cout; k.f_relu = d->fuse_relu ? 1 : 0;
         return d->W <= 31 ? launch_patch3x3<128, 128, 2, 2, 2, true>(k, (hipStream_t)stream) : launch_patch3x3<256, 128, 4, 2, 2, true>(k, (hipStream_t)stream);
     }
-    if (d->fuse_w) {
-        // the following 1x1 conv rides in this launch's epilogue: the whole channel width must sit in ONE 256-wide tile
-        if (!d->fuse_y || d->fuse_cout <= 0 || (d->fuse_cout % 16) != 0 || d->fuse_cout > 256) return MT4_EINVAL;
-        if (!(fast && d->dtype == MT4_BF16 && d->out_dtype == MT4_BF16 && d->Cout == 256 && !d->out_row_map && k.y_ld == d->Cout &&
-              d->relu <= 1 && d->tile == 0))
-            return MT4_EUNSUPPORTED;
-        if (((uintptr_t)d->fuse_w | (uintptr_t)d->fuse_y | (uintptr_t)d->fuse_bias) & 15) return MT4_EALIGN;
-        k.f_w = (const char*)d->fuse_w; k.f_bias = d->fuse_bias; k.f_y = (char*)d->fuse_y; k.f_cout = d->fuse_cout; k.f_relu = d->fuse_relu ? 1 : 0;
-        k.f_w_row_bytes = d->Cout * 2;     // packed [fuse_cout][Cout] bf16: 256 channels = 4 K-steps of 128 bytes, no padding
-        return launch_fused_next1x1(k, (hipStream_t)stream);
-    }
+    if (d->fuse_w) return MT4_EUNSUPPORTED;   // (fuse_w exists with fuse_expand only; two dependent 1x1 convs in one launch: mt4_chain_gemm_bf16)
     if (d->x2) {
         // second K source: y = act([W | W2] . [x ; x2 gathered at stride x2_stride] + bias); w rows hold both K ranges back to back
         if (d->x2_H <= 0 || d->x2_W <= 0 || d->x2_C <= 0 || d->x2_stride <= 0) return MT4_EINVAL;

@@ -97,10 +97,8 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
               residual: Optional[torch.Tensor] = None, relu: bool = False, out_dtype: Optional[torch.dtype] = None,
               out: Optional[torch.Tensor] = None, tile: int = 0, act: Optional[str] = None,
               out_row_map: Optional[torch.Tensor] = None, y_ld: int = 0, res_ld: int = 0, out_hw: Optional[Tuple[int, int]] = None,
-              out_rows_per_image: int = 0, run_pixels: int = 1, fuse_next=None, second=None):
+              out_rows_per_image: int = 0, run_pixels: int = 1, second=None):
     """y = act(conv(x, w) + bias [+ residual]); x [B,H,W,Cin] contiguous channels-last storage.
-    fuse_next = (w2_packed [C2][Cout], bias2 [C2], relu2): the following 1x1 conv runs in this launch's epilogue (bf16, Cout == 256);
-    returns (y, y2) then, y2 [B,Ho,Wo,C2] = act2(conv1x1(y, w2) + bias2), bit-identical to the stand-alone launch.
     second = (x2 [B,H2,W2,C2], stride): a second K source behind x, gathered at x2[b, s*ho, s*wo] -- conv3 + the downsample branch of a strided
     Bottleneck in one accumulator chain; `w_packed` = torch.cat([w3_packed, wds_packed], 1), `bias` = b3 + bds (bf16 1x1 launches).
     run_pixels > 1: a tap reads a contiguous run of that many pixels (Cin_eff = run_pixels * x.shape[-1]; kw must be 1, no padding,
@@ -130,7 +128,7 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
     res_f32 = 0
     if residual is not None:
         if residual.dtype == torch.float32 and x.dtype == torch.bfloat16:      # mixed-precision training GEMM: bf16 operands, fp32 output + residual
-            assert od == torch.float32 and fuse_next is None
+            assert od == torch.float32
             res_f32 = 1
         else:
             assert residual.dtype == x.dtype
@@ -154,25 +152,14 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
         assert (b * ho * wo) % out_row_map.numel() == 0
     if tile == 0 and _LATENCY_TILES.get():
         tile = -1
-    y2 = None
-    f_w = f_b = f_y = None
-    f_cout = f_relu = 0
-    if fuse_next is not None:
-        w2, b2, relu2 = fuse_next
-        _need_cuda(w2, b2)
-        assert x.dtype == torch.bfloat16 and od == torch.bfloat16 and w2.dtype == torch.bfloat16 and tuple(w2.shape) == (w2.shape[0], cout)
-        assert b2 is None or (b2.dtype == torch.float32 and b2.numel() == w2.shape[0])
-        y2 = torch.empty((b, ho, wo, w2.shape[0]), dtype=torch.bfloat16, device=x.device)
-        f_w, f_b, f_y, f_cout, f_relu = w2.data_ptr(), (b2.data_ptr() if b2 is not None else None), y2.data_ptr(), w2.shape[0], 1 if relu2 else 0
-        tile = 0
     d = ConvDesc(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
                  residual.data_ptr() if residual is not None else None, out.data_ptr(),
                  out_row_map.data_ptr() if out_row_map is not None else None,
                  b, h, w_, cin, ho, wo, cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1],
                  act_code, dt_code(x.dtype), dt_code(od), tile, out_row_map.numel() if out_row_map is not None else 0, y_ld, res_ld,
-                 out_rows_per_image, pix, f_cout, f_w, f_b, f_y, f_relu, res_f32, x2p, x2h, x2w, x2c, x2s, 0)
+                 out_rows_per_image, pix, 0, None, None, None, 0, res_f32, x2p, x2h, x2w, x2c, x2s, 0)
     check(lib.mt4_conv_nhwc(C.byref(d), _stream()), "mt4_conv_nhwc")
-    return out if fuse_next is None else (out, y2)
+    return out
 
 
 def pack_fragments(w_packed: torch.Tensor) -> torch.Tensor:

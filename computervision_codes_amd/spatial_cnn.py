@@ -39,12 +39,6 @@ class VideoNas:
         self._sd: Dict[str, torch.Tensor] = {}
         self._p: Dict[str, object] = {}
         self._streams = []
-        # conv3 + the next block's conv1 in one launch (`mt4_conv_desc.fuse_w`): bit-identical, but MEASURED SLOWER -- 19.2 -> 22.0 ms per 1336
-        # frames at 224x224, same-box A/B (tools/fuse_ab.py): the fused epilogue needs the whole 256-channel vector of a pixel in one tile,
-        # i.e. the 16-wave 256 x 256 tile at one workgroup per CU, and on these K = 64 HBM-bound layers its serial phases (operands -> MFMA ->
-        # 4 x [residual, staging, store, second GEMM]) leave nothing to overlap with; the saved re-read (1.6 MB per frame and pair) does
-        # not pay for that.  Off by default; kept for the A/B and as the starting point of a smaller-tile variant.
-        self.fuse_next_conv = False
         import os
         self.fuse_stem_pool = not os.environ.get("MT4_NO_STEM_POOL_FUSE")   # stem conv + max-pool in one launch (bf16 uint8-frame path)
         self.fuse_expand = not os.environ.get("MT4_NO_EXPAND_FUSE")   # layer2's stride-1 blocks: conv2 + conv3 in one launch (large batches)
@@ -202,7 +196,7 @@ class VideoNas:
                     pending = None
                     nq = f"{pre}layer{li}.{bi + 1}." if bi + 1 < n else (f"{pre}layer{li + 1}.0." if li < last else None)
                     if (li in self.chain_layers and nq is not None and o_buf is None and self.dtype == torch.bfloat16 and (q + "conv3frag") in self._p
-                            and (nq + "conv1frag") in self._p and not self.fuse_next_conv
+                            and (nq + "conv1frag") in self._p
                             and ops.chain_gemm_supported(self._p[q + "conv3frag"].shape[1], self._p[q + "conv3frag"].shape[0], self._p[nq + "conv1frag"].shape[0], True)):
                         # conv2, then conv3 + add + ReLU and the NEXT block's conv1 + ReLU in one launch: this block's output map is written once
                         # (the next block's residual) and never read back
@@ -212,7 +206,7 @@ class VideoNas:
                                                 self._p[nq + "conv1"][1], r1=idt)
                         x, pending = y1.view(bb, hh, ww, -1), t1.view(bb, hh, ww, -1)
                         continue
-                    if (q + "conv3frag") in self._p and li == 2 and self.fuse_expand and not self.fuse_next_conv:
+                    if (q + "conv3frag") in self._p and li == 2 and self.fuse_expand:
                         # conv2 and conv3 (+ residual) of a layer2 identity block in one launch: the 128-channel map stays in LDS (bit-identical;
                         # None where the patch kernel does not run -- small batches)
                         (w2, b2), b3 = self._p[q + "conv2"], self._p[q + "conv3"][1]
@@ -221,17 +215,7 @@ class VideoNas:
                             x = y
                             continue
                     o = self._conv(o, q + "conv2", 3, stride=s, pad=1)
-                    # the next Bottleneck's conv1 (a 1x1 conv on this block's output at the same resolution) rides in this conv3's epilogue
-                    # while the 256-channel tile is still in LDS: the map is written once (next residual) and not read back (bf16 only;
-                    # 256 output channels = layer1: its three blocks hand over to blocks 1, 2 and to layer2.0)
-                    nq = f"{pre}layer{li}.{bi + 1}." if bi + 1 < n else (f"{pre}layer{li + 1}.0." if li < last else None)
-                    w3, b3 = self._p[q + "conv3"]
-                    if (self.fuse_next_conv and nq is not None and o_buf is None and self.dtype == torch.bfloat16 and w3.shape[0] == 256
-                            and o.shape[0] * o.shape[1] * o.shape[2] >= 256):
-                        w1n, b1n = self._p[nq + "conv1"]
-                        x, pending = ops.conv_nhwc(o, w3, b3, kh=1, kw=1, residual=idt, relu=True, fuse_next=(w1n, b1n, True))
-                    else:
-                        x = self._conv(o, q + "conv3", 1, residual=idt, out=o_buf)
+                    x = self._conv(o, q + "conv3", 1, residual=idt, out=o_buf)
                 else:           # resnet.py:35-72
                     o = self._conv(x, q + "conv1", 3, stride=s, pad=1)
                     x = self._conv(o, q + "conv2", 3, pad=1, residual=idt, out=o_buf)

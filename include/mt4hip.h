@@ -86,14 +86,11 @@ typedef struct mt4_conv_desc {
     int32_t x_pixel_stride;     /* elements between neighbouring pixels of x (0 = Cin).  < Cin: the Cin elements of a tap are a
                                    contiguous run over several pixels of a narrower image (KW = 1, no padding; the caller pads x so
                                    that every run stays inside it): the ResNet stem on the space-to-depth frame, 4 x 16 channels */
-    int32_t fuse_cout;          /* with fuse_w: output channels of the fused following 1x1 conv (multiple of 16, <= 256) */
-    /* Optional: the 1x1 conv that FOLLOWS this launch's output -- the next Bottleneck's conv1 + bn1 + ReLU (resnet.py:101-103) after this
-       block's conv3 + bn3 + add + ReLU (:112-119) -- run in this launch's epilogue on the tile's bf16 result while it is still in LDS:
-           y2[m][0..fuse_cout) = act2( fuse_w . y[m][0..Cout) + fuse_bias )
-       so the Cout-wide map is written once (it is the next block's residual) and not read back by a second launch.  bf16 in / out,
-       Cout == 256 (one 256-wide tile holds a pixel's whole channel vector), dense y, no out_row_map, tile 0; MT4_EUNSUPPORTED otherwise.
-       y2 is bit-identical to the stand-alone launch on y (same K order, bias-initialised fp32 accumulator, one rounding). */
-    const void* fuse_w;         /* [fuse_cout][Cout] bf16 packed by mt4_pack_conv_weight (1x1) or NULL */
+    int32_t fuse_cout;          /* with fuse_expand: output channels of the conv3 run behind this launch's own conv (a multiple of 128) */
+    /* fuse_w / fuse_bias / fuse_y / fuse_relu: operands of `fuse_expand` (below).  Round 2's other use -- the next Bottleneck's conv1 in the
+       epilogue of a 256-channel conv3 (fuse_w without fuse_expand) -- measured slower than the two launches and is gone: that request returns
+       MT4_EUNSUPPORTED; two dependent 1x1 convs in one launch are mt4_chain_gemm_bf16. */
+    const void* fuse_w;         /* conv3's weights in fragment order (mt4_pack_fragments_bf16) or NULL */
     const float* fuse_bias;     /* [fuse_cout] or NULL */
     void* fuse_y;               /* [B][Ho][Wo][fuse_cout] bf16 */
     int32_t fuse_relu;          /* 0 / 1 */
@@ -114,7 +111,7 @@ typedef struct mt4_conv_desc {
                                    (y is not written), `residual` ([B][H][W][fuse_cout], the block input) is added to y2 = fuse_y before fuse_relu,
                                    fuse_cout is a multiple of 128 and fuse_w is in fragment order (mt4_pack_fragments_bf16 of the packed
                                    [fuse_cout][128] matrix).  Runs where the 3x3 patch kernel runs (>= 256 tiles of 256 x 256): MT4_EUNSUPPORTED
-                                   otherwise -- launch the two convs then; the results are bit-identical either way.  0 = fuse_w as described above */
+                                   otherwise -- launch the two convs then; the results are bit-identical either way */
 } mt4_conv_desc;
 
 int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream);

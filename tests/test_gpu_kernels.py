@@ -252,25 +252,6 @@ def test_maxpool_avgpool_linear(cuda, dtype):
     assert (y - F.linear(f, w, b)).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("c2,relu2,res", [(64, True, True), (128, True, True), (64, False, False)])
-def test_conv_fused_following_1x1_is_bit_identical(cuda, c2, relu2, res):
-    """`mt4_conv_desc.fuse_w`: the next bottleneck's conv1 run in the epilogue of conv3 (+bn3 + add + ReLU) equals, bit for bit, the two
-    stand-alone launches; ragged pixel count (the last 256-pixel tile is partial), K of one step (layer1: 64 channels) and of several"""
-    from computervision_codes_amd import ops
-    g = torch.Generator().manual_seed(31)
-    for cin, b, h, w in ((64, 3, 21, 19), (128, 2, 17, 9)):
-        x = torch.randn(b, h, w, cin, generator=g).to(torch.bfloat16).to(cuda)
-        w3 = ops.pack_conv_weight((torch.randn(256, cin, 1, 1, generator=g) / cin ** 0.5).to(cuda), None, torch.bfloat16)
-        b3 = torch.randn(256, generator=g).to(cuda)
-        r = torch.randn(b, h, w, 256, generator=g).to(torch.bfloat16).to(cuda) if res else None
-        w1 = ops.pack_conv_weight((torch.randn(c2, 256, 1, 1, generator=g) / 16).to(cuda), None, torch.bfloat16)
-        b1 = torch.randn(c2, generator=g).to(cuda)
-        y = ops.conv_nhwc(x, w3, b3, kh=1, kw=1, residual=r, relu=True)
-        t = ops.conv_nhwc(y, w1, b1, kh=1, kw=1, relu=relu2)
-        yf, tf = ops.conv_nhwc(x, w3, b3, kh=1, kw=1, residual=r, relu=True, fuse_next=(w1, b1, relu2))
-        assert torch.equal(yf, y) and torch.equal(tf, t), (cin, (yf.float() - y.float()).abs().max().item(), (tf.float() - t.float()).abs().max().item())
-
-
 @pytest.mark.parametrize("b,h,w", [(3, 56, 56), (2, 16, 24), (1, 9, 15), (2, 8, 14), (1, 1, 1)])
 @pytest.mark.parametrize("ds", [False, True])
 def test_bottleneck_fused_bit_identical_to_three_launches(cuda, b, h, w, ds):

@@ -195,21 +195,6 @@ def test_bf16_argmax_top5_agreement(cuda):
         assert am >= 0.99 and t5 >= 0.98, (gi, am, t5)
 
 
-def test_spatial_cnn_fused_conv3_conv1_is_bit_identical(cuda):
-    """ResNet-50 bf16: layer1's conv3 launches carry the next block's conv1 in their epilogue (`mt4_conv_desc.fuse_w`); features and logits
-    equal the one-launch-per-conv path bit for bit, at 224x224 and at the reference's 256x448"""
-    _, cfg = load_golden("cnn_resnet50_224")
-    m = _cnn_model(cfg, torch.bfloat16)
-    for (n, h, w) in ((5, 224, 224), (3, 256, 448), (2, 64, 96)):
-        frames = synth.synthetic_frames(n, h, w, seed=13).to(cuda)
-        m.fuse_bottleneck = False                         # (this fusion acts on the one-launch-per-conv layer1)
-        m.fuse_next_conv = True
-        a = m.extract_u8(frames)
-        m.fuse_next_conv = False
-        b = m.extract_u8(frames)
-        assert torch.equal(a[3][0], b[3][0]) and all(torch.equal(a[i][1], b[i][1]) for i in range(4)), (n, h, w)
-
-
 def test_spatial_cnn_fused_layer1_bottlenecks_are_bit_identical(cuda):
     """ResNet-50 bf16 (the default path): every layer1 Bottleneck is ONE launch (`mt4_bottleneck_fused_bf16`: conv1 + conv2 + conv3 (+ downsample),
     intermediates in LDS); features and logits equal the one-launch-per-conv path bit for bit at 224x224, the reference's 256x448 and a small

@@ -287,7 +287,7 @@ def test_mstct_run_t_e_under_torchrun_two_ranks_writes_each_file_once(cuda, tmp_
     vids = _make_dataset(data, n_frames=20, h=8, w=8)
     rng = np.random.default_rng(4)
     D = 64
-    lens = {v[-2:]: 12 + 3 * i for i, v in enumerate(vids)}              # ragged lengths: the greedy sharding gives the ranks different videos
+    lens = {v[-2:]: 13 + (i % 7) for i, v in enumerate(vids)}            # ragged lengths (> the 12-frame window, <= the 20 labelled frames): the greedy sharding gives the ranks different videos
     featfile.write_feats(str(tree / "0-5fold" / "data_feats" / "run_X" / "k1_v_feats.pkl"), {k: rng.standard_normal((n, D)).astype(np.float32) for k, n in lens.items()})
     flags = ["--loss_type", "v", "--input_dim", str(D), "--epochs", "1", "--batch", "31", "-l", "1e-2", "5e-3", "1e-2", "-w", "9", "18", "500",
              "--decay_rate", "0.999", "--version", "X_MSTCT", "--version1", "X", "--data_dir", data, "--kfold", "1", "--num_clips", "12"]
