@@ -299,7 +299,7 @@ class VideoNas:
                         and ops.chain_gemm_supported(planes[li - 1], 4 * planes[li - 1], nplanes, True)):
                     groups += [[idx[q + "conv2"]], [idx[q + "conv3"], idx[nq + "conv1"]]]
                     pending = True
-                elif li == 2 and not has_ds and self.fuse_expand and not self.fuse_next_conv:
+                elif li == 2 and not has_ds and self.fuse_expand:
                     groups.append([idx[q + "conv2"], idx[q + "conv3"]])
                 else:
                     groups += [[idx[q + "conv2"]], [idx[q + "conv3"]]]
