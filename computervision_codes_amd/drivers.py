@@ -327,7 +327,10 @@ def _tenco_train(F):
     model_dir = f"./__checkpoint__/run_{F.version}"
     logfile = os.path.join(model_dir, modelname + ".log")
     if not F.fpn:
-        raise NotImplementedError("training is built for the shipped recipe (--fpn, Scripts/train_fold1.sh:28)")
+        # the reference's own train loop cannot run a model without --fpn: `out_list_i / _v / _t` stay empty (`network.py:56-66`), so `loss_i`,
+        # `loss_v`, `loss_t` stay the int 0 they start as (`run.py:190`) and `loss_i.item()` raises AttributeError at `run.py:214` in the first step
+        raise NotImplementedError("Temporal_tenco training needs --fpn (Scripts/train_fold1.sh:28): without it the reference's train loop itself fails "
+                                  "in its first step (run.py:190,214: .item() on the int 0 that loss_i stays when the model returns no per-component logits)")
     tr = TencoTrainer(F.num_layers_PG, F.num_layers_R, F.num_R, 512, F.input_dim, lr=F.initial_learning_rates[2], weight_decay=F.weight_decay)
     from . import shapes, synth
     init = os.path.join(model_dir, modelname + "_latest.pth")

@@ -42,7 +42,9 @@ class VideoNas:
         assert path in ("auto", "tcn", "igemm")
         self.path = path
         if getattr(args, "output", False) or getattr(args, "hier", False):
-            raise NotImplementedError("--output / --hier are never set by the shipped scripts (Scripts/*.sh)")
+            raise NotImplementedError("--output / --hier are never set by the shipped scripts (Scripts/*.sh).  --output cannot run in the reference at "
+                                      "the shipped widths (Refinement.conv_1x1 takes num_classes channels, network.py:141, and is handed the "
+                                      "num_f_maps-channel feature, :58,150-151); --hier (AvgPool1d(7,3) between stages, :154-155) is not built")
         self.args = args
         self.use_fpn = bool(getattr(args, "fpn", False))
         self.num_layers_PG, self.num_layers_R, self.num_R = num_layers_PG, num_layers_R, num_R
