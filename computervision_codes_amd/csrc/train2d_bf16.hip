@@ -22,12 +22,22 @@ template <> __device__ __forceinline__ void st4<float>(float* p, float4 v) { *(f
 template <> __device__ __forceinline__ void st4<u16>(u16* p, float4 v) { *(uint2*)p = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm2d (training), typed tensors
-// same arithmetic and work split as train2d_kernels.hip: float64 per-channel reductions, a thread owns 4 consecutive channels
+// same arithmetic as train2d_kernels.hip: float64 per-channel reductions, a thread owns 4 consecutive channels.  The reductions run 1024-thread
+// blocks (64 channels x 64 row phases) and at most ~512 of them: every block ends in 128 fp64 atomics on its slab's 128 addresses, and with 2048
+// blocks of 256 threads on a 64-channel tensor those 2048-deep same-address chains (~25 ns a link at the L2) took longer than the stream --
+// 52-58 us for 59 MB where the apply kernel moves twice the bytes in 20-29 us (profiles/r03_bn_training_kernels.txt)
 __device__ __forceinline__ void bn_block_reduce(double (&acc)[8], double* __restrict__ sums, int C, int c0) {
     __shared__ double red[16][8][17];
-    const int cg = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[r][j][cg] = acc[j];
+    for (int j = 0; j < 8; ++j) {                                            // the 4 row phases of a wave
+        acc[j] += __shfl_xor(acc[j], 16);
+        acc[j] += __shfl_xor(acc[j], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[w][j][lane] = acc[j];
+    }
     __syncthreads();
     if (threadIdx.x < 128) {
         const int g = threadIdx.x & 15, j = threadIdx.x >> 4;
@@ -40,16 +50,33 @@ __device__ __forceinline__ void bn_block_reduce(double (&acc)[8], double* __rest
 }
 
 template <typename TZ>
-__global__ __launch_bounds__(256) void bn_stats_t_kernel(const TZ* __restrict__ x, double* __restrict__ sums, long long M, int C) {
+__global__ __launch_bounds__(1024) void bn_stats_t_kernel(const TZ* __restrict__ x, double* __restrict__ sums, long long M, int C) {
     const int c0 = blockIdx.x * 64, c = c0 + (threadIdx.x & 15) * 4;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (c < C)
-        for (long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4); m < M; m += (long long)gridDim.y * 16) {
-            const float4 v = ld4<TZ>(x + m * C + c);
+    if (c < C) {
+        // 4 rows in flight per thread: with one 8-byte load outstanding per lane the 32 waves of a CU hold 16 KB in flight, a latency bound of
+        // ~2.6 TB/s (measured); rows are still added in ascending order, so the sums keep their bits
+        const long long st = (long long)gridDim.y * 64;
+        long long m = (long long)blockIdx.y * 64 + (threadIdx.x >> 4);
+        auto add = [&](const float4 v) {
             acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
             acc[4] += (double)v.x * v.x; acc[5] += (double)v.y * v.y; acc[6] += (double)v.z * v.z; acc[7] += (double)v.w * v.w;
+        };
+        for (; m + 3 * st < M; m += 4 * st) {
+            const float4 v0 = ld4<TZ>(x + m * C + c), v1 = ld4<TZ>(x + (m + st) * C + c), v2 = ld4<TZ>(x + (m + 2 * st) * C + c),
+                         v3 = ld4<TZ>(x + (m + 3 * st) * C + c);
+            add(v0); add(v1); add(v2); add(v3);
         }
+        for (; m < M; m += st) add(ld4<TZ>(x + m * C + c));
+    }
     bn_block_reduce(acc, sums, C, c0);
+}
+
+int bn_reduce_slabs(long long M, int C) {                                      // 64-row slabs of the 1024-thread reductions
+    long long gy = (M + 63) / 64;
+    const long long cap = (512 + cdiv(C, 64) - 1) / cdiv(C, 64);
+    if (gy > cap) gy = cap;
+    return gy < 1 ? 1 : (int)gy;
 }
 
 int bn_row_slabs(long long M, int C) {
@@ -74,27 +101,44 @@ __global__ void bn_finalize_t_kernel(const double* __restrict__ sums, float* __r
     }
 }
 
-// y (bf16) = act( (x - mean) * invstd * gamma + beta [+ residual (bf16)] )
+// y (bf16) = act( (x - mean) * invstd * gamma + beta [+ residual (bf16)] ).  Column slabs like the reductions: a thread owns 4 consecutive
+// channels and walks rows, its per-channel parameters in registers -- one element group per thread re-loaded 64 bytes of parameters for every
+// 16 bytes of tensor traffic and ran at 3.8-4.1 TB/s where the bare stream measures 5-6 (tools/bn_stream_micro.hip).  Same expressions: same bits.
 template <typename TZ>
-__global__ void bn_apply_t_kernel(const TZ* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                  const float* __restrict__ beta, const u16* __restrict__ res, u16* __restrict__ y, long long n4, int C, int relu) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    const int c = (int)((i * 4) % C);
-    const float4 xv = ld4<TZ>(x + i * 4);
+__global__ __launch_bounds__(256) void bn_apply_t_kernel(const TZ* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, const u16* __restrict__ res,
+                                                         u16* __restrict__ y, long long M, int C, int relu) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
+    if (c >= C) return;
     const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c), g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
-    float4 o = make_float4((xv.x - mu.x) * is.x * g.x + b.x, (xv.y - mu.y) * is.y * g.y + b.y, (xv.z - mu.z) * is.z * g.z + b.z,
-                           (xv.w - mu.w) * is.w * g.w + b.w);
-    if (res) { const float4 r = ld4<u16>(res + i * 4); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
-    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    st4<u16>(y + i * 4, o);
+    const long long st = (long long)gridDim.y * 16;
+    long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto put = [&](long long i, const float4 xv, const float4 r) {
+        float4 o = make_float4((xv.x - mu.x) * is.x * g.x + b.x, (xv.y - mu.y) * is.y * g.y + b.y, (xv.z - mu.z) * is.z * g.z + b.z,
+                               (xv.w - mu.w) * is.w * g.w + b.w);
+        if (res) { o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        st4<u16>(y + i, o);
+    };
+    for (; m + 3 * st < M; m += 4 * st) {
+        const long long i0 = m * C + c, i1 = (m + st) * C + c, i2 = (m + 2 * st) * C + c, i3 = (m + 3 * st) * C + c;
+        const float4 x0 = ld4<TZ>(x + i0), x1 = ld4<TZ>(x + i1), x2 = ld4<TZ>(x + i2), x3 = ld4<TZ>(x + i3);
+        float4 r0 = zero, r1 = zero, r2 = zero, r3 = zero;
+        if (res) { r0 = ld4<u16>(res + i0); r1 = ld4<u16>(res + i1); r2 = ld4<u16>(res + i2); r3 = ld4<u16>(res + i3); }
+        put(i0, x0, r0); put(i1, x1, r1); put(i2, x2, r2); put(i3, x3, r3);
+    }
+    for (; m < M; m += st) {
+        const long long i0 = m * C + c;
+        put(i0, ld4<TZ>(x + i0), res ? ld4<u16>(res + i0) : zero);
+    }
 }
 
 // relu: 0 none; 1 the ReLU gate is read from the stored output y; 2 it is recomputed from x -- (x - mean) * invstd * gamma + beta > 0, the
 // forward's own fp32 expression -- for units without a residual input: y need not be read (2 of the 6 / 8 bytes per element these HBM-bound
 // kernels move)
 template <typename TZ>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_t_kernel(const u16* __restrict__ dy, const u16* __restrict__ y, const TZ* __restrict__ x,
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_t_kernel(const u16* __restrict__ dy, const u16* __restrict__ y, const TZ* __restrict__ x,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, double* __restrict__ sums,
                                                               long long M, int C, int relu) {
@@ -104,16 +148,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_t_kernel(const u16* __restr
         const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
         float4 ga = make_float4(0, 0, 0, 0), be = ga;
         if (relu == 2) { ga = *(const float4*)(gamma + c); be = *(const float4*)(beta + c); }
-        for (long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4); m < M; m += (long long)gridDim.y * 16) {
-            float4 g = ld4<u16>(dy + m * C + c);
-            const float4 xv = ld4<TZ>(x + m * C + c);
+        const long long st = (long long)gridDim.y * 64;
+        long long m = (long long)blockIdx.y * 64 + (threadIdx.x >> 4);
+        auto add = [&](float4 g, const float4 xv, const float4 yv) {
             if (relu == 2) {
                 if (!((xv.x - mu.x) * is.x * ga.x + be.x > 0.f)) g.x = 0.f;
                 if (!((xv.y - mu.y) * is.y * ga.y + be.y > 0.f)) g.y = 0.f;
                 if (!((xv.z - mu.z) * is.z * ga.z + be.z > 0.f)) g.z = 0.f;
                 if (!((xv.w - mu.w) * is.w * ga.w + be.w > 0.f)) g.w = 0.f;
             } else if (relu) {
-                const float4 yv = ld4<u16>(y + m * C + c);
                 if (!(yv.x > 0.f)) g.x = 0.f;
                 if (!(yv.y > 0.f)) g.y = 0.f;
                 if (!(yv.z > 0.f)) g.z = 0.f;
@@ -122,45 +165,83 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_t_kernel(const u16* __restr
             acc[0] += (double)g.x; acc[1] += (double)g.y; acc[2] += (double)g.z; acc[3] += (double)g.w;
             acc[4] += (double)g.x * (double)((xv.x - mu.x) * is.x); acc[5] += (double)g.y * (double)((xv.y - mu.y) * is.y);
             acc[6] += (double)g.z * (double)((xv.z - mu.z) * is.z); acc[7] += (double)g.w * (double)((xv.w - mu.w) * is.w);
+        };
+        const bool rd_y = relu == 1;
+        const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+        // 2 rows x up to 3 tensors in flight per thread (see bn_stats_t_kernel); rows are added in ascending order
+        for (; m + st < M; m += 2 * st) {
+            const long long i0 = m * C + c, i1 = (m + st) * C + c;
+            const float4 g0 = ld4<u16>(dy + i0), g1 = ld4<u16>(dy + i1);
+            const float4 x0 = ld4<TZ>(x + i0), x1 = ld4<TZ>(x + i1);
+            float4 y0 = one, y1 = one;
+            if (rd_y) { y0 = ld4<u16>(y + i0); y1 = ld4<u16>(y + i1); }
+            add(g0, x0, y0); add(g1, x1, y1);
+        }
+        for (; m < M; m += st) {
+            const long long i0 = m * C + c;
+            add(ld4<u16>(dy + i0), ld4<TZ>(x + i0), rd_y ? ld4<u16>(y + i0) : one);
         }
     }
     bn_block_reduce(acc, sums, C, c0);
 }
 
-// dx has the type of x (the convolution output: bf16, or fp32 for the stem); dres = the gated gradient, bf16
+// dx has the type of x (the convolution output: bf16, or fp32 for the stem); dres = the gated gradient, bf16.  Column slabs, parameters and the two
+// per-channel means of the reduction in registers (see bn_apply_t_kernel)
 template <typename TZ>
-__global__ void bn_bwd_apply_t_kernel(const u16* __restrict__ dy, const u16* __restrict__ y, const TZ* __restrict__ x, const float* __restrict__ mean,
-                                      const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                      const double* __restrict__ sums, TZ* __restrict__ dx, u16* __restrict__ dres, float* __restrict__ dgamma,
-                                      float* __restrict__ dbeta, long long M, int C, int relu) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < C) { dbeta[i] = (float)sums[i]; dgamma[i] = (float)sums[C + i]; }
-    if (i >= M * C / 4) return;
-    const int c = (int)((i * 4) % C);
-    float4 g = ld4<u16>(dy + i * 4);
-    if (relu == 2) {
-        const float4 xg = ld4<TZ>(x + i * 4), mg = *(const float4*)(mean + c), ig = *(const float4*)(invstd + c), gg = *(const float4*)(gamma + c),
-                     bg = *(const float4*)(beta + c);
-        if (!((xg.x - mg.x) * ig.x * gg.x + bg.x > 0.f)) g.x = 0.f;
-        if (!((xg.y - mg.y) * ig.y * gg.y + bg.y > 0.f)) g.y = 0.f;
-        if (!((xg.z - mg.z) * ig.z * gg.z + bg.z > 0.f)) g.z = 0.f;
-        if (!((xg.w - mg.w) * ig.w * gg.w + bg.w > 0.f)) g.w = 0.f;
-    } else if (relu) {
-        const float4 yv = ld4<u16>(y + i * 4);
-        if (!(yv.x > 0.f)) g.x = 0.f;
-        if (!(yv.y > 0.f)) g.y = 0.f;
-        if (!(yv.z > 0.f)) g.z = 0.f;
-        if (!(yv.w > 0.f)) g.w = 0.f;
-    }
-    const float4 xv = ld4<TZ>(x + i * 4), mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c), ga = *(const float4*)(gamma + c);
+__global__ __launch_bounds__(256) void bn_bwd_apply_t_kernel(const u16* __restrict__ dy, const u16* __restrict__ y, const TZ* __restrict__ x,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const double* __restrict__ sums, TZ* __restrict__ dx, u16* __restrict__ dres,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, long long M, int C, int relu) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
+    if (c >= C) return;
     const double invM = 1.0 / (double)M;
-    float4 o;
-    o.x = ga.x * is.x * (g.x - (float)(sums[c] * invM) - (xv.x - mu.x) * is.x * (float)(sums[C + c] * invM));
-    o.y = ga.y * is.y * (g.y - (float)(sums[c + 1] * invM) - (xv.y - mu.y) * is.y * (float)(sums[C + c + 1] * invM));
-    o.z = ga.z * is.z * (g.z - (float)(sums[c + 2] * invM) - (xv.z - mu.z) * is.z * (float)(sums[C + c + 2] * invM));
-    o.w = ga.w * is.w * (g.w - (float)(sums[c + 3] * invM) - (xv.w - mu.w) * is.w * (float)(sums[C + c + 3] * invM));
-    st4<TZ>(dx + i * 4, o);
-    if (dres) st4<u16>(dres + i * 4, g);
+    const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c), ga = *(const float4*)(gamma + c);
+    float4 bg = make_float4(0, 0, 0, 0);
+    if (relu == 2) bg = *(const float4*)(beta + c);
+    const float4 m1 = make_float4((float)(sums[c] * invM), (float)(sums[c + 1] * invM), (float)(sums[c + 2] * invM), (float)(sums[c + 3] * invM));
+    const float4 m2 = make_float4((float)(sums[C + c] * invM), (float)(sums[C + c + 1] * invM), (float)(sums[C + c + 2] * invM),
+                                  (float)(sums[C + c + 3] * invM));
+    if (blockIdx.y == 0 && (threadIdx.x >> 4) == 0) {
+        *(float4*)(dbeta + c) = make_float4((float)sums[c], (float)sums[c + 1], (float)sums[c + 2], (float)sums[c + 3]);
+        *(float4*)(dgamma + c) = make_float4((float)sums[C + c], (float)sums[C + c + 1], (float)sums[C + c + 2], (float)sums[C + c + 3]);
+    }
+    const long long st = (long long)gridDim.y * 16;
+    long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4);
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+    const bool rd_y = relu == 1;
+    auto put = [&](long long i, float4 g, const float4 xv, const float4 yv) {
+        if (relu == 2) {
+            if (!((xv.x - mu.x) * is.x * ga.x + bg.x > 0.f)) g.x = 0.f;
+            if (!((xv.y - mu.y) * is.y * ga.y + bg.y > 0.f)) g.y = 0.f;
+            if (!((xv.z - mu.z) * is.z * ga.z + bg.z > 0.f)) g.z = 0.f;
+            if (!((xv.w - mu.w) * is.w * ga.w + bg.w > 0.f)) g.w = 0.f;
+        } else if (relu) {
+            if (!(yv.x > 0.f)) g.x = 0.f;
+            if (!(yv.y > 0.f)) g.y = 0.f;
+            if (!(yv.z > 0.f)) g.z = 0.f;
+            if (!(yv.w > 0.f)) g.w = 0.f;
+        }
+        float4 o;
+        o.x = ga.x * is.x * (g.x - m1.x - (xv.x - mu.x) * is.x * m2.x);
+        o.y = ga.y * is.y * (g.y - m1.y - (xv.y - mu.y) * is.y * m2.y);
+        o.z = ga.z * is.z * (g.z - m1.z - (xv.z - mu.z) * is.z * m2.z);
+        o.w = ga.w * is.w * (g.w - m1.w - (xv.w - mu.w) * is.w * m2.w);
+        st4<TZ>(dx + i, o);
+        if (dres) st4<u16>(dres + i, g);
+    };
+    for (; m + st < M; m += 2 * st) {
+        const long long i0 = m * C + c, i1 = (m + st) * C + c;
+        const float4 g0 = ld4<u16>(dy + i0), g1 = ld4<u16>(dy + i1);
+        const float4 x0 = ld4<TZ>(x + i0), x1 = ld4<TZ>(x + i1);
+        float4 y0 = one, y1 = one;
+        if (rd_y) { y0 = ld4<u16>(y + i0); y1 = ld4<u16>(y + i1); }
+        put(i0, g0, x0, y0); put(i1, g1, x1, y1);
+    }
+    for (; m < M; m += st) {
+        const long long i0 = m * C + c;
+        put(i0, ld4<u16>(dy + i0), ld4<TZ>(x + i0), rd_y ? ld4<u16>(y + i0) : one);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ Conv2d weight gradient, bf16 operands
@@ -450,53 +531,129 @@ __global__ void repack_bf16_kernel(const float* __restrict__ src, u16* __restric
     dst[idx] = f32_to_bf16(v);
 }
 
+// The same gradient from a 16 x 16 input tile x 64 channels per workgroup: the 19 x 19 input pixels under the tile's 9 x 9 windows go to LDS once,
+// a window's winner (first maximum in scan order, the rule above) is found once per window instead of once per pixel under it -- 4 nibble
+// compares per pixel then replace the 32 neighbour loads and 256 compares of the per-pixel form, which ran at 0.87 ms for a 0.6 GB exchange
+// (ResNet-50, 64 x 256 x 448).  Gradients are added in the same (ho, wo) order: same bits.
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_bf16_tile_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, u16* __restrict__ dx, int H,
+                                                                        int W, int C, int Ho, int Wo) {
+    __shared__ uint4 xs[19 * 19][8];
+    __shared__ uint4 dys[81][8];
+    __shared__ unsigned win[81][8];
+    const int cslabs = C >> 6;
+    const int b = blockIdx.z / cslabs, cb = (blockIdx.z - b * cslabs) * 64;
+    const int h0 = blockIdx.y * 16, w0 = blockIdx.x * 16;
+    const uint4 ninf = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u), zero4 = make_uint4(0, 0, 0, 0);
+    for (int t = threadIdx.x; t < 19 * 19 * 8; t += 256) {
+        const int pix = t >> 3, g = t & 7, r = pix / 19, cc = pix - r * 19;
+        const int hh = h0 - 1 + r, ww = w0 - 1 + cc;
+        xs[pix][g] = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? *(const uint4*)(x + (((long long)b * H + hh) * W + ww) * C + cb + g * 8) : ninf;
+    }
+    for (int t = threadIdx.x; t < 81 * 8; t += 256) {
+        const int wi = t >> 3, g = t & 7, wr = wi / 9, wc = wi - wr * 9;
+        const int ho = (h0 >> 1) + wr, wo = (w0 >> 1) + wc;
+        dys[wi][g] = (ho < Ho && wo < Wo) ? *(const uint4*)(dy + (((long long)b * Ho + ho) * Wo + wo) * C + cb + g * 8) : zero4;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 81 * 8; t += 256) {
+        const int wi = t >> 3, g = t & 7, wr = wi / 9, wc = wi - wr * 9;
+        float best[8];
+        unpack8(xs[(2 * wr) * 19 + 2 * wc][g], best);
+        unsigned idx = 0;
+#pragma unroll
+        for (int k = 1; k < 9; ++k) {
+            float v[8];
+            unpack8(xs[(2 * wr + k / 3) * 19 + 2 * wc + k % 3][g], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (v[e] > best[e]) { best[e] = v[e]; idx = (idx & ~(15u << (4 * e))) | ((unsigned)k << (4 * e)); }
+        }
+        win[wi][g] = idx;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 256 * 8; t += 256) {
+        const int p = t >> 3, g = t & 7, h = h0 + (p >> 4), w = w0 + (p & 15);
+        if (h >= H || w >= W) continue;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int ho = h >> 1; ho <= ((h + 1) >> 1) && ho < Ho; ++ho)
+            for (int wo = w >> 1; wo <= ((w + 1) >> 1) && wo < Wo; ++wo) {
+                const int wi = (ho - (h0 >> 1)) * 9 + (wo - (w0 >> 1));
+                const unsigned k = (unsigned)((h - (2 * ho - 1)) * 3 + (w - (2 * wo - 1))) * 0x11111111u;
+                const unsigned diff = win[wi][g] ^ k;                        // a zero nibble: this pixel is that channel's winner
+                float gr[8];
+                unpack8(dys[wi][g], gr);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (!((diff >> (4 * e)) & 15u)) acc[e] += gr[e];
+            }
+        *(uint4*)(dx + (((long long)b * H + h) * W + w) * C + cb + g * 8) =
+            make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ derived weight matrices in one launch
 // After every optimizer step the trainer rebuilds, from the fp32 master weights, the matrices its kernels read: bf16 copies for the forward
 // convolutions, transposed (tap-flipped) copies for the stride-1 data gradients, the four sub-pixel phase kernels of a stride-2 3x3 data
 // gradient -- some 200 small matrices.  One launch walks a table of them (a launch each cost 1.5 ms per step of ~4 us launches).
 __global__ __launch_bounds__(256) void refresh_weights_kernel(const mt4_refresh_entry* __restrict__ tab, int n_entries) {
-    // a workgroup moves one 32 (n) x 32 (c) tile of one tap through LDS: reads coalesced along c, writes coalesced along the destination's
+    // a 32 (n) x 32 (c) tile of one tap goes through LDS: reads coalesced along c, writes coalesced along the destination's
     // fast index (n when transposed).  Only valid elements are written: the destinations' padding was zeroed once, at allocation.
-    __shared__ float tile[32][33];
+    __shared__ float tile[MT4_REFRESH_TILES_PER_BLOCK][32][33];
     int lo = 0, hi = n_entries - 1;                        // the entry of this block: last one whose first block is <= blockIdx.x
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (tab[mid].block0 <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const mt4_refresh_entry e = tab[lo];
-    int b = (int)((long long)blockIdx.x - e.block0);
-    const int ct = (e.cin + 31) / 32, nt = (e.cout + 31) / 32;
-    const int tc = b % ct;
-    b /= ct;
-    const int tn = b % nt, tp = b / nt;
-    const int n0 = tn * 32, c0 = tc * 32;
+    const int ct = (e.cin + 31) / 32, nt = (e.cout + 31) / 32, ntiles = e.ntaps_dst * nt * ct;
+    const int first = (int)((long long)blockIdx.x - e.block0) * MT4_REFRESH_TILES_PER_BLOCK;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int c = c0 + tx;
+    // a block moves MT4_REFRESH_TILES_PER_BLOCK consecutive tiles of its entry, all their loads in flight together: one tile per block spent most
+    // of its life in the table search and one dependent load -> LDS -> store chain (0.41 ms per step for ~0.2 GB)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + ty + 8 * i;
-        tile[ty + 8 * i][tx] = (n < e.cout && c < e.cin) ? e.src[(long long)n * e.kpad_src + e.tap_map[tp] * e.tapw_src + c] : 0.f;
+    for (int q = 0; q < MT4_REFRESH_TILES_PER_BLOCK; ++q) {
+        int b = first + q;
+        if (b >= ntiles) break;
+        const int tc = b % ct;
+        b /= ct;
+        const int tn = b % nt, tp = b / nt, n0 = tn * 32, c = tc * 32 + tx;
+        const long long tap_off = (long long)e.tap_map[tp] * e.tapw_src;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + ty + 8 * i;
+            tile[q][ty + 8 * i][tx] = (n < e.cout && c < e.cin) ? e.src[(long long)n * e.kpad_src + tap_off + c] : 0.f;
+        }
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        long long o;
-        float v;
-        bool ok;
-        if (e.transposed) {
-            const int cc = c0 + ty + 8 * i, nn = n0 + tx;
-            ok = cc < e.cin && nn < e.cout;
-            o = (long long)cc * e.kpad_dst + tp * e.tapw_dst + nn;
-            v = tile[tx][ty + 8 * i];
-        } else {
-            const int nn = n0 + ty + 8 * i;
-            ok = nn < e.cout && c < e.cin;
-            o = (long long)nn * e.kpad_dst + tp * e.tapw_dst + c;
-            v = tile[ty + 8 * i][tx];
-        }
-        if (ok) {
-            if (e.dst_bf16) ((u16*)e.dst)[o] = f32_to_bf16(v);
-            else ((float*)e.dst)[o] = v;
+    for (int q = 0; q < MT4_REFRESH_TILES_PER_BLOCK; ++q) {
+        int b = first + q;
+        if (b >= ntiles) break;
+        const int tc = b % ct;
+        b /= ct;
+        const int tn = b % nt, tp = b / nt, n0 = tn * 32, c0 = tc * 32, c = c0 + tx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long long o;
+            float v;
+            bool ok;
+            if (e.transposed) {
+                const int cc = c0 + ty + 8 * i, nn = n0 + tx;
+                ok = cc < e.cin && nn < e.cout;
+                o = (long long)cc * e.kpad_dst + tp * e.tapw_dst + nn;
+                v = tile[q][tx][ty + 8 * i];
+            } else {
+                const int nn = n0 + ty + 8 * i;
+                ok = nn < e.cout && c < e.cin;
+                o = (long long)nn * e.kpad_dst + tp * e.tapw_dst + c;
+                v = tile[q][ty + 8 * i][tx];
+            }
+            if (ok) {
+                if (e.dst_bf16) ((u16*)e.dst)[o] = f32_to_bf16(v);
+                else ((float*)e.dst)[o] = v;
+            }
         }
     }
 }
@@ -517,9 +674,9 @@ extern "C" int mt4_bn_stats_t(const void* x, int32_t x_dtype, double* sums_zeroe
     if (!x || !sums_zeroed || !mean || !invstd || M <= 0 || C <= 0) return MT4_EINVAL;
     if (C % 4) return MT4_EALIGN;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(cdiv(C, 64), bn_row_slabs(M, C));
-    if (x_dtype == MT4_BF16) hipLaunchKernelGGL(bn_stats_t_kernel<u16>, grid, dim3(256), 0, s, (const u16*)x, sums_zeroed, (long long)M, C);
-    else if (x_dtype == MT4_F32) hipLaunchKernelGGL(bn_stats_t_kernel<float>, grid, dim3(256), 0, s, (const float*)x, sums_zeroed, (long long)M, C);
+    const dim3 grid(cdiv(C, 64), bn_reduce_slabs(M, C));
+    if (x_dtype == MT4_BF16) hipLaunchKernelGGL(bn_stats_t_kernel<u16>, grid, dim3(1024), 0, s, (const u16*)x, sums_zeroed, (long long)M, C);
+    else if (x_dtype == MT4_F32) hipLaunchKernelGGL(bn_stats_t_kernel<float>, grid, dim3(1024), 0, s, (const float*)x, sums_zeroed, (long long)M, C);
     else return MT4_EUNSUPPORTED;
     hipLaunchKernelGGL(bn_finalize_t_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, sums_zeroed, mean, invstd, running_mean, running_var, (long long)M, C,
                        momentum, eps);
@@ -531,13 +688,12 @@ extern "C" int mt4_bn_apply_t(const void* x, int32_t x_dtype, const float* mean,
     mt4_clear_error();
     if (!x || !mean || !invstd || !gamma || !beta || !y_bf16 || M <= 0 || C <= 0) return MT4_EINVAL;
     if (C % 4) return MT4_EALIGN;
-    const long long n4 = M * C / 4;
-    const dim3 grid((unsigned)((n4 + 255) / 256));
+    const dim3 grid(cdiv(C, 64), bn_row_slabs(M, C));
     hipStream_t s = (hipStream_t)stream;
     if (x_dtype == MT4_BF16)
-        hipLaunchKernelGGL(bn_apply_t_kernel<u16>, grid, dim3(256), 0, s, (const u16*)x, mean, invstd, gamma, beta, (const u16*)residual_bf16, (u16*)y_bf16, n4, C, relu);
+        hipLaunchKernelGGL(bn_apply_t_kernel<u16>, grid, dim3(256), 0, s, (const u16*)x, mean, invstd, gamma, beta, (const u16*)residual_bf16, (u16*)y_bf16, (long long)M, C, relu);
     else if (x_dtype == MT4_F32)
-        hipLaunchKernelGGL(bn_apply_t_kernel<float>, grid, dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const u16*)residual_bf16, (u16*)y_bf16, n4, C, relu);
+        hipLaunchKernelGGL(bn_apply_t_kernel<float>, grid, dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const u16*)residual_bf16, (u16*)y_bf16, (long long)M, C, relu);
     else return MT4_EUNSUPPORTED;
     return mt4_check_launch();
 }
@@ -551,17 +707,14 @@ extern "C" int mt4_bn_backward_t(const void* dy_bf16, const void* y_post_bf16, c
     if (C % 4) return MT4_EALIGN;
     if (x_dtype != MT4_BF16 && x_dtype != MT4_F32) return MT4_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 g1(cdiv(C, 64), bn_row_slabs(M, C));
-    long long n = M * C / 4;
-    if (n < C) n = C;
-    const dim3 g2((unsigned)((n + 255) / 256));
+    const dim3 g1(cdiv(C, 64), bn_reduce_slabs(M, C)), g2(cdiv(C, 64), bn_row_slabs(M, C));
     const u16 *dy = (const u16*)dy_bf16, *yp = (const u16*)y_post_bf16;
     if (x_dtype == MT4_BF16) {
-        hipLaunchKernelGGL(bn_bwd_reduce_t_kernel<u16>, g1, dim3(256), 0, s, dy, yp, (const u16*)x, mean, invstd, gamma, beta, sums_zeroed, (long long)M, C, relu);
+        hipLaunchKernelGGL(bn_bwd_reduce_t_kernel<u16>, g1, dim3(1024), 0, s, dy, yp, (const u16*)x, mean, invstd, gamma, beta, sums_zeroed, (long long)M, C, relu);
         hipLaunchKernelGGL(bn_bwd_apply_t_kernel<u16>, g2, dim3(256), 0, s, dy, yp, (const u16*)x, mean, invstd, gamma, beta, sums_zeroed, (u16*)dx,
                            (u16*)dres_bf16, dgamma, dbeta, (long long)M, C, relu);
     } else {
-        hipLaunchKernelGGL(bn_bwd_reduce_t_kernel<float>, g1, dim3(256), 0, s, dy, yp, (const float*)x, mean, invstd, gamma, beta, sums_zeroed, (long long)M, C, relu);
+        hipLaunchKernelGGL(bn_bwd_reduce_t_kernel<float>, g1, dim3(1024), 0, s, dy, yp, (const float*)x, mean, invstd, gamma, beta, sums_zeroed, (long long)M, C, relu);
         hipLaunchKernelGGL(bn_bwd_apply_t_kernel<float>, g2, dim3(256), 0, s, dy, yp, (const float*)x, mean, invstd, gamma, beta, sums_zeroed, (float*)dx,
                            (u16*)dres_bf16, dgamma, dbeta, (long long)M, C, relu);
     }
@@ -604,6 +757,11 @@ extern "C" int mt4_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, void* dx
     if (!x || !dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0) return MT4_EINVAL;
     if ((C & 7) || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15)) return MT4_EALIGN;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if (!(C & 63) && (long long)B * (C >> 6) <= 65535) {
+        hipLaunchKernelGGL(maxpool3x3s2_bwd_bf16_tile_kernel, dim3(cdiv(W, 16), cdiv(H, 16), B * (C >> 6)), dim3(256), 0, (hipStream_t)stream, (const u16*)x,
+                           (const u16*)dy, (u16*)dx, H, W, C, Ho, Wo);
+        return mt4_check_launch();
+    }
     const long long n = (long long)B * H * W * (C / 8);
     hipLaunchKernelGGL(maxpool3x3s2_bwd_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u16*)x, (const u16*)dy,
                        (u16*)dx, B, H, W, C, Ho, Wo);

@@ -907,6 +907,9 @@ def avgpool_bwd_bf16(dfeat, b, hw, c):
     return dx
 
 
+REFRESH_TILES_PER_BLOCK = 4          # MT4_REFRESH_TILES_PER_BLOCK of include/mt4hip.h
+
+
 class RefreshTable:
     """the derived weight matrices of a trainer (bf16 forward copies, transposed data-gradient operators, sub-pixel phase kernels), rebuilt from the
     fp32 master weights by ONE launch (`mt4_refresh_weights`).  `add` allocates a zeroed destination and records how it is filled; `run` launches."""
@@ -933,7 +936,8 @@ class RefreshTable:
             e.tap_map[i] = t
         self._entries.append(e)
         self._keep = getattr(self, "_keep", []) + [src, dst]
-        self._blocks += len(tap_map) * ((cout + 31) // 32) * ((cin + 31) // 32)
+        tiles = len(tap_map) * ((cout + 31) // 32) * ((cin + 31) // 32)
+        self._blocks += (tiles + REFRESH_TILES_PER_BLOCK - 1) // REFRESH_TILES_PER_BLOCK
         self._table = None
         return dst
 

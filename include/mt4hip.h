@@ -386,8 +386,9 @@ int mt4_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
  * taps of tapw_src elements):
  *     transposed == 0:  dst[n][t][c] = src[n][tap_map[t]][c]      (a bf16 copy of a forward weight)
  *     transposed == 1:  dst[c][t][n] = src[n][tap_map[t]][c]      (data-gradient operators: flipped taps, sub-pixel phases of a strided conv)
- * A workgroup moves one 32 (n) x 32 (c) tile of one tap: an entry takes ntaps_dst * ceil(cout / 32) * ceil(cin / 32) workgroups, block0 = its first one
- * (entries ordered by block0).  Only valid elements are written: zero the destinations once at allocation.  The table lives in device memory. */
+ * The unit is a 32 (n) x 32 (c) tile of one tap and a workgroup moves MT4_REFRESH_TILES_PER_BLOCK consecutive tiles of one entry: an entry takes
+ * ceil(ntaps_dst * ceil(cout / 32) * ceil(cin / 32) / MT4_REFRESH_TILES_PER_BLOCK) workgroups, block0 = its first one (entries ordered by block0).  Only valid elements are written: zero the destinations once at allocation.  The table lives in device memory. */
+#define MT4_REFRESH_TILES_PER_BLOCK 4
 typedef struct {
     const float* src;
     void* dst;

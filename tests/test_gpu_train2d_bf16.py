@@ -90,6 +90,23 @@ def test_batchnorm_bf16_fwd_bwd(cuda, m, c, relu, res, xf32):
         assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
+@pytest.mark.parametrize("b,h,w,c", [(2, 13, 18, 64), (1, 40, 37, 128), (2, 13, 18, 8), (1, 32, 48, 64)])
+def test_maxpool_backward_bf16(cuda, b, h, w, c):
+    """C % 64 == 0 runs the LDS-tiled kernel (several 16 x 16 tiles, ragged edges), other channel counts the per-pixel one"""
+    from computervision_codes_amd import ops
+    x = _rand((b, h, w, c), 1).to(BF)
+    x[0, 2:5, 2:5, :8] = 1.5                                        # ties: the first maximum in scan order takes the gradient
+    x[0, 14:19, 14:19, :] = -0.25                                   # ties across a tile boundary
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    dy = _rand((b, ho, wo, c), 2).to(BF)
+    xt = x.float().permute(0, 3, 1, 2).clone().requires_grad_()
+    with torch.enable_grad():
+        F.max_pool2d(xt, 3, 2, 1).backward(dy.float().permute(0, 3, 1, 2))
+    dx = ops.maxpool3x3s2_bwd_bf16(x.to(cuda), dy.to(cuda))
+    ref = xt.grad.permute(0, 2, 3, 1)
+    assert (dx.float().cpu() - ref).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
+
+
 def test_pool_backward_and_repack_bf16(cuda):
     from computervision_codes_amd import ops
     b, h, w, c = 2, 13, 18, 64
