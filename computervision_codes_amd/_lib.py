@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("x_pixel_stride", C.c_int32), ("fuse_cout", C.c_int32),
         ("fuse_w", C.c_void_p), ("fuse_bias", C.c_void_p), ("fuse_y", C.c_void_p), ("fuse_relu", C.c_int32), ("residual_float", C.c_int32),
         ("x2", C.c_void_p), ("x2_H", C.c_int32), ("x2_W", C.c_int32), ("x2_C", C.c_int32), ("x2_stride", C.c_int32), ("fuse_expand", C.c_int32),
+        ("stat_sums", C.c_void_p),
     ]
 
 
@@ -105,6 +106,7 @@ SIGNATURES = {
     "mt4_distill_kl_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _i32, _vp]),
     "mt4_mse_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, _vp]),
     "mt4_bn_stats_t": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, C.c_float, C.c_float, _vp]),
+    "mt4_bn_apply_sums_t": (C.c_int, [_vp, _i32] + [_vp] * 9 + [C.c_int64, _i32, C.c_float, C.c_float, _i32, _vp]),
     "mt4_bn_apply_t": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _vp]),
     "mt4_bn_backward_t": (C.c_int, [_vp, _vp, _vp, _i32] + [_vp] * 9 + [C.c_int64, _i32, _i32, _vp]),
     "mt4_wgrad_conv2d_bf16": (C.c_int, [_vp, _vp, _vp] + [_i32] * 9 + [_vp]),
@@ -162,7 +164,7 @@ def _load() -> C.CDLL:
     return lib
 
 
-ABI_VERSION = 8         # what mt4_abi_version() of a matching libmt4hip.so returns (csrc/misc_kernels.hip)
+ABI_VERSION = 9         # what mt4_abi_version() of a matching libmt4hip.so returns (csrc/misc_kernels.hip)
 lib = _load()
 if lib.mt4_abi_version() != ABI_VERSION:      # a stale libmt4hip.so next to newer Python: fail at import, not in the first launch
     raise ImportError(f"libmt4hip.so reports ABI {lib.mt4_abi_version()}, this package binds ABI {ABI_VERSION}: rebuild (make -C computervision_codes_amd/csrc)")

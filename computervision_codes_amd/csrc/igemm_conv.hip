@@ -99,19 +99,57 @@ struct ConvK {
     long long x2_img_bytes, x2_total_bytes;
     int x2_W, x2_s, x2_pix_bytes, x2_HoWo, x2_Wo;
     int nsteps1;            // K-steps of the first source
+    double* stat_sums;      // mt4_conv_desc.stat_sums: [MT4_STAT_REPLICAS][2][Cout], += sum | sum of squares of the stored values
     const char* f_w;        // packed [f_cout][Cout] bf16 (mt4_pack_conv_weight, 1x1)
     const float* f_bias;
     char* f_y;
     int f_cout, f_relu, f_w_row_bytes;
 };
 
+// Per-channel sums of a launch's STORED values for the train-mode BatchNorm behind a convolution (mt4_conv_desc.stat_sums): every thread of the
+// staged epilogue keeps the float64 sum and sum of squares of its CH channels over the rows it stores; here the threads that share a channel
+// group are folded (lanes of a wave by shuffle, waves through LDS) and the tile's totals are added to one of MT4_STAT_REPLICAS copies of the
+// [2][Cout] sums (copy = pixel tile % replicas: the same-address chains of float64 atomics at the L2 stay ~1/8 of the pixel tiles long).
+// float64 throughout: the totals equal those of a float64 pass over the stored map to ~1e-16, i.e. the same float32 mean / invstd.
+template <int TPR, int NTH, int CH, int BN>
+__device__ __forceinline__ void colstat_flush(double (&cs)[CH], double (&cq)[CH], char* smem, double* __restrict__ sums, int n0, int Cout, int tid) {
+    static_assert(TPR <= 64 && 64 % TPR == 0, "a wave covers whole rows of the read-back");
+    constexpr int NW = NTH / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = TPR; o < 64; o <<= 1) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) { cs[e] += __shfl_xor(cs[e], o); cq[e] += __shfl_xor(cq[e], o); }
+    }
+    double* red = (double*)smem;   // [NW][2][BN]
+    __syncthreads();               // the staging rows have been read back
+    if (lane < TPR) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            red[(wave * 2) * BN + lane * CH + e] = cs[e];
+            red[(wave * 2 + 1) * BN + lane * CH + e] = cq[e];
+        }
+    }
+    __syncthreads();
+    for (int col = tid; col < 2 * BN; col += NTH) {
+        const int h = col / BN, c = col - h * BN;
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[(w * 2 + h) * BN + c];
+        if (n0 + c < Cout) atomicAdd(sums + (long long)h * Cout + n0 + c, t);
+    }
+}
+
 // KS > 1 (FAST only): the workgroup holds KS groups of WAVES_M x WAVES_N waves; group g runs the K-steps g, g+KS, ... of the SAME output
 // tile through its own operand stages and the partial tiles are added in LDS in the fixed order g = 0, 1, ... before the epilogue
 // (deterministic, independent of the batch).  For launches with few tiles and a long K (a TCN layer over one short video: 128 workgroups,
 // 48 K-steps) the K loop -- one barrier and one DMA round trip per step -- is the launch's critical path; this cuts it KS-fold.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool FAST, bool OUT_F32, int KS = 1, bool DUAL = false>
+// STATS: the epilogue also adds the channel sums of the stored values to a.stat_sums (colstat_flush); a separate instantiation, so that the
+// float64 accumulators cost the inference launches no registers
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool FAST, bool OUT_F32, int KS = 1, bool DUAL = false, bool STATS = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel(const ConvK a) {
     static_assert(!DUAL || (FAST && sizeof(T) == 2 && KS == 1), "the second K source exists on the bf16 LDS-DMA path");
+    static_assert(!STATS || (KS == 1 && !DUAL && WAVES_M * WAVES_N * BN * 16 <= (BM + BN) * 128), "channel sums: one-group forms whose LDS holds the waves' partial rows");
     constexpr int ES = (int)sizeof(T);
     constexpr int ROWS = BM + BN;
     constexpr int NWG = WAVES_M * WAVES_N;  // waves of one group
@@ -476,6 +514,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel
         // (the K loop ended with a barrier: every wave is done reading the operand stages)
         const int rc = tid % TPR, rr = tid / TPR;
         const int n = n0 + rc * CH;
+        double cs[STATS ? CH : 1], cq[STATS ? CH : 1];
+        if constexpr (STATS) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) cs[e] = cq[e] = 0.0;
+        }
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             // residual rows of this pass go in flight BEFORE the LDS hand-off, all at once: issued inside the read-back
@@ -571,14 +614,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel
                 }
                 if constexpr (OUT_F32) {
                     *(float4*)(a.y + o * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    if constexpr (STATS) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const double dv = (double)v[e]; cs[e] += dv; cq[e] = fma(dv, dv, cq[e]); }
+                    }
                 } else {
                     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                     const u32x4 ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
                     if (a.nt_epi) __builtin_nontemporal_store(ov, (u32x4*)(a.y + o * 2));
                     else *(uint4*)(a.y + o * 2) = make_uint4(ov.x, ov.y, ov.z, ov.w);
+                    if constexpr (STATS) {   // of the rounded values: the statistics of the tensor BatchNorm reads
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const double lo = (double)__uint_as_float(ov[e] << 16), hi = (double)__uint_as_float(ov[e] & 0xffff0000u);
+                            cs[2 * e] += lo; cq[2 * e] = fma(lo, lo, cq[2 * e]); cs[2 * e + 1] += hi; cq[2 * e + 1] = fma(hi, hi, cq[2 * e + 1]);
+                        }
+                    }
                 }
             }
         }
+        if constexpr (STATS)
+            colstat_flush<TPR, NTH, CH, BN>(cs, cq, smem, a.stat_sums + (long long)(tile_m & (MT4_STAT_REPLICAS - 1)) * 2 * a.Cout, n0, a.Cout, tid);
         return;
     }
     // Direct path (ragged Cout, e.g. the 131-wide concatenated heads): per-element guards
@@ -921,6 +977,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 
         }
         return;
     }
+    double cs[8], cq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.0;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         // residual rows of the pass (the second conv of a BasicBlock) go in flight before the LDS hand-off, like in the generic kernel
@@ -966,8 +1025,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 
             char* yp = a.y + ((long long)m * a.y_ld + n) * 2;
             if (a.nt_epi) __builtin_nontemporal_store(ov, (u32x4*)yp);
             else *(uint4*)yp = make_uint4(ov.x, ov.y, ov.z, ov.w);
+            if (a.stat_sums) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double lo = (double)__uint_as_float(ov[e] << 16), hi = (double)__uint_as_float(ov[e] & 0xffff0000u);
+                    cs[2 * e] += lo; cq[2 * e] = fma(lo, lo, cq[2 * e]); cs[2 * e + 1] += hi; cq[2 * e + 1] = fma(hi, hi, cq[2 * e + 1]);
+                }
+            }
         }
     }
+    if (a.stat_sums) colstat_flush<TPR, NTH, 8, BN>(cs, cq, smem, a.stat_sums + (long long)(tile_m & (MT4_STAT_REPLICAS - 1)) * 2 * a.Cout, n0, a.Cout, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ stem patch kernel
@@ -1343,6 +1410,8 @@ template <typename T, int BM, int BN, int WM_, int WN_, int STAGES, bool OUT_F32
 int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     const int m_tiles = cdiv(k.M, BM);
     ConvK kk = k;
+    constexpr bool CAN_STATS = KS == 1 && WM_ * WN_ * BN * 16 <= (BM + BN) * 128;   // the staged epilogue's LDS holds the waves' partial rows
+    if (k.stat_sums && (!CAN_STATS || (k.Cout % (OUT_F32 ? 4 : 8)) != 0)) return MT4_EUNSUPPORTED;
     kk.n_tiles = cdiv(k.Cout, BN);
     kk.total_tiles = m_tiles * kk.n_tiles;
     kk.nt_epi = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
@@ -1371,6 +1440,24 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     } else {
     const int lds = k.nsteps > 1 ? (fast ? STAGES : 2) * stage : (stage > epi ? stage : epi);
     const int grid = kk.total_tiles;  // one tile per workgroup (see PERSIST in the kernel)
+    if constexpr (CAN_STATS) {
+        if (k.stat_sums) {
+            if (fast) {
+                auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, STAGES, true, OUT_F32, 1, false, true>;
+                if (lds > 65536) {
+                    MT4_RAISE_LDS(fn);
+                }
+                hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, s, kk);
+            } else {
+                auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, 2, false, OUT_F32, 1, false, true>;
+                if (lds > 65536) {
+                    MT4_RAISE_LDS(fn);
+                }
+                hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, s, kk);
+            }
+            return mt4_check_launch();
+        }
+    }
     if (fast) {
         auto fn = igemm_conv_kernel<T, BM, BN, WM_, WN_, STAGES, true, OUT_F32>;
         if (lds > 65536) {
@@ -1466,6 +1553,7 @@ int launch_patch3x3(const ConvK& k, hipStream_t s) {
     if (EXPAND && lds < 2 * BM * 128 + epi) lds = 2 * BM * 128 + epi;   // the bf16 tile (two 64-channel planes) + the staging of a pass
     if (WS == 9 && k.SPT != 1) return MT4_EUNSUPPORTED;
     if (lds > 160 * 1024 || (k.SPT > 1 && cdiv(pra, rpp) > 11 - WS)) return MT4_EUNSUPPORTED;   // (next-slice patch pieces ride along with taps 0..)
+    if (k.stat_sums && (EXPAND || (k.Cout & 7))) return MT4_EUNSUPPORTED;
     auto fn = conv3x3_patch_kernel<BM, BN, WM_, WN_, WS, EXPAND>;
     if (lds > 65536) {
         MT4_RAISE_LDS(fn);
@@ -1655,6 +1743,12 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     k.x_bytes = (unsigned)(xb < 0x7fffffffLL ? xb : 0);
     k.w_bytes = (unsigned)(wb < 0x7fffffffLL ? wb : 0);
     k.SPT = fast ? k.CPT / 8 : 1;
+    if (d->stat_sums) {
+        // the statistics of a train-mode BatchNorm behind this convolution: plain launches of the generic and the 3x3 patch kernel only
+        if ((uintptr_t)d->stat_sums & 7) return MT4_EALIGN;
+        if (d->fuse_w || d->x2 || d->out_row_map || d->tile == -1 || d->tile == 33 || pix != d->Cin * es) return MT4_EUNSUPPORTED;
+        k.stat_sums = d->stat_sums;
+    }
     if (d->fuse_w && d->fuse_expand) {
         // the Bottleneck's conv3 + bn3 + add + ReLU behind its 3x3 conv, in the patch kernel: only where that kernel runs (many tiles: the
         // caller launches the two convs otherwise -- the results are bit-identical either way)

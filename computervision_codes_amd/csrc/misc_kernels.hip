@@ -3,7 +3,7 @@
 
 thread_local int g_mt4_last_hip_error = 0;
 
-extern "C" int mt4_abi_version(void) { return 8; }   // 6: + mt4_stem_maxpool_bf16, mt4_conv_desc.x2 (second K source), mt4_bottleneck_fused_next_bf16; 7: + mt4_copy_spans_u8; 8: + mt4_chain_gemm_bf16
+extern "C" int mt4_abi_version(void) { return 9; }   // 6: + mt4_stem_maxpool_bf16, mt4_conv_desc.x2 (second K source), mt4_bottleneck_fused_next_bf16; 7: + mt4_copy_spans_u8; 8: + mt4_chain_gemm_bf16; 9: + mt4_conv_desc.stat_partials, mt4_bn_finalize_partials, mt4_refresh_weights moves MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup
 extern "C" int mt4_last_hip_error(void) { return g_mt4_last_hip_error; }
 extern "C" const char* mt4_strerror(int code) {
     switch (code) {

@@ -104,13 +104,48 @@ __global__ void bn_finalize_t_kernel(const double* __restrict__ sums, float* __r
 // y (bf16) = act( (x - mean) * invstd * gamma + beta [+ residual (bf16)] ).  Column slabs like the reductions: a thread owns 4 consecutive
 // channels and walks rows, its per-channel parameters in registers -- one element group per thread re-loaded 64 bytes of parameters for every
 // 16 bytes of tensor traffic and ran at 3.8-4.1 TB/s where the bare stream measures 5-6 (tools/bn_stream_micro.hip).  Same expressions: same bits.
-template <typename TZ>
-__global__ __launch_bounds__(256) void bn_apply_t_kernel(const TZ* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+// FIN: mean / invstd come from the channel sums a convolution's epilogue left (mt4_conv_desc.stat_sums): the first 64 threads fold the replicas and
+// evaluate bn_finalize_t_kernel's expressions for the workgroup's 64 channels (float64: done by every thread it would cost more than the stream),
+// the row-slab 0 workgroups also write mean / invstd for the backward and update the running statistics
+template <typename TZ, bool FIN>
+__global__ __launch_bounds__(256) void bn_apply_t_kernel(const TZ* __restrict__ x, float* __restrict__ mean, float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, const u16* __restrict__ res,
-                                                         u16* __restrict__ y, long long M, int C, int relu) {
+                                                         u16* __restrict__ y, long long M, int C, int relu, const double* __restrict__ sums,
+                                                         float* __restrict__ run_mean, float* __restrict__ run_var, float momentum, float eps) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
-    if (c >= C) return;
-    const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c), g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    float4 mu, is;
+    if constexpr (FIN) {
+        __shared__ __attribute__((aligned(16))) float s_mu[64], s_is[64];
+        const int ch = blockIdx.x * 64 + threadIdx.x;
+        if (threadIdx.x < 64 && ch < C) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int r = 0; r < MT4_STAT_REPLICAS; ++r) { s1 += sums[(long long)(2 * r) * C + ch]; s2 += sums[(long long)(2 * r + 1) * C + ch]; }
+            const double m_ = s1 / (double)M;
+            double var = s2 / (double)M - m_ * m_;
+            var = var > 0.0 ? var : 0.0;
+            const float mf = (float)m_, isf = (float)(1.0 / sqrt(var + (double)eps));
+            s_mu[threadIdx.x] = mf;
+            s_is[threadIdx.x] = isf;
+            if (blockIdx.y == 0) {
+                mean[ch] = mf;
+                invstd[ch] = isf;
+                if (run_mean) {
+                    run_mean[ch] = (1.f - momentum) * run_mean[ch] + momentum * mf;
+                    run_var[ch] = (1.f - momentum) * run_var[ch] + momentum * (float)(var * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+                }
+            }
+        }
+        __syncthreads();
+        if (c >= C) return;
+        mu = *(const float4*)(s_mu + (threadIdx.x & 15) * 4);
+        is = *(const float4*)(s_is + (threadIdx.x & 15) * 4);
+    } else {
+        if (c >= C) return;
+        mu = *(const float4*)(mean + c);
+        is = *(const float4*)(invstd + c);
+    }
+    const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
     const long long st = (long long)gridDim.y * 16;
     long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4);
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -691,9 +726,29 @@ extern "C" int mt4_bn_apply_t(const void* x, int32_t x_dtype, const float* mean,
     const dim3 grid(cdiv(C, 64), bn_row_slabs(M, C));
     hipStream_t s = (hipStream_t)stream;
     if (x_dtype == MT4_BF16)
-        hipLaunchKernelGGL(bn_apply_t_kernel<u16>, grid, dim3(256), 0, s, (const u16*)x, mean, invstd, gamma, beta, (const u16*)residual_bf16, (u16*)y_bf16, (long long)M, C, relu);
+        hipLaunchKernelGGL((bn_apply_t_kernel<u16, false>), grid, dim3(256), 0, s, (const u16*)x, (float*)mean, (float*)invstd, gamma, beta, (const u16*)residual_bf16,
+                           (u16*)y_bf16, (long long)M, C, relu, (const double*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0.f);
     else if (x_dtype == MT4_F32)
-        hipLaunchKernelGGL(bn_apply_t_kernel<float>, grid, dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const u16*)residual_bf16, (u16*)y_bf16, (long long)M, C, relu);
+        hipLaunchKernelGGL((bn_apply_t_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, (float*)mean, (float*)invstd, gamma, beta,
+                           (const u16*)residual_bf16, (u16*)y_bf16, (long long)M, C, relu, (const double*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0.f);
+    else return MT4_EUNSUPPORTED;
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_bn_apply_sums_t(const void* x, int32_t x_dtype, const double* stat_sums, float* mean, float* invstd, float* running_mean, float* running_var,
+                                   const float* gamma, const float* beta, const void* residual_bf16, void* y_bf16, int64_t M, int32_t C, float momentum,
+                                   float eps, int32_t relu, void* stream) {
+    mt4_clear_error();
+    if (!x || !stat_sums || !mean || !invstd || !gamma || !beta || !y_bf16 || M <= 0 || C <= 0) return MT4_EINVAL;
+    if (C % 4) return MT4_EALIGN;
+    const dim3 grid(cdiv(C, 64), bn_row_slabs(M, C));
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == MT4_BF16)
+        hipLaunchKernelGGL((bn_apply_t_kernel<u16, true>), grid, dim3(256), 0, s, (const u16*)x, mean, invstd, gamma, beta, (const u16*)residual_bf16, (u16*)y_bf16,
+                           (long long)M, C, relu, stat_sums, running_mean, running_var, momentum, eps);
+    else if (x_dtype == MT4_F32)
+        hipLaunchKernelGGL((bn_apply_t_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const u16*)residual_bf16,
+                           (u16*)y_bf16, (long long)M, C, relu, stat_sums, running_mean, running_var, momentum, eps);
     else return MT4_EUNSUPPORTED;
     return mt4_check_launch();
 }

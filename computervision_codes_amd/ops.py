@@ -92,13 +92,18 @@ def with_latency_tiles(fn):
     return wrapped
 
 
+STAT_REPLICAS = 8                    # MT4_STAT_REPLICAS of include/mt4hip.h
+
+
 def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, kh: int, kw: int,
               stride: Tuple[int, int] = (1, 1), pad: Tuple[int, int] = (0, 0), dil: Tuple[int, int] = (1, 1),
               residual: Optional[torch.Tensor] = None, relu: bool = False, out_dtype: Optional[torch.dtype] = None,
               out: Optional[torch.Tensor] = None, tile: int = 0, act: Optional[str] = None,
               out_row_map: Optional[torch.Tensor] = None, y_ld: int = 0, res_ld: int = 0, out_hw: Optional[Tuple[int, int]] = None,
-              out_rows_per_image: int = 0, run_pixels: int = 1, second=None):
+              out_rows_per_image: int = 0, run_pixels: int = 1, second=None, stat_sums: Optional[torch.Tensor] = None):
     """y = act(conv(x, w) + bias [+ residual]); x [B,H,W,Cin] contiguous channels-last storage.
+    stat_sums: float64 [STAT_REPLICAS, 2, Cout], zeroed by the caller: the launch adds the channel sums / sums of squares of the y it stores
+    (`mt4_conv_desc.stat_sums`) -- what `bn_apply_sums_t` turns into the train-mode BatchNorm without a statistics pass over y.
     second = (x2 [B,H2,W2,C2], stride): a second K source behind x, gathered at x2[b, s*ho, s*wo] -- conv3 + the downsample branch of a strided
     Bottleneck in one accumulator chain; `w_packed` = torch.cat([w3_packed, wds_packed], 1), `bias` = b3 + bds (bf16 1x1 launches).
     run_pixels > 1: a tap reads a contiguous run of that many pixels (Cin_eff = run_pixels * x.shape[-1]; kw must be 1, no padding,
@@ -158,6 +163,10 @@ def conv_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
                  b, h, w_, cin, ho, wo, cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1],
                  act_code, dt_code(x.dtype), dt_code(od), tile, out_row_map.numel() if out_row_map is not None else 0, y_ld, res_ld,
                  out_rows_per_image, pix, 0, None, None, None, 0, res_f32, x2p, x2h, x2w, x2c, x2s, 0)
+    if stat_sums is not None:
+        _need_cuda(stat_sums)
+        assert stat_sums.dtype == torch.float64 and stat_sums.is_contiguous() and stat_sums.numel() == STAT_REPLICAS * 2 * cout
+        d.stat_sums = stat_sums.data_ptr()
     check(lib.mt4_conv_nhwc(C.byref(d), _stream()), "mt4_conv_nhwc")
     return out
 
@@ -854,6 +863,24 @@ def bn_stats_t(x2d, running_mean=None, running_var=None, momentum=0.1, eps=1e-5,
                              running_mean.data_ptr() if running_mean is not None else None,
                              running_var.data_ptr() if running_var is not None else None, m, c, momentum, eps, _stream()), "mt4_bn_stats_t")
     return mean, invstd
+
+
+def bn_apply_sums_t(x2d, stat_sums, gamma, beta, residual=None, relu=True, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """train-mode BatchNorm of a convolution output from the channel sums the convolution's epilogue left (`conv_nhwc(stat_sums=...)`): ONE launch
+    computes mean / invstd (returned for the backward), updates the running statistics and applies y = act((x - mean) * invstd * gamma + beta
+    [+ residual]).  Returns (y, mean, invstd)"""
+    _need_cuda(x2d, stat_sums, gamma, beta, residual)
+    m, c = x2d.shape
+    assert x2d.is_contiguous() and stat_sums.dtype == torch.float64 and stat_sums.numel() == STAT_REPLICAS * 2 * c
+    mean = torch.empty(c, dtype=torch.float32, device=x2d.device)
+    invstd = torch.empty_like(mean)
+    y = torch.empty((m, c), dtype=BF16, device=x2d.device)
+    check(lib.mt4_bn_apply_sums_t(x2d.data_ptr(), dt_code(x2d.dtype), stat_sums.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                  running_mean.data_ptr() if running_mean is not None else None,
+                                  running_var.data_ptr() if running_var is not None else None, gamma.data_ptr(), beta.data_ptr(),
+                                  residual.data_ptr() if residual is not None else None, y.data_ptr(), m, c, momentum, eps, 1 if relu else 0, _stream()),
+          "mt4_bn_apply_sums_t")
+    return y, mean, invstd
 
 
 def bn_apply_t(x2d, mean, invstd, gamma, beta, residual=None, relu=True):

@@ -12,6 +12,7 @@
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Sequence
 
 import torch
@@ -51,6 +52,8 @@ class SpatialCnnTrainer:
         # bfloat16: the convolutions' GEMM operands (activations, activation gradients, weight copies) are bf16, sums fp32 / fp64, master
         # weights + gradients + SGD fp32 (csrc/train2d_bf16.hip); the stem's 7x7x3 convolution and the heads / KD branch stay fp32
         self.op16 = operand_dtype == torch.bfloat16
+        # bf16 mode: BatchNorm statistics from the producing convolution's epilogue (MT4_NO_EPILOGUE_STATS=1: the separate pass over the map)
+        self.epilogue_stats = self.op16 and not os.environ.get("MT4_NO_EPILOGUE_STATS")
         self.loss_type = loss_type
         self.heads = _ALL_HEADS if loss_type == "all" else tuple(h for h in _ALL_HEADS if h[0] == loss_type)
         self.NH = sum(k for _, k in self.heads)
@@ -150,12 +153,14 @@ class SpatialCnnTrainer:
             b.copy_(bsrc.to(dev))
             self.lin[name] = (w, b, gw, gb, co, ci)
         assert off == total
-        # float64 scratch of every BatchNorm reduction of a step (forward 2C + backward 2C), zeroed once per step
-        self._arena = torch.zeros(sum(4 * u.cout for u in self.units.values()), dtype=torch.float64, device=dev)
+        # float64 scratch of every BatchNorm reduction of a step (forward 2C -- or its STAT_REPLICAS copies when the convolution's epilogue
+        # fills them -- and backward 2C), zeroed once per step
+        rep = ops.STAT_REPLICAS if self.epilogue_stats else 1
+        self._arena = torch.zeros(sum((2 * rep + 2) * u.cout for u in self.units.values()), dtype=torch.float64, device=dev)
         o = 0
         for u in self.units.values():
-            u.sums_f, u.sums_b = self._arena[o:o + 2 * u.cout], self._arena[o + 2 * u.cout:o + 4 * u.cout]
-            o += 4 * u.cout
+            u.sums_f, u.sums_b = self._arena[o:o + 2 * rep * u.cout], self._arena[o + 2 * rep * u.cout:o + (2 * rep + 2) * u.cout]
+            o += (2 * rep + 2) * u.cout
         self._row_maps: Dict[tuple, torch.Tensor] = {}
         self._col_scales: Dict[int, torch.Tensor] = {}
         self._graphs: Dict[tuple, object] = {}
@@ -253,6 +258,16 @@ class SpatialCnnTrainer:
     # ------------------------------------------------------------------ building blocks
     def _fwd_unit(self, u: _Unit, x, residual=None, relu=True, saved=None):
         w = u.w16 if (self.op16 and u.cin != 4) else u.w            # (bf16 mode: the stem reads the fp32 image with its fp32 weights)
+        if self.op16 and self.epilogue_stats:
+            # the BatchNorm statistics ride in the convolution's epilogue, mean / invstd are evaluated inside the apply launch: no pass over z
+            z = ops.conv_nhwc(x, w, None, kh=u.k, kw=u.k, stride=(u.stride, u.stride), pad=(u.pad, u.pad), stat_sums=u.sums_f)
+            b, ho, wo, c = z.shape
+            a, mean, invstd = ops.bn_apply_sums_t(z.view(-1, c), u.sums_f, u.gamma, u.beta, residual.view(-1, c) if residual is not None else None, relu,
+                                                  u.rmean, u.rvar)
+            a = a.view(b, ho, wo, c)
+            if saved is not None:
+                saved.append((u, x, z, mean, invstd, a, relu, residual is not None))
+            return a
         z = ops.conv_nhwc(x, w, None, kh=u.k, kw=u.k, stride=(u.stride, u.stride), pad=(u.pad, u.pad))
         b, ho, wo, c = z.shape
         z2 = z.view(-1, c)

@@ -30,8 +30,9 @@ extern "C" {
 #define MT4_F32 0
 #define MT4_BF16 1
 
-/* 8 in this revision (5 -> 6: mt4_stem_maxpool_bf16, mt4_bottleneck_fused_next_bf16, mt4_pack_fragments_bf16, the x2 / fuse_expand fields at the
- * end of mt4_conv_desc; 6 -> 7: mt4_copy_spans_u8; 7 -> 8: mt4_chain_gemm_bf16).  A binding checks it once at load
+/* 9 in this revision (5 -> 6: mt4_stem_maxpool_bf16, mt4_bottleneck_fused_next_bf16, mt4_pack_fragments_bf16, the x2 / fuse_expand fields at the
+ * end of mt4_conv_desc; 6 -> 7: mt4_copy_spans_u8; 7 -> 8: mt4_chain_gemm_bf16; 8 -> 9: stat_sums at the end of
+ * mt4_conv_desc, mt4_bn_apply_sums_t, MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup in mt4_refresh_weights).  A binding checks it once at load
  * (computervision_codes_amd/_lib.py: ABI_VERSION). */
 int mt4_abi_version(void);
 const char* mt4_strerror(int code);
@@ -54,6 +55,7 @@ int mt4_last_hip_error(void);
  *   y        [B][Ho][Wo][Cout]         out_dtype (MT4_F32 allowed with bf16 inputs)
  * Contract: Cin*esize % 16 == 0; x, w, y, residual 16-byte aligned.
  */
+#define MT4_STAT_REPLICAS 8
 typedef struct mt4_conv_desc {
     const void* x;
     const void* w;
@@ -112,6 +114,13 @@ typedef struct mt4_conv_desc {
                                    fuse_cout is a multiple of 128 and fuse_w is in fragment order (mt4_pack_fragments_bf16 of the packed
                                    [fuse_cout][128] matrix).  Runs where the 3x3 patch kernel runs (>= 256 tiles of 256 x 256): MT4_EUNSUPPORTED
                                    otherwise -- launch the two convs then; the results are bit-identical either way */
+    /* Statistics of the train-mode BatchNorm that follows this convolution (Spatial_cnn/run.py:145-224 trains resnet.py's conv -> bn pairs),
+       taken in the epilogue instead of a pass over y: the launch ADDS, per output channel c,
+           stat_sums[r][0][c] += sum of y[m][c],   stat_sums[r][1][c] += sum of y[m][c]^2      (float64; of the STORED, i.e. rounded, values)
+       over its pixels m, spread over the MT4_STAT_REPLICAS copies r (by pixel tile) so that the float64 atomics behind it do not queue on
+       one address; the statistics are the sums over r (mt4_bn_apply_sums_t).  The caller zeroes the buffer.  Plain launches only (no fuse_*,
+       x2, out_row_map, x_pixel_stride, tile -1 / 33 / K-split ids; Cout % 8 == 0, % 4 for fp32 output): MT4_EUNSUPPORTED otherwise.  NULL = off. */
+    double* stat_sums;          /* [MT4_STAT_REPLICAS][2][Cout] float64 */
 } mt4_conv_desc;
 
 int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream);
@@ -362,6 +371,12 @@ int mt4_bn_stats_t(const void* x, int32_t x_dtype, double* sums_zeroed, float* m
 /* y (bf16) = act( (x - mean) * invstd * gamma + beta [+ residual (bf16)] ) */
 int mt4_bn_apply_t(const void* x, int32_t x_dtype, const float* mean, const float* invstd, const float* gamma, const float* beta,
                    const void* residual_bf16, void* y_bf16, int64_t M, int32_t C, int32_t relu, void* stream);
+/* mt4_bn_stats_t's second step + mt4_bn_apply_t in ONE launch, from the channel sums a convolution's epilogue left (mt4_conv_desc.stat_sums,
+ * [MT4_STAT_REPLICAS][2][C]): mean / invstd are computed (float64, the expressions of mt4_bn_stats_t) and written for the backward, the running
+ * statistics take nn.BatchNorm2d's momentum update, and y = act((x - mean) * invstd * gamma + beta [+ residual]) as above. */
+int mt4_bn_apply_sums_t(const void* x, int32_t x_dtype, const double* stat_sums, float* mean, float* invstd, float* running_mean, float* running_var,
+                        const float* gamma, const float* beta, const void* residual_bf16, void* y_bf16, int64_t M, int32_t C, float momentum, float eps,
+                        int32_t relu, void* stream);
 /* as mt4_bn_backward_f32 with dy / y_post / dres in bf16 and dx in the type of x.  relu: 0 none; 1 the ReLU gate is read from y_post; 2 it is
  * recomputed from x ((x - mean) * invstd * gamma + beta > 0, the forward's own expression; units WITHOUT a residual input only): y_post may be
  * NULL and is not read */

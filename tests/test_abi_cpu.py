@@ -26,7 +26,7 @@ def test_header_symbols_all_exported_and_bound():
 
 def test_abi_version_and_error_strings():
     from computervision_codes_amd import _lib
-    assert _lib.lib.mt4_abi_version() == _lib.ABI_VERSION == 8
+    assert _lib.lib.mt4_abi_version() == _lib.ABI_VERSION == 9
     assert _lib.lib.mt4_strerror(0) == b"ok"
     assert b"invalid" in _lib.lib.mt4_strerror(-1)
 

@@ -90,6 +90,50 @@ def test_batchnorm_bf16_fwd_bwd(cuda, m, c, relu, res, xf32):
         assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout,k,s,dt,tile", [
+    (2, 24, 40, 64, 64, 1, 1, "bf16", 0), (2, 24, 40, 64, 256, 1, 1, "bf16", 0), (3, 13, 21, 128, 128, 3, 1, "bf16", 0), (8, 64, 112, 64, 64, 3, 1, "bf16", 0),
+    (2, 30, 52, 256, 512, 1, 2, "bf16", 0), (2, 24, 40, 64, 64, 1, 1, "bf16", 17), (2, 24, 40, 64, 128, 1, 1, "bf16", 5), (1, 40, 72, 4, 64, 7, 2, "f32", 0),
+    (2, 16, 20, 64, 72, 1, 1, "bf16", 0)])
+def test_conv_epilogue_statistics(cuda, b, h, w, cin, cout, k, s, dt, tile):
+    """`mt4_conv_desc.stat_sums`: the replicas add up to the float64 column sums / sums of squares of the map the launch stored (generic tiles,
+    the 3x3 patch kernel where it runs, the fp32 stem geometry, ragged last tiles and channel tiles), and `mt4_bn_apply_sums_t` equals
+    `mt4_bn_stats_t` + `mt4_bn_apply_t` on the stored map bit for bit"""
+    from computervision_codes_amd import ops
+    tdt = BF if dt == "bf16" else torch.float32
+    pad = k // 2
+    x = _rand((b, h, w, cin), 1).to(tdt).to(cuda)
+    wt = _rand((cout, cin, k, k), 2, 0.2).to(cuda)
+    wp = ops.pack_conv_weight(wt, None, tdt)
+    sums = torch.zeros((ops.STAT_REPLICAS, 2, cout), dtype=torch.float64, device=cuda)
+    y = ops.conv_nhwc(x, wp, None, kh=k, kw=k, stride=(s, s), pad=(pad, pad), stat_sums=sums, tile=tile)
+    y0 = ops.conv_nhwc(x, wp, None, kh=k, kw=k, stride=(s, s), pad=(pad, pad), tile=tile)
+    assert torch.equal(y, y0)
+    m = y.numel() // cout
+    yd = y.view(m, cout).double()
+    tot = sums.sum(0)
+    assert (tot[0] - yd.sum(0)).abs().max().item() <= 1e-12 * m * yd.abs().max().item()
+    assert (tot[1] - (yd * yd).sum(0)).abs().max().item() <= 1e-12 * m * yd.abs().max().item() ** 2
+    g, bt = _rand((cout,), 3).to(cuda) + 1.5, _rand((cout,), 4).to(cuda)
+    res = _rand((m, cout), 5).to(BF).to(cuda)
+    rm, rv = torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda)
+    rm0, rv0 = rm.clone(), rv.clone()
+    a, mean, invstd = ops.bn_apply_sums_t(y.view(m, cout), sums, g, bt, res, True, rm, rv)
+    mean0, invstd0 = ops.bn_stats_t(y.view(m, cout), rm0, rv0, sums=torch.zeros(2 * cout, dtype=torch.float64, device=cuda))
+    a0 = ops.bn_apply_t(y.view(m, cout), mean0, invstd0, g, bt, res, True)
+    assert torch.equal(mean, mean0) and torch.equal(invstd, invstd0) and torch.equal(rm, rm0) and torch.equal(rv, rv0) and torch.equal(a, a0)
+
+
+def test_conv_epilogue_statistics_refusals(cuda):
+    from computervision_codes_amd import _lib, ops
+    x = _rand((2, 16, 16, 64), 1).to(BF).to(cuda)
+    wp = ops.pack_conv_weight(_rand((64, 64, 1, 1), 2).to(cuda), None, BF)
+    sums = torch.zeros((ops.STAT_REPLICAS, 2, 64), dtype=torch.float64, device=cuda)
+    for tile in (-1, 40):                                           # K-split tiles keep no channel sums
+        with pytest.raises(_lib.Mt4Error):
+            ops.conv_nhwc(x, wp, None, kh=1, kw=1, stat_sums=sums, tile=tile)
+    assert float(sums.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("b,h,w,c", [(2, 13, 18, 64), (1, 40, 37, 128), (2, 13, 18, 8), (1, 32, 48, 64)])
 def test_maxpool_backward_bf16(cuda, b, h, w, c):
     """C % 64 == 0 runs the LDS-tiled kernel (several 16 x 16 tiles, ragged edges), other channel counts the per-pixel one"""
