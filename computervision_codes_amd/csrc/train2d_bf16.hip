@@ -318,10 +318,9 @@ struct WgK {
     int tiles_h, tiles_w, ntiles, nsplit, cin_tiles;
 };
 
-template <int K, int S, int TH, int BMT, int BNT>
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgK a) {
+template <int K, int S, int TH, int BMT, int BNT, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void wgrad_bf16_kernel(const WgK a) {
     constexpr bool PREFETCH = true;
-    static_assert(!(K == 3 && BMT * BNT > 1), "3x3: 64 x 64 tiles (registers)");
     constexpr int PAD = K / 2;
     constexpr int IW = S * 15 + K;                              // input pixels per tile row (with the column halo)
     constexpr int PITCH = (IW + 15) / 16 * 16;                  // pixels per LDS row of the input tile
@@ -463,23 +462,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgK a) {
                 }
 }
 
-template <int K, int S, int TH, int BMT, int BNT>
+template <int K, int S, int TH, int BMT, int BNT, int OCC = 2>
 int launch_wgrad(WgK a, hipStream_t stream) {
     constexpr int IW = S * 15 + K, PITCH = (IW + 15) / 16 * 16;
     constexpr int LDS = BMT * TH * 16 * WG_ROWB + BNT * TH * PITCH * WG_ROWB;
-    static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+    static_assert(LDS * OCC <= 160 * 1024, "OCC workgroups per CU");
     a.tiles_h = cdiv(a.Ho, TH);
     a.tiles_w = cdiv(a.Wo, 16);
     a.ntiles = a.B * a.tiles_h * a.tiles_w;
     a.cin_tiles = cdiv(a.Cin, 64 * BNT);
     const int pairs = cdiv(a.Cout, 64 * BMT) * a.cin_tiles * K;
     // workgroups per launch: every one ends with (64 BMT)(64 BNT) K fp32 atomics, so as few as keep the CUs busy (two per CU)
-    const int target = MT4_ENV_INT("MT4_WGRAD_WGS", 512);
+    const int target = MT4_ENV_INT("MT4_WGRAD_WGS", 256 * OCC);
     int nsplit = (target + pairs - 1) / pairs;
     if (nsplit > a.ntiles) nsplit = a.ntiles;
     if (nsplit < 1) nsplit = 1;
     a.nsplit = nsplit;
-    auto fn = wgrad_bf16_kernel<K, S, TH, BMT, BNT>;
+    auto fn = wgrad_bf16_kernel<K, S, TH, BMT, BNT, OCC>;
     MT4_RAISE_LDS(fn);
     hipLaunchKernelGGL(fn, dim3((unsigned)(pairs * nsplit)), dim3(256), LDS, stream, a);
     return mt4_check_launch();
@@ -802,9 +801,13 @@ extern "C" int mt4_wgrad_conv2d_bf16(const void* dy, const void* x, float* dw_pa
         if (m2) return launch_wgrad<1, 2, 8, 2, 1>(a, s);
         return launch_wgrad<1, 2, 8, 1, 1>(a, s);
     }
-    // 3x3: 64 x 64 per kernel row (K x 16 accumulator registers per wave leave room for the one-tile-ahead staging registers)
-    if (stride == 1) return launch_wgrad<3, 1, 8, 1, 1>(a, s);
-    return launch_wgrad<3, 2, 8, 1, 1>(a, s);
+    // 3x3: 64 x 64 per kernel row (K x 16 accumulator registers per wave leave room for the one-tile-ahead staging registers), tiles of 4 rows
+    // and THREE workgroups per CU: a workgroup waits out a load round trip per tile (request behind the barrier, needed at the next one), and
+    // with two per CU the matrix cores idled through most of it -- same-box, ResNet-50 b64 shapes: layer2 117 -> 84 us, layer3 115 -> 71,
+    // layer4 105 -> 69, the strided ones 142 -> 89 (profiles/r03_wgrad_experiments.txt).  The 1x1 forms spend ~45 % of their time in the
+    // closing fp32 atomics (one dword per clock and L2 channel): more workgroups mean more of those, and they stay at two per CU.
+    if (stride == 1) return launch_wgrad<3, 1, 4, 1, 1, 3>(a, s);
+    return launch_wgrad<3, 2, 4, 1, 1, 3>(a, s);
 }
 
 extern "C" int mt4_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
