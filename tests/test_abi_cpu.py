@@ -54,8 +54,9 @@ def test_ops_refuse_cpu_tensors():
 def test_struct_layout_matches_header():
     from computervision_codes_amd import _lib
     # 6 pointers + 24 int32 + fuse_cout + the three fuse pointers (8-byte aligned: 25 int32 pad to 104 bytes) + fuse_relu + residual_float
-    # + the second K source: x2 and its four int32, + fuse_expand (padded to 8 bytes)
-    assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 26 * 4 + 3 * 8 + 2 * 4 + 8 + 4 * 4 + 8
+    # + the second K source: x2 and its four int32, + fuse_expand (padded to 8 bytes) + stat_sums
+    assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 26 * 4 + 3 * 8 + 2 * 4 + 8 + 4 * 4 + 8 + 8
+    assert _lib.ConvDesc.stat_sums.offset == ctypes.sizeof(_lib.ConvDesc) - 8
     assert _lib.ConvDesc.fuse_w.offset == 6 * 8 + 26 * 4 and _lib.ConvDesc.fuse_relu.offset == 6 * 8 + 26 * 4 + 24
 
 
@@ -73,7 +74,7 @@ def test_integration_doc_struct_matches_header_mirror():
     struct = re.sub(r"/\*.*?\*/", "", struct, flags=re.S)
     fields = []
     for decl in struct.split(";"):
-        m = re.match(r"\s*(?:const\s+)?(?:void|float|int32_t)\s*\*?\s*(.+)$", decl.strip().replace("\n", " "))
+        m = re.match(r"\s*(?:const\s+)?(?:void|float|double|int32_t)\s*\*?\s*(.+)$", decl.strip().replace("\n", " "))
         if m:
             fields += [n.strip() for n in m.group(1).split(",")]
     assert fields == [f[0] for f in _lib.ConvDesc._fields_], fields
