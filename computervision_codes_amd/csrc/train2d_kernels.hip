@@ -9,13 +9,22 @@
 // The per-channel reductions of BatchNorm (these and the two of the backward) accumulate in float64: the kernels are
 // HBM-bound, CDNA4 runs fp64 VALU at half the fp32 rate, and E[x^2]-E[x]^2 as well as the backward's projections cancel
 // badly in fp32 -- torch's CPU BatchNorm (the reference's arithmetic) accumulates in double too.
-// Work split of the three reductions: a thread owns 4 consecutive channels (one 16-byte load per row), a workgroup 64 channels x 16
-// rows per iteration; gridDim.y row slabs per channel block.
+// Work split: a thread owns 4 consecutive channels (one 16-byte load per row) and walks rows; the reductions run 1024-thread workgroups
+// (64 channels x 64 row phases), at most ~512 per launch: every workgroup ends in 128 float64 atomics on its slab's 128 addresses, and 2048
+// workgroups of 256 threads on a 64-channel map made those same-address chains (~25 ns a link at the L2) longer than the stream itself
+// (profiles/r03_bn_training_kernels.txt; the bf16-tensor twins live in train2d_bf16.hip)
 __device__ __forceinline__ void bn_block_reduce(double (&acc)[8], double* __restrict__ sums, int C, int c0) {
-    __shared__ double red[16][8][17];               // [row lane][value][channel group], padded
-    const int cg = threadIdx.x & 15, r = threadIdx.x >> 4;
+    __shared__ double red[16][8][17];               // [wave][value][channel group], padded
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[r][j][cg] = acc[j];
+    for (int j = 0; j < 8; ++j) {                   // the 4 row phases of a wave
+        acc[j] += __shfl_xor(acc[j], 16);
+        acc[j] += __shfl_xor(acc[j], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[w][j][lane] = acc[j];
+    }
     __syncthreads();
     if (threadIdx.x < 128) {                        // 16 channel groups x 8 values
         const int g = threadIdx.x & 15, j = threadIdx.x >> 4;
@@ -27,19 +36,33 @@ __device__ __forceinline__ void bn_block_reduce(double (&acc)[8], double* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, long long M, int C) {
+__global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, long long M, int C) {
     const int c0 = blockIdx.x * 64, c = c0 + (threadIdx.x & 15) * 4;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (c < C)
-        for (long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4); m < M; m += (long long)gridDim.y * 16) {
-            const float4 v = *(const float4*)(x + m * C + c);
+    if (c < C) {
+        const long long st = (long long)gridDim.y * 64;
+        long long m = (long long)blockIdx.y * 64 + (threadIdx.x >> 4);
+        auto add = [&](const float4 v) {
             acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
             acc[4] += (double)v.x * v.x; acc[5] += (double)v.y * v.y; acc[6] += (double)v.z * v.z; acc[7] += (double)v.w * v.w;
+        };
+        for (; m + st < M; m += 2 * st) {           // two rows in flight, added in ascending order
+            const float4 v0 = *(const float4*)(x + m * C + c), v1 = *(const float4*)(x + (m + st) * C + c);
+            add(v0); add(v1);
         }
+        for (; m < M; m += st) add(*(const float4*)(x + m * C + c));
+    }
     bn_block_reduce(acc, sums, C, c0);
 }
 
-static inline int bn_row_slabs(long long M, int C) {
+static inline int bn_reduce_slabs(long long M, int C) {                      // 64-row slabs of the 1024-thread reductions
+    long long gy = (M + 63) / 64;
+    const long long cap = (512 + cdiv(C, 64) - 1) / cdiv(C, 64);
+    if (gy > cap) gy = cap;
+    return gy < 1 ? 1 : (int)gy;
+}
+
+static inline int bn_row_slabs(long long M, int C) {                         // 16-row slabs of the 256-thread streaming kernels
     long long gy = (M + 63) / 64;
     const long long cap = (2048 + cdiv(C, 64) - 1) / cdiv(C, 64);
     if (gy > cap) gy = cap;
@@ -68,26 +91,41 @@ extern "C" int mt4_bn_stats_f32(const float* x, double* sums_zeroed, float* mean
     if (!x || !sums_zeroed || !mean || !invstd || M <= 0 || C <= 0) return MT4_EINVAL;
     if (C % 4) return MT4_EALIGN;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(C, 64), bn_row_slabs(M, C)), dim3(256), 0, s, x, sums_zeroed, (long long)M, C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(C, 64), bn_reduce_slabs(M, C)), dim3(1024), 0, s, x, sums_zeroed, (long long)M, C);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, sums_zeroed, mean, invstd, running_mean, running_var,
                        (long long)M, C, momentum, eps);
     return mt4_check_launch();
 }
 
-// y = act( (x - mean) * invstd * gamma + beta [+ residual] )
-__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res,
-                                float* __restrict__ y, long long n4, int C, int relu) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    const int c = (int)((i * 4) % C);
-    const float4 xv = *(const float4*)(x + i * 4);
+// y = act( (x - mean) * invstd * gamma + beta [+ residual] ): column slabs, the 4 channels' parameters in registers (one element group per
+// thread re-loaded 64 bytes of parameters per 16 bytes of tensor traffic); the same expressions, the same bits
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res,
+                                                       float* __restrict__ y, long long M, int C, int relu) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
+    if (c >= C) return;
     const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c), g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
-    float4 o = make_float4((xv.x - mu.x) * is.x * g.x + b.x, (xv.y - mu.y) * is.y * g.y + b.y, (xv.z - mu.z) * is.z * g.z + b.z,
-                           (xv.w - mu.w) * is.w * g.w + b.w);
-    if (res) { const float4 r = *(const float4*)(res + i * 4); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
-    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    *(float4*)(y + i * 4) = o;
+    const long long st = (long long)gridDim.y * 16;
+    long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto put = [&](long long i, const float4 xv, const float4 r) {
+        float4 o = make_float4((xv.x - mu.x) * is.x * g.x + b.x, (xv.y - mu.y) * is.y * g.y + b.y, (xv.z - mu.z) * is.z * g.z + b.z,
+                               (xv.w - mu.w) * is.w * g.w + b.w);
+        if (res) { o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *(float4*)(y + i) = o;
+    };
+    for (; m + st < M; m += 2 * st) {
+        const long long i0 = m * C + c, i1 = (m + st) * C + c;
+        const float4 x0 = *(const float4*)(x + i0), x1 = *(const float4*)(x + i1);
+        float4 r0 = zero, r1 = zero;
+        if (res) { r0 = *(const float4*)(res + i0); r1 = *(const float4*)(res + i1); }
+        put(i0, x0, r0); put(i1, x1, r1);
+    }
+    for (; m < M; m += st) {
+        const long long i0 = m * C + c;
+        put(i0, *(const float4*)(x + i0), res ? *(const float4*)(res + i0) : zero);
+    }
 }
 
 extern "C" int mt4_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
@@ -95,25 +133,24 @@ extern "C" int mt4_bn_apply_f32(const float* x, const float* mean, const float* 
     mt4_clear_error();
     if (!x || !mean || !invstd || !gamma || !beta || !y || M <= 0 || C <= 0) return MT4_EINVAL;
     if (C % 4) return MT4_EALIGN;
-    const long long n4 = M * C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, residual,
-                       y, n4, C, relu);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(C, 64), bn_row_slabs(M, C)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, residual,
+                       y, (long long)M, C, relu);
     return mt4_check_launch();
 }
 
 // backward pass 1: with dy' = relu ? (y > 0 ? dy : 0) : dy :  sums[0][c] += sum dy',  sums[1][c] += sum dy' * xhat
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                            const float* __restrict__ x, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, double* __restrict__ sums, long long M, int C, int relu) {
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             const float* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, double* __restrict__ sums, long long M, int C, int relu) {
     const int c0 = blockIdx.x * 64, c = c0 + (threadIdx.x & 15) * 4;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (c < C) {
         const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
-        for (long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4); m < M; m += (long long)gridDim.y * 16) {
-            float4 g = *(const float4*)(dy + m * C + c);
-            const float4 xv = *(const float4*)(x + m * C + c);
+        const long long st = (long long)gridDim.y * 64;
+        long long m = (long long)blockIdx.y * 64 + (threadIdx.x >> 4);
+        const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+        auto add = [&](float4 g, const float4 xv, const float4 yv) {
             if (relu) {
-                const float4 yv = *(const float4*)(y + m * C + c);
                 if (!(yv.x > 0.f)) g.x = 0.f;
                 if (!(yv.y > 0.f)) g.y = 0.f;
                 if (!(yv.z > 0.f)) g.z = 0.f;
@@ -122,6 +159,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             acc[0] += (double)g.x; acc[1] += (double)g.y; acc[2] += (double)g.z; acc[3] += (double)g.w;
             acc[4] += (double)g.x * (double)((xv.x - mu.x) * is.x); acc[5] += (double)g.y * (double)((xv.y - mu.y) * is.y);
             acc[6] += (double)g.z * (double)((xv.z - mu.z) * is.z); acc[7] += (double)g.w * (double)((xv.w - mu.w) * is.w);
+        };
+        for (; m + st < M; m += 2 * st) {
+            const long long i0 = m * C + c, i1 = (m + st) * C + c;
+            const float4 g0 = *(const float4*)(dy + i0), g1 = *(const float4*)(dy + i1);
+            const float4 x0 = *(const float4*)(x + i0), x1 = *(const float4*)(x + i1);
+            float4 y0 = one, y1 = one;
+            if (relu) { y0 = *(const float4*)(y + i0); y1 = *(const float4*)(y + i1); }
+            add(g0, x0, y0); add(g1, x1, y1);
+        }
+        for (; m < M; m += st) {
+            const long long i0 = m * C + c;
+            add(*(const float4*)(dy + i0), *(const float4*)(x + i0), relu ? *(const float4*)(y + i0) : one);
         }
     }
     bn_block_reduce(acc, sums, C, c0);
@@ -129,31 +178,53 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 // backward pass 2: dx = gamma * invstd * (dy' - sum(dy')/M - xhat * sum(dy' xhat)/M);  dres = dy' (gradient of the residual input);
 // dgamma = sums[1], dbeta = sums[0]
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const double* __restrict__ sums, float* __restrict__ dx, float* __restrict__ dres, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, long long M, int C, int relu) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 (4 channels of one row) per thread
-    if (i < C) { dbeta[i] = (float)sums[i]; dgamma[i] = (float)sums[C + i]; }
-    if (i >= M * C / 4) return;
-    const int c = (int)((i * 4) % C);
-    float4 g = *(const float4*)(dy + i * 4);
-    if (relu) {
-        const float4 yv = *(const float4*)(y + i * 4);
-        if (!(yv.x > 0.f)) g.x = 0.f;
-        if (!(yv.y > 0.f)) g.y = 0.f;
-        if (!(yv.z > 0.f)) g.z = 0.f;
-        if (!(yv.w > 0.f)) g.w = 0.f;
-    }
-    const float4 xv = *(const float4*)(x + i * 4), mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c), ga = *(const float4*)(gamma + c);
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const double* __restrict__ sums, float* __restrict__ dx,
+                                                           float* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta, long long M,
+                                                           int C, int relu) {
+    // column slabs: the parameters and the two per-channel means of the reduction stay in registers
+    const int c = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
+    if (c >= C) return;
     const double invM = 1.0 / (double)M;
-    float4 o;
-    o.x = ga.x * is.x * (g.x - (float)(sums[c] * invM) - (xv.x - mu.x) * is.x * (float)(sums[C + c] * invM));
-    o.y = ga.y * is.y * (g.y - (float)(sums[c + 1] * invM) - (xv.y - mu.y) * is.y * (float)(sums[C + c + 1] * invM));
-    o.z = ga.z * is.z * (g.z - (float)(sums[c + 2] * invM) - (xv.z - mu.z) * is.z * (float)(sums[C + c + 2] * invM));
-    o.w = ga.w * is.w * (g.w - (float)(sums[c + 3] * invM) - (xv.w - mu.w) * is.w * (float)(sums[C + c + 3] * invM));
-    *(float4*)(dx + i * 4) = o;
-    if (dres) *(float4*)(dres + i * 4) = g;
+    const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c), ga = *(const float4*)(gamma + c);
+    const float4 m1 = make_float4((float)(sums[c] * invM), (float)(sums[c + 1] * invM), (float)(sums[c + 2] * invM), (float)(sums[c + 3] * invM));
+    const float4 m2 = make_float4((float)(sums[C + c] * invM), (float)(sums[C + c + 1] * invM), (float)(sums[C + c + 2] * invM),
+                                  (float)(sums[C + c + 3] * invM));
+    if (blockIdx.y == 0 && (threadIdx.x >> 4) == 0) {
+        *(float4*)(dbeta + c) = make_float4((float)sums[c], (float)sums[c + 1], (float)sums[c + 2], (float)sums[c + 3]);
+        *(float4*)(dgamma + c) = make_float4((float)sums[C + c], (float)sums[C + c + 1], (float)sums[C + c + 2], (float)sums[C + c + 3]);
+    }
+    const long long st = (long long)gridDim.y * 16;
+    long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4);
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+    auto put = [&](long long i, float4 g, const float4 xv, const float4 yv) {
+        if (relu) {
+            if (!(yv.x > 0.f)) g.x = 0.f;
+            if (!(yv.y > 0.f)) g.y = 0.f;
+            if (!(yv.z > 0.f)) g.z = 0.f;
+            if (!(yv.w > 0.f)) g.w = 0.f;
+        }
+        float4 o;
+        o.x = ga.x * is.x * (g.x - m1.x - (xv.x - mu.x) * is.x * m2.x);
+        o.y = ga.y * is.y * (g.y - m1.y - (xv.y - mu.y) * is.y * m2.y);
+        o.z = ga.z * is.z * (g.z - m1.z - (xv.z - mu.z) * is.z * m2.z);
+        o.w = ga.w * is.w * (g.w - m1.w - (xv.w - mu.w) * is.w * m2.w);
+        *(float4*)(dx + i) = o;
+        if (dres) *(float4*)(dres + i) = g;
+    };
+    for (; m + st < M; m += 2 * st) {
+        const long long i0 = m * C + c, i1 = (m + st) * C + c;
+        const float4 g0 = *(const float4*)(dy + i0), g1 = *(const float4*)(dy + i1);
+        const float4 x0 = *(const float4*)(x + i0), x1 = *(const float4*)(x + i1);
+        float4 y0 = one, y1 = one;
+        if (relu) { y0 = *(const float4*)(y + i0); y1 = *(const float4*)(y + i1); }
+        put(i0, g0, x0, y0); put(i1, g1, x1, y1);
+    }
+    for (; m < M; m += st) {
+        const long long i0 = m * C + c;
+        put(i0, *(const float4*)(dy + i0), *(const float4*)(x + i0), relu ? *(const float4*)(y + i0) : one);
+    }
 }
 
 extern "C" int mt4_bn_backward_f32(const float* dy, const float* y_post, const float* x, const float* mean, const float* invstd,
@@ -164,11 +235,9 @@ extern "C" int mt4_bn_backward_f32(const float* dy, const float* y_post, const f
     if (relu && !y_post) return MT4_EINVAL;
     if (C % 4) return MT4_EALIGN;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), bn_row_slabs(M, C)), dim3(256), 0, s, dy, y_post, x, mean, invstd, sums_zeroed,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), bn_reduce_slabs(M, C)), dim3(1024), 0, s, dy, y_post, x, mean, invstd, sums_zeroed,
                        (long long)M, C, relu);
-    long long n = M * C / 4;
-    if (n < C) n = C;                               // the first C threads also publish dgamma / dbeta
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, y_post, x, mean, invstd, gamma, sums_zeroed, dx,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(C, 64), bn_row_slabs(M, C)), dim3(256), 0, s, dy, y_post, x, mean, invstd, gamma, sums_zeroed, dx,
                        dres, dgamma, dbeta, (long long)M, C, relu);
     return mt4_check_launch();
 }
