@@ -5,7 +5,9 @@ Component disentangling (`compute_video_AP('i'|'v'|'t'|'iv'|'it')` on the 100-wa
 class takes the MAX over the triplets that contain it, for scores and labels alike, through the CholecT45/T50 triplet dictionary
 (the table of `Spatial_cnn/maps.txt`, which no reference code reads -- ivtmetrics bundles the same one).
 PARITY UNPINNED: ivtmetrics is not installed and the reference holds no fixture for it; pinned here against sklearn
-and hand-built cases only.  `ignore_null=True` (challenge protocol, off for every shipped recipe) is not restated."""
+and hand-built cases only.  `ignore_null=True` (the CholecTriplet challenge protocol, off for every shipped recipe): restated from ivtmetrics'
+published behaviour -- the six null triplets (instrument, null_verb, null_target), ids 94-99, are dropped from the 100-way scores before the
+AP; other components ignore the flag -- equally unpinned."""
 from __future__ import annotations
 
 import warnings
@@ -27,6 +29,10 @@ _TRIPLETS = (
     (4,4,4), (4,4,1), (5,6,6), (5,2,2), (5,2,4), (5,2,1), (5,2,0), (5,2,10), (5,7,7), (5,7,4),
     (5,7,8), (5,1,0), (5,1,8), (5,1,10), (0,9,14), (1,9,14), (2,9,14), (3,9,14), (4,9,14), (5,9,14),
 )
+
+
+N_NULL_TRIPLETS = sum(1 for (_, v, t) in _TRIPLETS if v == 9 and t == 14)      # the last 6 ids: (instrument, null_verb, null_target)
+assert all(v == 9 and t == 14 for (_, v, t) in _TRIPLETS[-N_NULL_TRIPLETS:]) and N_NULL_TRIPLETS == 6
 
 
 def _component_index(component: str) -> np.ndarray:
@@ -77,11 +83,11 @@ class Recognition:
         return out
 
     def compute_video_AP(self, component: str = "ivt", ignore_null: bool = False):
-        if ignore_null:
-            raise NotImplementedError("challenge-protocol null filtering is not restated (off in every shipped recipe)")
         if component != "ivt" and self.num_class != 100:
             raise ValueError("component disentangling needs the 100-way triplet scores")
-        per_video = [self._ap_per_class(disentangle(t, component), disentangle(p, component))
+        drop = N_NULL_TRIPLETS if (ignore_null and component == "ivt" and self.num_class == 100) else 0
+        cut = (lambda a: a[:, :a.shape[1] - drop]) if drop else (lambda a: a)
+        per_video = [self._ap_per_class(cut(disentangle(t, component)), cut(disentangle(p, component)))
                      for t, p in zip(self.global_targets, self.global_predictions)]
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", category=RuntimeWarning)

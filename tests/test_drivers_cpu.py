@@ -109,3 +109,18 @@ def test_recognition_component_disentangling():
         per_video.append([average_precision_score(yv[sl, c], pv[sl, c]) if yv[sl, c].sum() > 0 else np.nan for c in range(10)])
     want = np.nanmean(np.array(per_video), axis=0)
     assert np.allclose(got["AP"], want, equal_nan=True) and abs(got["mAP"] - np.nanmean(want)) < 1e-12
+
+
+def test_recognition_ignore_null_drops_the_six_null_triplets():
+    """challenge protocol: the null triplets (ids 94-99) leave the 100-way AP; component APs ignore the flag (restated, parity unpinned)"""
+    from computervision_codes_amd.metrics import Recognition, N_NULL_TRIPLETS
+    rng = np.random.default_rng(1)
+    y = (rng.random((60, 100)) < 0.08).astype(np.float64)
+    p = rng.random((60, 100))
+    m = Recognition(100)
+    m.update(y[:30], p[:30]); m.video_end()
+    m.update(y[30:], p[30:]); m.video_end()
+    full, cut = m.compute_video_AP("ivt"), m.compute_video_AP("ivt", ignore_null=True)
+    assert N_NULL_TRIPLETS == 6 and cut["AP"].shape == (94,) and np.allclose(cut["AP"], full["AP"][:94], equal_nan=True)
+    assert abs(cut["mAP"] - np.nanmean(full["AP"][:94])) < 1e-12 and cut["mAP"] != full["mAP"]
+    assert np.allclose(m.compute_video_AP("v", ignore_null=True)["AP"], m.compute_video_AP("v")["AP"], equal_nan=True)
