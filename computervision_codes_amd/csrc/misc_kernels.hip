@@ -3,7 +3,7 @@
 
 thread_local int g_mt4_last_hip_error = 0;
 
-extern "C" int mt4_abi_version(void) { return 9; }   // 6: + mt4_stem_maxpool_bf16, mt4_conv_desc.x2 (second K source), mt4_bottleneck_fused_next_bf16; 7: + mt4_copy_spans_u8; 8: + mt4_chain_gemm_bf16; 9: + mt4_conv_desc.stat_partials, mt4_bn_finalize_partials, mt4_refresh_weights moves MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup
+extern "C" int mt4_abi_version(void) { return 9; }   // 6: + mt4_stem_maxpool_bf16, mt4_conv_desc.x2 (second K source), mt4_bottleneck_fused_next_bf16; 7: + mt4_copy_spans_u8; 8: + mt4_chain_gemm_bf16; 9: + mt4_conv_desc.stat_sums, mt4_bn_apply_sums_t, mt4_refresh_weights moves MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup, mt4_avgpool1d_rows, mt4_interp_linear_rows
 extern "C" int mt4_last_hip_error(void) { return g_mt4_last_hip_error; }
 extern "C" const char* mt4_strerror(int code) {
     switch (code) {
@@ -357,5 +357,80 @@ extern "C" int mt4_linear_f32(const float* x, const float* w, const float* bias,
     if (!x || !w || !y || B <= 0 || K <= 0 || N <= 0) return MT4_EINVAL;
     if ((K & 3) == 0 && (((uintptr_t)x | (uintptr_t)w) & 15)) return MT4_EALIGN;
     hipLaunchKernelGGL(linear_f32_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, K, N);
+    return mt4_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ `--hier` of Temporal_tenco: pooling between the
+// refinement stages (Temporal_tenco/network.py:147,154-155: nn.AvgPool1d(kernel_size=7, stride=3)) and the FPN's linear re-interpolation to the
+// lateral's length (network.py:96: F.interpolate(x, size=W, mode='linear'), align_corners False), both over the time axis of frame-major rows
+namespace {
+template <typename T> __device__ __forceinline__ float4 ldrow4(const T* p);
+template <> __device__ __forceinline__ float4 ldrow4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ __forceinline__ float4 ldrow4<u16>(const u16* p) {
+    const uint2 v = *(const uint2*)p;
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void strow4(T* p, float4 v);
+template <> __device__ __forceinline__ void strow4<float>(float* p, float4 v) { *(float4*)p = v; }
+template <> __device__ __forceinline__ void strow4<u16>(u16* p, float4 v) { *(uint2*)p = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+
+template <typename T>
+__global__ void avgpool1d_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int Tin, int Tout, int C, int k, int stride, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = C >> 2;
+    const int c = (int)(i % c4) * 4;
+    const long long r = i / c4;
+    const int to = (int)(r % Tout);
+    const long long b = r / Tout;
+    const T* src = x + (b * Tin + (long long)to * stride) * C + c;
+    float4 s = ldrow4<T>(src);
+    for (int j = 1; j < k; ++j) { const float4 v = ldrow4<T>(src + (long long)j * C); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    const float d = (float)k;
+    strow4<T>(y + r * C + c, make_float4(s.x / d, s.y / d, s.z / d, s.w / d));
+}
+
+template <typename T>
+__global__ void interp_linear_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int Tin, int Tout, int C, float scale, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = C >> 2;
+    const int c = (int)(i % c4) * 4;
+    const long long r = i / c4;
+    const int w = (int)(r % Tout);
+    const long long b = r / Tout;
+    float src = scale * ((float)w + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    const int i0 = (int)src;
+    const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+    const float l1 = src - (float)i0, l0 = 1.f - l1;
+    const float4 a = ldrow4<T>(x + (b * Tin + i0) * C + c), v = ldrow4<T>(x + (b * Tin + i1) * C + c);
+    strow4<T>(y + r * C + c, make_float4(l0 * a.x + l1 * v.x, l0 * a.y + l1 * v.y, l0 * a.z + l1 * v.z, l0 * a.w + l1 * v.w));
+}
+}  // namespace
+
+extern "C" int mt4_avgpool1d_rows(const void* x, void* y, int32_t B, int32_t Tin, int32_t C, int32_t k, int32_t stride, int32_t dtype, void* stream) {
+    mt4_clear_error();
+    if (!x || !y || B <= 0 || Tin <= 0 || C <= 0 || k <= 0 || stride <= 0 || Tin < k) return MT4_EINVAL;
+    if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    if ((C & 3) || (((uintptr_t)x | (uintptr_t)y) & 15) || (dtype == MT4_BF16 && (C & 7))) return MT4_EALIGN;
+    const int Tout = (Tin - k) / stride + 1;
+    const long long n4 = (long long)B * Tout * (C >> 2);
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    if (dtype == MT4_F32) hipLaunchKernelGGL(avgpool1d_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, Tin, Tout, C, k, stride, n4);
+    else hipLaunchKernelGGL(avgpool1d_rows_kernel<u16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, (u16*)y, Tin, Tout, C, k, stride, n4);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_interp_linear_rows(const void* x, void* y, int32_t B, int32_t Tin, int32_t Tout, int32_t C, int32_t dtype, void* stream) {
+    mt4_clear_error();
+    if (!x || !y || B <= 0 || Tin <= 0 || Tout <= 0 || C <= 0) return MT4_EINVAL;
+    if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
+    if ((C & 3) || (((uintptr_t)x | (uintptr_t)y) & 15) || (dtype == MT4_BF16 && (C & 7))) return MT4_EALIGN;
+    const long long n4 = (long long)B * Tout * (C >> 2);
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    const float scale = (float)Tin / (float)Tout;
+    if (dtype == MT4_F32) hipLaunchKernelGGL(interp_linear_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, Tin, Tout, C, scale, n4);
+    else hipLaunchKernelGGL(interp_linear_rows_kernel<u16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, (u16*)y, Tin, Tout, C, scale, n4);
     return mt4_check_launch();
 }

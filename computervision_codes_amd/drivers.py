@@ -326,6 +326,9 @@ def _tenco_train(F):
     modelname = f"{F.model}_l8_cholect{F.dataset_variant}_k{F.kfold}_batchnorm_lowres"
     model_dir = f"./__checkpoint__/run_{F.version}"
     logfile = os.path.join(model_dir, modelname + ".log")
+    if getattr(F, "hier", False):
+        raise NotImplementedError("--hier True (pooled refinement levels, Temporal_tenco/network.py:154-155) is built for inference (temporal_tenco.VideoNas); "
+                                  "the HIP training step covers the shipped recipe (Scripts/train_fold1.sh: no --hier)")
     if not F.fpn:
         # the reference's own train loop cannot run a model without --fpn: `out_list_i / _v / _t` stay empty (`network.py:56-66`), so `loss_i`,
         # `loss_v`, `loss_t` stay the int 0 they start as (`run.py:190`) and `loss_i.item()` raises AttributeError at `run.py:214` in the first step

@@ -853,6 +853,26 @@ def kd_mix_bwd(s, teas, gs):
 BF16 = torch.bfloat16
 
 
+def avgpool1d_rows(x: torch.Tensor, k: int = 7, stride: int = 3) -> torch.Tensor:
+    """nn.AvgPool1d(k, stride) over the time axis of frame-major rows x [B, T, C] (`Temporal_tenco/network.py:147,154-155`)"""
+    _need_cuda(x)
+    assert x.dim() == 3 and x.is_contiguous()
+    b, t, c = x.shape
+    y = torch.empty((b, (t - k) // stride + 1, c), dtype=x.dtype, device=x.device)
+    check(lib.mt4_avgpool1d_rows(x.data_ptr(), y.data_ptr(), b, t, c, k, stride, dt_code(x.dtype), _stream()), "mt4_avgpool1d_rows")
+    return y
+
+
+def interp_linear_rows(x: torch.Tensor, t_out: int) -> torch.Tensor:
+    """F.interpolate(x, size=t_out, mode='linear') over the time axis of frame-major rows x [B, T, C] (`Temporal_tenco/network.py:96`)"""
+    _need_cuda(x)
+    assert x.dim() == 3 and x.is_contiguous()
+    b, t, c = x.shape
+    y = torch.empty((b, t_out, c), dtype=x.dtype, device=x.device)
+    check(lib.mt4_interp_linear_rows(x.data_ptr(), y.data_ptr(), b, t, t_out, c, dt_code(x.dtype), _stream()), "mt4_interp_linear_rows")
+    return y
+
+
 def bn_stats_t(x2d, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, sums=None):
     """`bn_stats` for a bf16 (or fp32) convolution output"""
     _need_cuda(x2d)

@@ -30,8 +30,9 @@ TCN_PATH_MAX_ROWS = {torch.float32: 896, torch.bfloat16: 640}
 class VideoNas:
     """Drop-in for `Temporal_tenco.network.VideoNas` (inference path; eval semantics).
 
-    args needs: fpn, output, hier (only output=False / hier=False -- what every shipped script uses --
-    are implemented; the others raise).
+    args needs: fpn, output, hier.  output=False is what every shipped script uses and the only form the reference itself can run at the
+    shipped widths (True raises here, naming the lines); hier=True (AvgPool1d(7, 3) behind every refinement stage, linear re-interpolation
+    in the FPN: `network.py:147,154-155,96`; set by no shipped script) runs on the implicit-GEMM path.
     """
 
     def __init__(self, args, num_layers_PG, num_layers_R, num_R, num_f_maps, dim, num_classes, num_i=6, num_v=10,
@@ -41,10 +42,11 @@ class VideoNas:
         self.dtype = dtype
         assert path in ("auto", "tcn", "igemm")
         self.path = path
-        if getattr(args, "output", False) or getattr(args, "hier", False):
-            raise NotImplementedError("--output / --hier are never set by the shipped scripts (Scripts/*.sh).  --output cannot run in the reference at "
-                                      "the shipped widths (Refinement.conv_1x1 takes num_classes channels, network.py:141, and is handed the "
-                                      "num_f_maps-channel feature, :58,150-151); --hier (AvgPool1d(7,3) between stages, :154-155) is not built")
+        if getattr(args, "output", False):
+            raise NotImplementedError("--output is never set by the shipped scripts (Scripts/*.sh) and cannot run in the reference at the shipped widths "
+                                      "(Refinement.conv_1x1 takes num_classes channels, network.py:141, and is handed the num_f_maps-channel "
+                                      "feature, :58,150-151)")
+        self.hier = bool(getattr(args, "hier", False))
         self.args = args
         self.use_fpn = bool(getattr(args, "fpn", False))
         self.num_layers_PG, self.num_layers_R, self.num_R = num_layers_PG, num_layers_R, num_R
@@ -174,6 +176,48 @@ class VideoNas:
         f_ref = [as_ref(ff) for ff in f_list]
         return out_list, out_i, out_v, out_t, f_ref, f_ref
 
+    def _forward_hier(self, x: torch.Tensor):
+        """`--hier True`: every refinement stage ends in AvgPool1d(7, 3) (`network.py:147,154-155`), so level l has its own length T_l and the
+        FPN's `F.interpolate(x, size=W, mode='linear')` (:96) resamples.  x [B,T,D] of self.dtype"""
+        b, t, _ = x.shape
+        p = self._p
+        as_ref = lambda y, tl: y.view(b, tl, -1).permute(0, 2, 1)
+        f = self._stage(self._c1(x.view(b, 1, t, self.D), "PG.conv_1x1"), "PG", self.num_layers_PG)
+        levels = [(f, t)]
+        out_list: List[torch.Tensor] = []
+        out_i: List[torch.Tensor] = []
+        out_v: List[torch.Tensor] = []
+        out_t: List[torch.Tensor] = []
+        if not self.use_fpn:
+            out_list.append(as_ref(ops.conv_nhwc(f, p["PG.conv_out.w"], p["PG.conv_out.b"], kh=1, kw=1, out_dtype=torch.float32), t))
+        tl = t
+        for r in range(self.num_R):
+            if tl < 7:
+                raise ValueError(f"--hier: level {r + 1} would pool {tl} < 7 frames (AvgPool1d(7, 3))")
+            g = self._stage(f, f"Rs.{r}", self.num_layers_R)
+            f = ops.avgpool1d_rows(g.view(b, tl, self.C), 7, 3)
+            tl = f.shape[1]
+            f = f.view(b, 1, tl, self.C)
+            levels.append((f, tl))
+        if self.use_fpn:
+            # p_l = interpolate(p_{l+1} -> T_l) + latlayer1(c_l)   (`FPN.forward`, :98-106: latlayer1 serves every lateral)
+            top, ttop = levels[-1]
+            ps = [(top, ttop)]
+            for c, tc in reversed(levels[:-1]):
+                up = ops.interp_linear_rows(top.view(b, ttop, self.C), tc).view(b, 1, tc, self.C)
+                top, ttop = self._c1(c, "fpn.latlayer1", residual=up), tc
+                ps.append((top, ttop))
+            levels = ps[::-1]
+            k0, k1, k2, k3 = self.head_sizes
+            for lvl, tlv in levels:
+                y = as_ref(ops.conv_nhwc(lvl, p["heads.w"], p["heads.b"], kh=1, kw=1, out_dtype=torch.float32), tlv)
+                out_list.append(y[:, :k0])
+                out_i.append(y[:, k0:k0 + k1])
+                out_v.append(y[:, k0 + k1:k0 + k1 + k2])
+                out_t.append(y[:, k0 + k1 + k2:])
+        f_ref = [as_ref(ff, tlv) for ff, tlv in levels]
+        return out_list, out_i, out_v, out_t, f_ref, f_ref
+
     @ops.with_latency_tiles
     def forward(self, x: torch.Tensor, ismask: bool = False):
         """x [B,T,D] float32 on the GPU.  Returns (out_list, out_list_i, out_list_v, out_list_t, f_list, f_list)
@@ -184,6 +228,8 @@ class VideoNas:
             raise RuntimeError("load_state_dict first")
         assert x.dim() == 3 and x.shape[2] == self.D and x.dtype == torch.float32
         b, t, _ = x.shape
+        if self.hier:
+            return self._forward_hier(x.contiguous().to(self.dtype))
         if self._use_tcn_path(b * t):
             return self._forward_tcn(x.contiguous().to(self.dtype))
         x4 = x.contiguous().to(self.dtype).view(b, 1, t, self.D)

@@ -32,7 +32,7 @@ extern "C" {
 
 /* 9 in this revision (5 -> 6: mt4_stem_maxpool_bf16, mt4_bottleneck_fused_next_bf16, mt4_pack_fragments_bf16, the x2 / fuse_expand fields at the
  * end of mt4_conv_desc; 6 -> 7: mt4_copy_spans_u8; 7 -> 8: mt4_chain_gemm_bf16; 8 -> 9: stat_sums at the end of
- * mt4_conv_desc, mt4_bn_apply_sums_t, MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup in mt4_refresh_weights).  A binding checks it once at load
+ * mt4_conv_desc, mt4_bn_apply_sums_t, mt4_avgpool1d_rows, mt4_interp_linear_rows, MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup in mt4_refresh_weights).  A binding checks it once at load
  * (computervision_codes_amd/_lib.py: ABI_VERSION). */
 int mt4_abi_version(void);
 const char* mt4_strerror(int code);
@@ -455,6 +455,13 @@ int mt4_tcn_stage(const void* x, void* buf_a, void* buf_b, void* h, void* y, con
 /* FPN top-down pathway at equal lengths (network.py:93-106; `F.interpolate(x, size=W, mode='linear')` to the same length is the
  * identity): levels[l] = lat[l] + levels[l+1] for l = nlev-2 .. 0, in place.  lat [nlev-1][n], levels [nlev][n] of dtype, n % 4 == 0. */
 int mt4_fpn_topdown(const void* lat, void* levels, int32_t nlev, int64_t n, int32_t dtype, void* stream);
+/* `--hier True` of Temporal_tenco, both over the time axis of frame-major rows x [B][Tin][C] (fp32 or bf16; C % 4 == 0, bf16 C % 8 == 0):
+ * mt4_avgpool1d_rows: nn.AvgPool1d(k, stride) between the refinement stages (network.py:147,154-155: k = 7, stride = 3),
+ *   y [B][(Tin - k) / stride + 1][C], sum of the k rows then one division;
+ * mt4_interp_linear_rows: F.interpolate(x, size = Tout, mode = 'linear') (align_corners False) of the FPN's `_upsample_add` (network.py:96),
+ *   y [B][Tout][C]: source index max(0, (Tin / Tout)(w + 0.5) - 0.5), the two neighbours weighted by its fraction. */
+int mt4_avgpool1d_rows(const void* x, void* y, int32_t B, int32_t Tin, int32_t C, int32_t k, int32_t stride, int32_t dtype, void* stream);
+int mt4_interp_linear_rows(const void* x, void* y, int32_t B, int32_t Tin, int32_t Tout, int32_t C, int32_t dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward pieces of the transformer-shaped temporal teacher MS-TCT (what torch autograd derives inside

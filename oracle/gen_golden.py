@@ -59,7 +59,7 @@ def _ref_tenco(cfg):
         mod = _load_by_path("ref_tenco_network", os.path.join(REF, "Temporal_tenco", "network.py"))
     finally:
         sys.path.pop(0)
-    args = types.SimpleNamespace(fpn=cfg["fpn"], output=False, feature=False, trans=False, mask=True, hier=False)
+    args = types.SimpleNamespace(fpn=cfg["fpn"], output=False, feature=False, trans=False, mask=True, hier=cfg.get("hier", False))
     m = mod.VideoNas(args, cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["num_f_maps"], cfg["dim"], 100)
     return m.eval()
 
@@ -73,6 +73,10 @@ TENCO_CASES = {
     "tenco_config1": dict(num_layers_PG=11, num_layers_R=10, num_R=0, num_f_maps=512, dim=2048, fpn=False, T=256, seed=47),
     # shipped student head: 4 stages + FPN, D=512, T=256
     "tenco_4stage": dict(num_layers_PG=11, num_layers_R=10, num_R=3, num_f_maps=512, dim=512, fpn=True, T=256, seed=47),
+    # `--hier True`: AvgPool1d(7, 3) behind every refinement stage (T = 301 -> 99 -> 31 -> 9), linear re-interpolation in the FPN
+    "tenco_hier": dict(num_layers_PG=6, num_layers_R=5, num_R=3, num_f_maps=64, dim=64, fpn=True, hier=True, T=301, seed=49),
+    # the shipped widths with hier, a ragged length
+    "tenco_hier_4stage": dict(num_layers_PG=11, num_layers_R=10, num_R=3, num_f_maps=512, dim=512, fpn=True, hier=True, T=777, seed=50),
 }
 
 
@@ -86,7 +90,7 @@ def gen_tenco(name):
     m.load_state_dict(sd, strict=True)
     x = synth.synthetic_features(cfg["T"], cfg["dim"], seed=cfg["seed"])
     ref = m(x, False)
-    ora = o_tenco.tenco_forward(sd, x, cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["fpn"])
+    ora = o_tenco.tenco_forward(sd, x, cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["fpn"], cfg.get("hier", False))
     out = {}
     for gi, gname in enumerate(("ivt", "i", "v", "t")):
         for li, (r, o) in enumerate(zip(ref[gi], ora[gi])):

@@ -18,19 +18,23 @@ def dilated_residual_layer(sd: SD, prefix: str, x: torch.Tensor, dilation: int) 
     return x + h
 
 
-def _stage(sd: SD, prefix: str, x: torch.Tensor, n_layers: int, project: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+def _stage(sd: SD, prefix: str, x: torch.Tensor, n_layers: int, project: bool, pool: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """`BaseCausalTCN.forward` (:118-135, project=True) / `Refinement.forward` (:149-162 with
-    use_output False -> no input projection, hier False -> no pooling)."""
+    use_output False -> no input projection; pool = args.hier: nn.AvgPool1d(7, 3) (:147,154-155) behind the layers, the stage's
+    feature AND its logits come from the pooled map)."""
     out = F.conv1d(x, sd[prefix + ".conv_1x1.weight"], sd[prefix + ".conv_1x1.bias"]) if project else x
     for i in range(n_layers):
         out = dilated_residual_layer(sd, f"{prefix}.layers.{i}", out, 2 ** i)
+    if pool:
+        out = F.avg_pool1d(out, kernel_size=7, stride=3)
     logits = F.conv1d(out, sd[prefix + ".conv_out.weight"], sd[prefix + ".conv_out.bias"])
     return out, logits
 
 
 def tenco_forward(sd: SD, x: torch.Tensor, num_layers_PG: int = 11, num_layers_R: int = 10, num_R: int = 3,
-                  fpn: bool = True):
-    """`VideoNas.forward` (:36-68) with ismask False, args.output False, args.hier False.
+                  fpn: bool = True, hier: bool = False):
+    """`VideoNas.forward` (:36-68) with ismask False, args.output False; hier = args.hier (every refinement stage ends in
+    AvgPool1d(7, 3), so the levels have different lengths and the FPN's linear interpolation (:96) is a real resampling).
 
     x: [B,T,D].  Returns (out_list, out_list_i, out_list_v, out_list_t, f_list, f_list) like the reference.
     """
@@ -44,7 +48,7 @@ def tenco_forward(sd: SD, x: torch.Tensor, num_layers_PG: int = 11, num_layers_R
     if not fpn:
         out_list.append(out1)
     for r in range(num_R):
-        f, out1 = _stage(sd, f"Rs.{r}", f, num_layers_R, project=False)
+        f, out1 = _stage(sd, f"Rs.{r}", f, num_layers_R, project=False, pool=hier)
         f_list.append(f)
     if fpn:
         # `FPN.forward` (:98-106): latlayer1 serves all three laterals; the linear interpolate to an

@@ -384,3 +384,24 @@ def test_preprocess_u8_s2d_matches_torch(cuda, b, h, w):
     ref = torch.zeros((b, hp // 2, wp // 2, 16), dtype=torch.bfloat16)
     ref[..., :12] = s2d
     assert got.shape == ref.shape and torch.equal(got.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("b,t,c", [(1, 301, 64), (2, 26, 512), (3, 7, 8)])
+def test_avgpool1d_and_linear_interpolation_rows(cuda, dtype, b, t, c):
+    """`--hier` pieces of Temporal_tenco on frame-major rows: nn.AvgPool1d(7, 3) and F.interpolate(mode='linear') over time, against torch"""
+    import torch.nn.functional as F
+    from computervision_codes_amd import ops
+    x = torch.randn(b, t, c, generator=torch.Generator().manual_seed(5)).to(dtype)
+    tol = 1e-6 if dtype == torch.float32 else 2 ** -8
+    y = ops.avgpool1d_rows(x.to(cuda), 7, 3)
+    ref = F.avg_pool1d(x.float().permute(0, 2, 1), 7, 3).permute(0, 2, 1)
+    assert tuple(y.shape) == tuple(ref.shape) == (b, (t - 7) // 3 + 1, c)
+    assert (y.float().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    for t_out in (t, 3 * t + 2, max(1, t // 2)):
+        u = ops.interp_linear_rows(x.to(cuda), t_out)
+        ref = F.interpolate(x.float().permute(0, 2, 1), size=t_out, mode="linear").permute(0, 2, 1)
+        assert tuple(u.shape) == (b, t_out, c)
+        assert (u.float().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+        if t_out == t:
+            assert torch.equal(u.cpu(), x)                 # to the same length: the identity (what the non-hier FPN relies on)

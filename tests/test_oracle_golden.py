@@ -9,7 +9,7 @@ from conftest import load_golden
 from oracle import spatial_cnn as o_cnn
 from oracle import tenco as o_tenco
 
-TENCO = ["tenco_tiny", "tenco_ragged", "tenco_config1", "tenco_4stage"]
+TENCO = ["tenco_tiny", "tenco_ragged", "tenco_config1", "tenco_4stage", "tenco_hier", "tenco_hier_4stage"]
 CNN_FAST = ["cnn_resnet18_odd", "cnn_resnet50_small", "cnn_resnet18_224"]
 
 
@@ -28,7 +28,7 @@ def test_tenco_oracle_matches_reference_outputs(name):
     sd = synth.fill_from_shapes(table, seed=cfg["seed"])
     x = synth.synthetic_features(cfg["T"], cfg["dim"], seed=cfg["seed"])
     with torch.no_grad():
-        out = o_tenco.tenco_forward(sd, x, cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["fpn"])
+        out = o_tenco.tenco_forward(sd, x, cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["fpn"], cfg.get("hier", False))
     for gi, g in enumerate(("ivt", "i", "v", "t")):
         for li, o in enumerate(out[gi]):
             _close(o, z[f"logit_{g}_{li}"])
