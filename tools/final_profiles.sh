@@ -36,6 +36,10 @@ echo mstct done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_q2l_train -o q2l -- python3 $R/tools/q2l_train_prof.py > $O/prof_q2l_train.log 2>&1
 rm -f $O/prof_q2l_train/*kernel_trace.csv
 echo q2l done
+rm -rf $O/prof_cnn_train
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cnn_train -o ct -- python3 $R/tools/bf16_train_prof.py > $O/prof_cnn_train.log 2>&1
+rm -f $O/prof_cnn_train/*kernel_trace.csv
+echo cnn train done
 cd $R
 cp profiles/traffic.json gpurun_out/traffic.json; cp profiles/mfma_util.json gpurun_out/mfma_util.json
 python tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 36 resnet50_bf16_b2672_224x224 gpurun_out/traffic.json
