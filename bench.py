@@ -723,8 +723,8 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     fps = world * nstep * a.steps / dt
 
-    res = None
-    if rank == 0:
+    def rank0_record():
+        """everything beyond the timed region that only rank 0 computes (per-launch roofline, single-GPU sub-records)"""
         flops_frame = conv_flops_per_frame(model, a.height, a.width)
         per_launch = time_conv_kernels(model, frames[:a.batch].contiguous())   # the launches of ONE stream's part of a step
         conv_ms = sum(per_launch)
@@ -818,6 +818,19 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_spatial(a.network, a.height, a.width, 1234)
             res["gpu_over_cpu"] = round(fps / res["cpu_baseline"]["value"], 1)
+        return res
+
+    res = None
+    if rank == 0:
+        try:
+            res = rank0_record()
+        except Exception as e:   # the other ranks are about to enter a collective: an exception here must not leave them waiting for rank 0
+            import traceback
+            traceback.print_exc()
+            res = {"metric": METRIC, "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                   "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+                   "data": "synthetic", "config": {"workload": f"Spatial_cnn {a.network} extractor, {a.height}x{a.width} frames, {a.dtype}, eval (BASELINE configs[1])"},
+                   "roofline": None, "error": f"rank-0 sub-records failed: {type(e).__name__}: {e}"}
     if world > 1 and not a.no_ddp_train:
         try:
             rec = ddp_train_bench(dev, dist, world, rank)  # every rank takes part (the exchange is collective)
