@@ -216,6 +216,31 @@ def test_bf16_operand_step_vs_reference_fixture(cuda, name):
                 assert cos > 0.9, (k, cos)
 
 
+def test_epilogue_statistics_step_equals_separate_pass(cuda, monkeypatch):
+    """the forward of a bf16 step with BatchNorm statistics taken in the convolution epilogue (default) and with the separate statistics pass
+    (MT4_NO_EPILOGUE_STATS=1) agree bit for bit: every unit's activations, the advanced running statistics, the BCE term (the KL / MSE terms are
+    summed with fp32 atomics and agree to their run-to-run noise)"""
+    from computervision_codes_amd.spatial_cnn_train import SpatialCnnTrainer
+    from oracle.spatial_cnn_train import damp_residual_gamma
+    z, cfg = load_golden("cnn_train_resnet50")
+    table = shapes.spatial_cnn_shapes(cfg["network"])
+    sd = damp_residual_gamma(synth.fill_from_shapes(table, seed=cfg["seed"]), cfg["network"], cfg.get("damp", 1.0))
+    img, labels, tpred, tfeat = _inputs(cfg)
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("MT4_NO_EPILOGUE_STATS", "1")
+        tr = SpatialCnnTrainer(cfg["network"], lr=cfg["lr"], weight_decay=1e-5, rates=cfg["rates"], temp=4.0, operand_dtype=BF).load_state_dict(sd)
+        assert tr.epilogue_stats == (not off)
+        terms = tr.train_step(img.to(cuda), labels, tpred, tfeat, apply_update=False)
+        res.append((terms, [rec[5].clone() for rec in tr.last_saved], {n: (u.rmean.clone(), u.rvar.clone()) for n, u in tr.units.items()}))
+    (t0, a0, r0), (t1, a1, r1) = res
+    assert all(torch.equal(x, y) for x, y in zip(a0, a1))
+    assert t0["hard"] == t1["hard"]
+    assert all(abs(t0[k] - t1[k]) <= 1e-6 * abs(t0[k]) for k in ("loss", "soft", "kd")), (t0, t1)   # (their reductions add with fp32 atomics)
+    assert all(torch.equal(r0[n][0], r1[n][0]) and torch.equal(r0[n][1], r1[n][1]) for n in r0)
+
+
 def test_bf16_operand_training_tracks_fp32(cuda):
     """six SGD steps on the same batches from the same start: the bf16-operand trainer's loss follows the fp32 trainer's within 1 %, and both fall"""
     from computervision_codes_amd.spatial_cnn_train import SpatialCnnTrainer
