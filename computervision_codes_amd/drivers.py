@@ -55,6 +55,12 @@ def _barrier():
         dist.barrier()
 
 
+def _chlg(F) -> bool:
+    """`set_chlg_eval` of the reference's drivers (`Spatial_cnn/run.py:122`): the challenge evaluation protocol (null triplets left out of the
+    100-way AP) for the `*challenge*` dataset variants"""
+    return "challenge" in str(getattr(F, "dataset_variant", ""))
+
+
 def _log(path: str, msg: str):
     print(msg)
     os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -109,7 +115,7 @@ def spatial_cnn_test(argv=None) -> Dict[str, np.ndarray]:
     if rank == 0:
         featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type), all_feats)
         _log(logfile, f"save time:::::: : {time.time() - t0:.4f} secs")
-        _log(logfile, " ".join(f"AP_{k}={m[k].compute_video_AP()['mAP']:.4f}" for k in m) + f" (rank-0 videos, world={world})")
+        _log(logfile, " ".join(f"AP_{k}={m[k].compute_video_AP(ignore_null=_chlg(F))['mAP']:.4f}" for k in m) + f" (rank-0 videos, world={world})")
     return all_feats
 
 
@@ -242,7 +248,7 @@ def spatial_cnn_train(argv=None) -> Dict[str, float]:
                                                     workers=getattr(F, "decode_workers", 0), decode=getattr(F, "png_decode", "host"))
                     m.update(lv[s0:s0 + vb, 1:], _sigmoid(model.extract_u8(fr)["ivt".index(vt) if single else 3][1]))
                 m.video_end()
-            score = float(m.compute_video_AP()["mAP"]) if val_videos else 0.0
+            score = float(m.compute_video_AP(ignore_null=_chlg(F))["mAP"]) if val_videos else 0.0
             last["val_mAP_ivt"] = score
             if score > best or not os.path.exists(ckpt):
                 best = max(best, score)
@@ -308,7 +314,7 @@ def _tenco_eval_rank0(F) -> Dict[str, float]:
         for key, lg in (("ivt", out), ("i", out_i), ("v", out_v), ("t", out_t)):   # finest FPN level, [K,T] -> [T,K]
             m[key].update(lab[key][:, 1:], _sigmoid(lg[0][0].transpose(0, 1)))
             m[key].video_end()
-    res = {f"AP_{k}": m[k].compute_video_AP()["mAP"] for k in m}
+    res = {f"AP_{k}": m[k].compute_video_AP(ignore_null=_chlg(F))["mAP"] for k in m}
     _log(logfile, f"eta {time.time() - t0:.3f} secs " + " ".join(f"{k}={v:.4f}" for k, v in res.items()))
     with open(os.path.join(model_dir, modelname + "_test_mAP.pkl"), "wb") as f:
         pickle.dump({k: {"targets": m[k].global_targets, "predictions": m[k].global_predictions} for k in m}, f)
@@ -606,7 +612,7 @@ def spatial_transformer_train(argv=None) -> Dict[str, float]:
                     zt = [] if single else [torch.zeros((fr.shape[0], F.teacher_dim), device=fr.device)] * 3   # (`dataloader.py:240-246`: zeros off the train split)
                     m.update(lv[s0:s0 + vb, 1:], _sigmoid(model(fr, *zt)[gi][1]))
                 m.video_end()
-            score = float(m.compute_video_AP()["mAP"]) if val_videos else 0.0
+            score = float(m.compute_video_AP(ignore_null=_chlg(F))["mAP"]) if val_videos else 0.0
             last["val_mAP"] = score
             if score > best or not os.path.exists(ckpt):
                 best = max(best, score)
