@@ -324,6 +324,124 @@ __global__ __launch_bounds__(256) void wgrad_conv2d_f32_kernel(const float* __re
     }
 }
 
+// The same product on 128 x 128 (output channel, K column) tiles, waves 2 x 2 with 64 x 64 each: per 4-pixel MFMA step a wave reads 4 + 4
+// operand values for 16 MFMAs where the 64 x 64 kernel above reads 1 + 4 for 4 -- that one issues ~1500 instructions per 104 MFMAs and is
+// bound by instruction issue, not by its matrix cores (profiles/r03_wgrad_experiments.txt) -- and the pixel coordinates of a thread's rows
+// advance incrementally instead of by a 64-bit division per row and chunk.  Same arithmetic: fp32 MFMA 16x16x4 over the pixels in order,
+// partial tiles added with fp32 atomics.
+template <int BMT, int BNT>      // tile = (64 BMT) output channels x (64 BNT) K columns; waves 2 x 2
+__global__ __launch_bounds__(256) void wgrad_conv2d_f32_wide_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                    float* __restrict__ dwp, const Wg2 a) {
+    constexpr int KT = 32, BM = 64 * BMT, BN = 64 * BNT, LDY = BM + 4, LDX = BN + 4;
+    constexpr int MI = 2 * BMT, NJ = 2 * BNT;                   // 16 x 16 accumulator tiles of a wave
+    constexpr int YG = BM / 4, XG = BN / 4;                     // float4 column groups per staged row
+    constexpr int YP = KT * YG / 256, XP = KT * XG / 256;       // staging passes (rows 256 / groups apart)
+    __shared__ __attribute__((aligned(16))) float sdy[KT * LDY];
+    __shared__ __attribute__((aligned(16))) float sx[KT * LDX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int k0 = blockIdx.x * BN, co0 = blockIdx.y * BM;
+    const int yr = tid / YG, yc = (tid % YG) * 4;               // dY: row yr + (256 / YG) i, columns yc ..
+    const int xr = tid / XG, xc = (tid % XG) * 4;               // x:  row xr + (256 / XG) i, K columns xc ..
+    const int kcol = k0 + xc;
+    const int xtap = kcol / a.tapw, xci = kcol - xtap * a.tapw;
+    const bool xcol_ok = xtap < a.KH * a.KW && xci < a.Cin;
+    const int kh = xtap / a.KW, kw = xtap - kh * a.KW;
+    const int dh0 = kh * a.dh - a.ph, dw0 = kw * a.dw - a.pw;
+    const bool ycol_ok = co0 + yc < a.Cout;
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long long mb = (long long)blockIdx.z * a.rows_per_split;
+    long long me = mb + a.rows_per_split;
+    if (me > a.M) me = a.M;
+    const int HoWo = a.Ho * a.Wo;
+    int pb[XP], pho[XP], pwo[XP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        const long long m = mb + xr + (256 / XG) * i;
+        pb[i] = (int)(m / HoWo);
+        const int rem = (int)(m - (long long)pb[i] * HoWo);
+        pho[i] = rem / a.Wo;
+        pwo[i] = rem - pho[i] * a.Wo;
+    }
+    const long long last = me - 1;
+    float4 ry[YP], rx[XP];
+    auto fetch = [&](long long m0) {      // unconditional loads from clamped addresses, zeroed by selects (no load waits behind a branch)
+#pragma unroll
+        for (int i = 0; i < YP; ++i) {
+            const long long m = m0 + yr + (256 / YG) * i;
+            const float4 vy = *(const float4*)(dy + (m < me ? m : last) * a.Cout + (ycol_ok ? co0 + yc : 0));
+            ry[i] = (m < me && ycol_ok) ? vy : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const long long m = m0 + xr + (256 / XG) * i;
+            const int hi = pho[i] * a.sh + dh0, wi = pwo[i] * a.sw + dw0;
+            const bool ok = xcol_ok && m < me && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const int hc = min(max(hi, 0), a.H - 1), wc = min(max(wi, 0), a.W - 1), bc = min(pb[i], a.B - 1);
+            const float4 vx = *(const float4*)(x + (((long long)bc * a.H + hc) * a.W + wc) * a.Cin + (xcol_ok ? xci : 0));
+            rx[i] = ok ? vx : make_float4(0, 0, 0, 0);
+            pwo[i] += KT;                  // the row this slot stages in the next chunk
+            while (pwo[i] >= a.Wo) {
+                pwo[i] -= a.Wo;
+                if (++pho[i] == a.Ho) { pho[i] = 0; ++pb[i]; }
+            }
+        }
+    };
+    fetch(mb);
+    for (long long m0 = mb; m0 < me; m0 += KT) {
+#pragma unroll
+        for (int i = 0; i < YP; ++i) *(float4*)(sdy + (yr + (256 / YG) * i) * LDY + yc) = ry[i];
+#pragma unroll
+        for (int i = 0; i < XP; ++i) *(float4*)(sx + (xr + (256 / XG) * i) * LDX + xc) = rx[i];
+        __syncthreads();
+        if (m0 + KT < me) fetch(m0 + KT);
+#pragma unroll
+        for (int kk = 0; kk < KT / 4; ++kk) {
+            const int row = kk * 4 + (lane >> 4);
+            float av[MI], bv[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) av[i] = sdy[row * LDY + wm * (32 * BMT) + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bv[j] = sx[row * LDX + wn * (32 * BNT) + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int k = k0 + wn * (32 * BNT) + j * 16 + (lane & 15);
+            if (k >= a.Kpad) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + wm * (32 * BMT) + i * 16 + (lane >> 4) * 4 + e;
+                if (co < a.Cout) atomicAdd(dwp + (long long)co * a.Kpad + k, acc[i][j][e]);
+            }
+        }
+}
+
+template <int BMT, int BNT>
+static int launch_wgrad32_wide(const float* dy, const float* x, float* dw, Wg2 a, int Cout, hipStream_t s) {
+    const int tiles = cdiv(a.Kpad, 64 * BNT) * cdiv(Cout, 64 * BMT);
+    long long splits = (MT4_ENV_INT("MT4_WGRAD32_WGS", 768) + tiles - 1) / tiles;
+    const long long max_splits = (a.M + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    a.rows_per_split = ((a.M + splits - 1) / splits + 31) / 32 * 32;
+    splits = (a.M + a.rows_per_split - 1) / a.rows_per_split;
+    hipLaunchKernelGGL((wgrad_conv2d_f32_wide_kernel<BMT, BNT>), dim3(cdiv(a.Kpad, 64 * BNT), cdiv(Cout, 64 * BMT), (unsigned)splits), dim3(256), 0, s, dy, x,
+                       dw, a);
+    return mt4_check_launch();
+}
+
 extern "C" int mt4_wgrad_conv2d_f32(const float* dy, const float* x, float* dw_packed_zeroed, int32_t B, int32_t H, int32_t W, int32_t Cin,
                                     int32_t Ho, int32_t Wo, int32_t Cout, int32_t KH, int32_t KW, int32_t stride_h, int32_t stride_w,
                                     int32_t pad_h, int32_t pad_w, int32_t dil_h, int32_t dil_w, void* stream) {
@@ -337,6 +455,17 @@ extern "C" int mt4_wgrad_conv2d_f32(const float* dy, const float* x, float* dw_p
     a.Kpad = (int)mt4_conv_packed_k(Cin, KH, KW, MT4_F32);
     a.tapw = ((Cin * 4 + 15) / 16) * 4;
     a.M = (long long)B * Ho * Wo;
+    // wider tiles where the channel counts allow AND the launch still has >= 2 workgroups per CU (each pixel split covers >= 256 pixels: a small
+    // batch has few of them -- ResNet-50 at batch 8: 9.6 ms with the 64 x 64 kernel everywhere, 10.2 with the wide tiles);
+    // the 64 x 64 kernel below: the narrowest layers, small batches
+    if (!MT4_ENV_SET("MT4_NO_WGRAD32_WIDE")) {
+        hipStream_t s = (hipStream_t)stream;
+        const long long max_splits = (a.M + 255) / 256;
+        auto fills = [&](int bm, int bn) { return (long long)cdiv(a.Kpad, bn) * cdiv(Cout, bm) * max_splits >= 512; };
+        if (Cout > 64 && a.Kpad > 64 && fills(128, 128)) return launch_wgrad32_wide<2, 2>(dy, x, dw_packed_zeroed, a, Cout, s);
+        if (a.Kpad >= 128 && fills(64, 128)) return launch_wgrad32_wide<1, 2>(dy, x, dw_packed_zeroed, a, Cout, s);
+        if (Cout > 64 && fills(128, 64)) return launch_wgrad32_wide<2, 1>(dy, x, dw_packed_zeroed, a, Cout, s);
+    }
     const int tiles = cdiv(a.Kpad, 64) * cdiv(Cout, 64);
     long long splits = (1024 + tiles - 1) / tiles;             // ~4 workgroups per CU in total
     const long long max_splits = (a.M + 255) / 256;             // at least 256 rows per split

@@ -58,7 +58,9 @@ def test_batchnorm_train_fwd_bwd(cuda, m, c, relu, res):
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,k,s,p", [(2, 14, 18, 64, 96, 3, 1, 1), (3, 16, 12, 64, 128, 3, 2, 1), (2, 16, 16, 128, 256, 1, 2, 0),
-                                                  (2, 9, 11, 256, 64, 1, 1, 0), (2, 38, 38, 4, 64, 7, 2, 0)])
+                                                  (2, 9, 11, 256, 64, 1, 1, 0), (2, 38, 38, 4, 64, 7, 2, 0),
+                                                  (2, 120, 112, 64, 136, 3, 1, 1), (2, 184, 184, 160, 64, 1, 1, 0), (3, 150, 150, 64, 256, 1, 1, 0), (2, 132, 120, 128, 256, 3, 2, 1)])
+# (the last four: enough pixels for the wide-tile kernels -- 128 x 128 with ragged channel tiles, 64 x 128, 128 x 64, 128 x 128 strided)
 def test_conv2d_weight_and_data_gradients(cuda, b, h, w, cin, cout, k, s, p):
     from computervision_codes_amd import ops
     from computervision_codes_amd.spatial_cnn_train import SpatialCnnTrainer, _Unit
