@@ -164,10 +164,11 @@ def test_mstct_train_step_with_dropout_draw_vs_oracle(cuda):
         assert (n1[k] - n2[k]).abs().max().item() <= 1e-6 * max(1.0, n1[k].abs().max().item()), k
 
 
-@pytest.mark.parametrize("b,t,cout,cin,taps,dil", [(9, 256, 192, 128, 3, 1), (5, 500, 200, 100, 3, 4), (1, 2304, 256, 512, 1, 1), (31, 256, 128, 864, 1, 1)])
+@pytest.mark.parametrize("b,t,cout,cin,taps,dil", [(9, 256, 192, 128, 3, 1), (5, 500, 200, 100, 3, 4), (1, 2304, 256, 512, 1, 1), (31, 256, 128, 864, 1, 1),
+                                                   (48, 256, 256, 864, 1, 1), (10, 2000, 200, 136, 3, 4)])
 def test_wgrad_conv1d_long_rows_vs_autograd(cuda, b, t, cout, cin, taps, dil):
-    """`mt4_wgrad_conv1d_f32` on row ranges of >= 2048 (the 128 x 128 LDS-DMA tile kernel): ragged tile edges, tap shifts across sequence
-    boundaries, the split of the row range over workgroups (atomic partial sums) -- against torch autograd"""
+    """`mt4_wgrad_conv1d_f32` on long row ranges (the last two cases: enough rows for the 128 x 128 kernel): ragged tile edges, tap shifts across
+    sequence boundaries, the split of the row range over workgroups (atomic partial sums) -- against torch autograd"""
     from computervision_codes_amd import ops
     x, dy = _rand((b, t, cin), 51), _rand((b, t, cout), 52)
     w = torch.zeros(cout, cin, taps, requires_grad=True)
