@@ -98,7 +98,7 @@ SIGNATURES = {
     "mt4_transpose_pack_conv1d_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "mt4_bn_stats_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, C.c_float, C.c_float, _vp]),
     "mt4_bn_apply_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _vp]),
-    "mt4_bn_backward_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _vp]),
+    "mt4_bn_backward_f32": (C.c_int, [_vp] * 12 + [C.c_int64, _i32, _i32, _vp]),
     "mt4_wgrad_conv2d_f32": (C.c_int, [_vp, _vp, _vp] + [_i32] * 15 + [_vp]),
     "mt4_maxpool3x3s2_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_avgpool_bwd_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),

@@ -141,16 +141,26 @@ extern "C" int mt4_bn_apply_f32(const float* x, const float* mean, const float* 
 // backward pass 1: with dy' = relu ? (y > 0 ? dy : 0) : dy :  sums[0][c] += sum dy',  sums[1][c] += sum dy' * xhat
 __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                              const float* __restrict__ x, const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd, double* __restrict__ sums, long long M, int C, int relu) {
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, double* __restrict__ sums, long long M, int C, int relu) {
+    // relu 2: the gate is recomputed from x -- (x - mean) * invstd * gamma + beta > 0, the forward's own fp32 expression, i.e. the stored y
+    // bit for bit (units without a residual input): y is not read, a third of this kernel's traffic
     const int c0 = blockIdx.x * 64, c = c0 + (threadIdx.x & 15) * 4;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (c < C) {
         const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
+        float4 ga = make_float4(0, 0, 0, 0), be = ga;
+        if (relu == 2) { ga = *(const float4*)(gamma + c); be = *(const float4*)(beta + c); }
         const long long st = (long long)gridDim.y * 64;
         long long m = (long long)blockIdx.y * 64 + (threadIdx.x >> 4);
         const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
         auto add = [&](float4 g, const float4 xv, const float4 yv) {
-            if (relu) {
+            if (relu == 2) {
+                if (!((xv.x - mu.x) * is.x * ga.x + be.x > 0.f)) g.x = 0.f;
+                if (!((xv.y - mu.y) * is.y * ga.y + be.y > 0.f)) g.y = 0.f;
+                if (!((xv.z - mu.z) * is.z * ga.z + be.z > 0.f)) g.z = 0.f;
+                if (!((xv.w - mu.w) * is.w * ga.w + be.w > 0.f)) g.w = 0.f;
+            } else if (relu) {
                 if (!(yv.x > 0.f)) g.x = 0.f;
                 if (!(yv.y > 0.f)) g.y = 0.f;
                 if (!(yv.z > 0.f)) g.z = 0.f;
@@ -165,12 +175,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __rest
             const float4 g0 = *(const float4*)(dy + i0), g1 = *(const float4*)(dy + i1);
             const float4 x0 = *(const float4*)(x + i0), x1 = *(const float4*)(x + i1);
             float4 y0 = one, y1 = one;
-            if (relu) { y0 = *(const float4*)(y + i0); y1 = *(const float4*)(y + i1); }
+            if (relu == 1) { y0 = *(const float4*)(y + i0); y1 = *(const float4*)(y + i1); }
             add(g0, x0, y0); add(g1, x1, y1);
         }
         for (; m < M; m += st) {
             const long long i0 = m * C + c;
-            add(*(const float4*)(dy + i0), *(const float4*)(x + i0), relu ? *(const float4*)(y + i0) : one);
+            add(*(const float4*)(dy + i0), *(const float4*)(x + i0), relu == 1 ? *(const float4*)(y + i0) : one);
         }
     }
     bn_block_reduce(acc, sums, C, c0);
@@ -180,14 +190,16 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __rest
 // dgamma = sums[1], dbeta = sums[0]
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ gamma, const double* __restrict__ sums, float* __restrict__ dx,
-                                                           float* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta, long long M,
-                                                           int C, int relu) {
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const double* __restrict__ sums, float* __restrict__ dx, float* __restrict__ dres,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, long long M, int C, int relu) {
     // column slabs: the parameters and the two per-channel means of the reduction stay in registers
     const int c = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
     if (c >= C) return;
     const double invM = 1.0 / (double)M;
     const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c), ga = *(const float4*)(gamma + c);
+    float4 bg = make_float4(0, 0, 0, 0);
+    if (relu == 2) bg = *(const float4*)(beta + c);
     const float4 m1 = make_float4((float)(sums[c] * invM), (float)(sums[c + 1] * invM), (float)(sums[c + 2] * invM), (float)(sums[c + 3] * invM));
     const float4 m2 = make_float4((float)(sums[C + c] * invM), (float)(sums[C + c + 1] * invM), (float)(sums[C + c + 2] * invM),
                                   (float)(sums[C + c + 3] * invM));
@@ -199,7 +211,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4);
     const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
     auto put = [&](long long i, float4 g, const float4 xv, const float4 yv) {
-        if (relu) {
+        if (relu == 2) {
+            if (!((xv.x - mu.x) * is.x * ga.x + bg.x > 0.f)) g.x = 0.f;
+            if (!((xv.y - mu.y) * is.y * ga.y + bg.y > 0.f)) g.y = 0.f;
+            if (!((xv.z - mu.z) * is.z * ga.z + bg.z > 0.f)) g.z = 0.f;
+            if (!((xv.w - mu.w) * is.w * ga.w + bg.w > 0.f)) g.w = 0.f;
+        } else if (relu) {
             if (!(yv.x > 0.f)) g.x = 0.f;
             if (!(yv.y > 0.f)) g.y = 0.f;
             if (!(yv.z > 0.f)) g.z = 0.f;
@@ -218,26 +235,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const float4 g0 = *(const float4*)(dy + i0), g1 = *(const float4*)(dy + i1);
         const float4 x0 = *(const float4*)(x + i0), x1 = *(const float4*)(x + i1);
         float4 y0 = one, y1 = one;
-        if (relu) { y0 = *(const float4*)(y + i0); y1 = *(const float4*)(y + i1); }
+        if (relu == 1) { y0 = *(const float4*)(y + i0); y1 = *(const float4*)(y + i1); }
         put(i0, g0, x0, y0); put(i1, g1, x1, y1);
     }
     for (; m < M; m += st) {
         const long long i0 = m * C + c;
-        put(i0, *(const float4*)(dy + i0), *(const float4*)(x + i0), relu ? *(const float4*)(y + i0) : one);
+        put(i0, *(const float4*)(dy + i0), *(const float4*)(x + i0), relu == 1 ? *(const float4*)(y + i0) : one);
     }
 }
 
 extern "C" int mt4_bn_backward_f32(const float* dy, const float* y_post, const float* x, const float* mean, const float* invstd,
-                                   const float* gamma, double* sums_zeroed, float* dx, float* dres, float* dgamma, float* dbeta, int64_t M,
-                                   int32_t C, int32_t relu, void* stream) {
+                                   const float* gamma, const float* beta, double* sums_zeroed, float* dx, float* dres, float* dgamma, float* dbeta,
+                                   int64_t M, int32_t C, int32_t relu, void* stream) {
     mt4_clear_error();
     if (!dy || !x || !mean || !invstd || !gamma || !sums_zeroed || !dx || !dgamma || !dbeta || M <= 0 || C <= 0) return MT4_EINVAL;
-    if (relu && !y_post) return MT4_EINVAL;
+    if (relu < 0 || relu > 2 || (relu == 1 && !y_post) || (relu == 2 && !beta)) return MT4_EINVAL;
     if (C % 4) return MT4_EALIGN;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), bn_reduce_slabs(M, C)), dim3(1024), 0, s, dy, y_post, x, mean, invstd, sums_zeroed,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), bn_reduce_slabs(M, C)), dim3(1024), 0, s, dy, y_post, x, mean, invstd, gamma, beta, sums_zeroed,
                        (long long)M, C, relu);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(C, 64), bn_row_slabs(M, C)), dim3(256), 0, s, dy, y_post, x, mean, invstd, gamma, sums_zeroed, dx,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(C, 64), bn_row_slabs(M, C)), dim3(256), 0, s, dy, y_post, x, mean, invstd, gamma, beta, sums_zeroed, dx,
                        dres, dgamma, dbeta, (long long)M, C, relu);
     return mt4_check_launch();
 }

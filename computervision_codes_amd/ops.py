@@ -784,16 +784,20 @@ def bn_apply(x2d, mean, invstd, gamma, beta, residual=None, relu=True):
     return y
 
 
-def bn_backward(dy, y_post, x2d, mean, invstd, gamma, dgamma, dbeta, relu=True, want_dres=False, sums=None):
+def bn_backward(dy, y_post, x2d, mean, invstd, gamma, dgamma, dbeta, relu=True, want_dres=False, sums=None, beta=None):
+    """with `beta` and relu the ReLU gate is recomputed from x2d (the forward's fp32 expression: the stored output's sign bit for bit) instead
+    of read from y_post -- units without a residual input"""
     m, c = x2d.shape
     if sums is None:
         sums = torch.zeros(2 * c, dtype=torch.float64, device=x2d.device)   # scratch: float64 accumulators
     assert sums.dtype == torch.float64 and sums.numel() == 2 * c
     dx = torch.empty_like(x2d)
     dres = torch.empty_like(x2d) if want_dres else None
-    check(lib.mt4_bn_backward_f32(dy.data_ptr(), y_post.data_ptr() if y_post is not None else None, x2d.data_ptr(), mean.data_ptr(),
-                                  invstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(), dx.data_ptr(), dres.data_ptr() if want_dres else None,
-                                  dgamma.data_ptr(), dbeta.data_ptr(), m, c, 1 if relu else 0, _stream()), "mt4_bn_backward_f32")
+    code = 0 if not relu else (2 if beta is not None else 1)
+    check(lib.mt4_bn_backward_f32(dy.data_ptr(), y_post.data_ptr() if (y_post is not None and code == 1) else None, x2d.data_ptr(), mean.data_ptr(),
+                                  invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr() if beta is not None else None, sums.data_ptr(), dx.data_ptr(),
+                                  dres.data_ptr() if want_dres else None, dgamma.data_ptr(), dbeta.data_ptr(), m, c, code, _stream()),
+          "mt4_bn_backward_f32")
     return dx, dres
 
 

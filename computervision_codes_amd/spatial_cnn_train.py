@@ -317,7 +317,7 @@ class SpatialCnnTrainer:
                                          relu=relu, want_dres=want_dres, sums=u.sums_b, beta=u.beta if (relu and not has_res) else None)
         else:
             dz, dres = ops.bn_backward(dy.reshape(-1, c), a.view(-1, c) if relu else None, z.view(-1, c), mean, invstd, u.gamma, u.ggamma, u.gbeta,
-                                       relu=relu, want_dres=want_dres, sums=u.sums_b)
+                                       relu=relu, want_dres=want_dres, sums=u.sums_b, beta=u.beta if (relu and not has_res) else None)
         dz = dz.view(z.shape)
         if self.op16 and u.cin != 4:
             ops.wgrad_conv2d_bf16(dz, x, u.gw, u.k, u.stride)                                         # (adds to G, zeroed once per step)

@@ -55,6 +55,10 @@ def test_batchnorm_train_fwd_bwd(cuda, m, c, relu, res):
     assert (dg.cpu() - gt.grad).abs().max() < tol(gt.grad) * 5 and (db.cpu() - bt.grad).abs().max() < tol(bt.grad) * 5
     if res:
         assert (dres.cpu() - rt.grad).abs().max() < 1e-6
+    if relu and not res:   # the gate recomputed from x (the forward's own fp32 expression) == the gate read from the stored output, bit for bit
+        dg2, db2 = torch.zeros(c, device=cuda), torch.zeros(c, device=cuda)
+        dx2, _ = ops.bn_backward(dy.to(cuda), None, xd, mean, invstd, g.to(cuda), dg2, db2, relu=True, beta=b.to(cuda))
+        assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,k,s,p", [(2, 14, 18, 64, 96, 3, 1, 1), (3, 16, 12, 64, 128, 3, 2, 1), (2, 16, 16, 128, 256, 1, 2, 0),
