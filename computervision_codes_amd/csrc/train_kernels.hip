@@ -92,103 +92,6 @@ __global__ __launch_bounds__(256) void wgrad_conv1d_f32_kernel(const float* __re
     }
 }
 
-// The same product on (64 BMT) x (64 BNT) tiles, waves 2 x 2 (as wgrad_conv2d_f32_wide_kernel in train2d_kernels.hip: the 64 x 64 kernel above
-// issues ~15 instructions per MFMA and is bound by instruction issue; here a wave reads 2 BMT + 2 BNT operand values per 4 BMT BNT MFMAs, the
-// (b, t) of a thread's rows advances incrementally and the loads are branch-free).  Taken where the launch still fills the chip.
-template <int BMT, int BNT>
-__global__ __launch_bounds__(256) void wgrad_conv1d_f32_wide_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                    float* __restrict__ dw, int B, int T, int Cout, int Cin, int taps,
-                                                                    int dil, int pad, int Kpad, int accumulate, long long rows_per_split) {
-    constexpr int KT = 32, BM = 64 * BMT, BN = 64 * BNT, LDY = BM + 4, LDX = BN + 4;
-    constexpr int MI = 2 * BMT, NJ = 2 * BNT;
-    constexpr int YG = BM / 4, XG = BN / 4, YP = KT * YG / 256, XP = KT * XG / 256;
-    __shared__ __attribute__((aligned(16))) float sdy[KT * LDY];
-    __shared__ __attribute__((aligned(16))) float sx[KT * LDX];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int k0 = blockIdx.x * BN, co0 = blockIdx.y * BM;
-    const int yr = tid / YG, yc = (tid % YG) * 4;
-    const int xr = tid / XG, xc = (tid % XG) * 4;
-    const int kcol = k0 + xc;
-    const int xtap = kcol / Cin, xci = kcol - xtap * Cin;
-    const bool xcol_ok = kcol < taps * Cin, ycol_ok = co0 + yc < Cout;
-    const int shift = xtap * dil - pad;
-    f32x4 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const long long Mall = (long long)B * T;
-    const long long mb = (long long)blockIdx.z * rows_per_split;
-    const long long M = mb + rows_per_split < Mall ? mb + rows_per_split : Mall;
-    int pb[XP], pt[XP];
-#pragma unroll
-    for (int i = 0; i < XP; ++i) {
-        const long long m = mb + xr + (256 / XG) * i;
-        pb[i] = (int)(m / T);
-        pt[i] = (int)(m - (long long)pb[i] * T);
-    }
-    const long long last = M - 1;
-    float4 ry[YP], rx[XP];
-    auto fetch = [&](long long m0) {
-#pragma unroll
-        for (int i = 0; i < YP; ++i) {
-            const long long m = m0 + yr + (256 / YG) * i;
-            const float4 vy = *(const float4*)(dy + (m < M ? m : last) * Cout + (ycol_ok ? co0 + yc : 0));
-            ry[i] = (m < M && ycol_ok) ? vy : make_float4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < XP; ++i) {
-            const long long m = m0 + xr + (256 / XG) * i;
-            const int ts = pt[i] + shift;
-            const bool ok = xcol_ok && m < M && (unsigned)ts < (unsigned)T;
-            const int tc = min(max(ts, 0), T - 1), bc = min(pb[i], B - 1);
-            const float4 vx = *(const float4*)(x + ((long long)bc * T + tc) * Cin + (xcol_ok ? xci : 0));
-            rx[i] = ok ? vx : make_float4(0, 0, 0, 0);
-            pt[i] += KT;
-            while (pt[i] >= T) { pt[i] -= T; ++pb[i]; }
-        }
-    };
-    fetch(mb);
-    for (long long m0 = mb; m0 < M; m0 += KT) {
-#pragma unroll
-        for (int i = 0; i < YP; ++i) *(float4*)(sdy + (yr + (256 / YG) * i) * LDY + yc) = ry[i];
-#pragma unroll
-        for (int i = 0; i < XP; ++i) *(float4*)(sx + (xr + (256 / XG) * i) * LDX + xc) = rx[i];
-        __syncthreads();
-        if (m0 + KT < M) fetch(m0 + KT);
-#pragma unroll
-        for (int kk = 0; kk < KT / 4; ++kk) {
-            const int row = kk * 4 + (lane >> 4);
-            float av[MI], bv[NJ];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) av[i] = sdy[row * LDY + wm * (32 * BMT) + i * 16 + (lane & 15)];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bv[j] = sx[row * LDX + wn * (32 * BNT) + j * 16 + (lane & 15)];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int k = k0 + wn * (32 * BNT) + j * 16 + (lane & 15);
-            if (k >= Kpad) continue;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int co = co0 + wm * (32 * BMT) + i * 16 + (lane >> 4) * 4 + e;
-                if (co >= Cout) continue;
-                float* p = dw + (long long)co * Kpad + k;
-                if (gridDim.z > 1) atomicAdd(p, acc[i][j][e]);
-                else *p = accumulate ? *p + acc[i][j][e] : acc[i][j][e];
-            }
-        }
-}
-
 // zero-fill as a KERNEL node: a hipMemsetAsync captured into one of several consecutive hipGraphs of a stream (graph.SegmentedGraph) left parts of
 // its range unwritten on replay (every fourth dword of the bias gradients, a different vector each run; the single-graph capture was fine), so
 // the zeroing in front of an atomic accumulation is a launch of our own
@@ -211,17 +114,6 @@ extern "C" int mt4_wgrad_conv1d_f32(const float* dy, const float* x, float* dw_p
     const long long M = (long long)B * T;
     const long long max_splits = (M + 255) / 256;              // at least 256 rows per split
     hipStream_t s = (hipStream_t)stream;
-    if (Cout > 64 && Kpad > 64 && (long long)cdiv(Kpad, 128) * cdiv(Cout, 128) * max_splits >= 512 && !MT4_ENV_SET("MT4_NO_WGRAD32_WIDE")) {
-        const int wt = cdiv(Kpad, 128) * cdiv(Cout, 128);
-        long long sp = (768 + wt - 1) / wt;
-        if (sp > max_splits) sp = max_splits;
-        const long long rps = ((M + sp - 1) / sp + 31) / 32 * 32;
-        sp = (M + rps - 1) / rps;
-        if (sp > 1 && !accumulate) zero_f32(dw_packed, (long long)Cout * Kpad, s);
-        hipLaunchKernelGGL((wgrad_conv1d_f32_wide_kernel<2, 2>), dim3(cdiv(Kpad, 128), cdiv(Cout, 128), (unsigned)sp), dim3(256), 0, s, dy, x, dw_packed, B, T,
-                           Cout, Cin, taps, dil, pad, Kpad, accumulate, rps);
-        return mt4_check_launch();
-    }
     const int tiles = cdiv(Kpad, 64) * cdiv(Cout, 64);
     long long splits = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU in total
     if (splits > max_splits) splits = max_splits;
