@@ -99,12 +99,48 @@ extern "C" int mt4_bn_stats_f32(const float* x, double* sums_zeroed, float* mean
 
 // y = act( (x - mean) * invstd * gamma + beta [+ residual] ): column slabs, the 4 channels' parameters in registers (one element group per
 // thread re-loaded 64 bytes of parameters per 16 bytes of tensor traffic); the same expressions, the same bits
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+// FIN: mean / invstd are evaluated here from the channel sums a convolution's epilogue left (mt4_conv_desc.stat_sums), as bn_apply_t_kernel does
+// for the bf16 mode: the first 64 threads fold the replicas (bn_finalize_kernel's float64 expressions), row-slab 0 writes mean / invstd for
+// the backward and advances the running statistics
+template <bool FIN>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res,
-                                                       float* __restrict__ y, long long M, int C, int relu) {
+                                                       float* __restrict__ y, long long M, int C, int relu, const double* __restrict__ sums,
+                                                       float* __restrict__ run_mean, float* __restrict__ run_var, float momentum, float eps) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
-    if (c >= C) return;
-    const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c), g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    float4 mu, is;
+    if constexpr (FIN) {
+        __shared__ __attribute__((aligned(16))) float s_mu[64], s_is[64];
+        const int ch = blockIdx.x * 64 + threadIdx.x;
+        if (threadIdx.x < 64 && ch < C) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int r = 0; r < MT4_STAT_REPLICAS; ++r) { s1 += sums[(long long)(2 * r) * C + ch]; s2 += sums[(long long)(2 * r + 1) * C + ch]; }
+            const double m_ = s1 / (double)M;
+            double var = s2 / (double)M - m_ * m_;
+            var = var > 0.0 ? var : 0.0;
+            const float mf = (float)m_, isf = (float)(1.0 / sqrt(var + (double)eps));
+            s_mu[threadIdx.x] = mf;
+            s_is[threadIdx.x] = isf;
+            if (blockIdx.y == 0) {
+                mean[ch] = mf;
+                invstd[ch] = isf;
+                if (run_mean) {
+                    run_mean[ch] = (1.f - momentum) * run_mean[ch] + momentum * mf;
+                    run_var[ch] = (1.f - momentum) * run_var[ch] + momentum * (float)(var * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+                }
+            }
+        }
+        __syncthreads();
+        if (c >= C) return;
+        mu = *(const float4*)(s_mu + (threadIdx.x & 15) * 4);
+        is = *(const float4*)(s_is + (threadIdx.x & 15) * 4);
+    } else {
+        if (c >= C) return;
+        mu = *(const float4*)(mean + c);
+        is = *(const float4*)(invstd + c);
+    }
+    const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
     const long long st = (long long)gridDim.y * 16;
     long long m = (long long)blockIdx.y * 16 + (threadIdx.x >> 4);
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -133,8 +169,19 @@ extern "C" int mt4_bn_apply_f32(const float* x, const float* mean, const float* 
     mt4_clear_error();
     if (!x || !mean || !invstd || !gamma || !beta || !y || M <= 0 || C <= 0) return MT4_EINVAL;
     if (C % 4) return MT4_EALIGN;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(C, 64), bn_row_slabs(M, C)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, residual,
-                       y, (long long)M, C, relu);
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(cdiv(C, 64), bn_row_slabs(M, C)), dim3(256), 0, (hipStream_t)stream, x, (float*)mean, (float*)invstd,
+                       gamma, beta, residual, y, (long long)M, C, relu, (const double*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0.f);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_bn_apply_sums_f32(const float* x, const double* stat_sums, float* mean, float* invstd, float* running_mean, float* running_var,
+                                     const float* gamma, const float* beta, const float* residual, float* y, int64_t M, int32_t C, float momentum,
+                                     float eps, int32_t relu, void* stream) {
+    mt4_clear_error();
+    if (!x || !stat_sums || !mean || !invstd || !gamma || !beta || !y || M <= 0 || C <= 0) return MT4_EINVAL;
+    if (C % 4) return MT4_EALIGN;
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(cdiv(C, 64), bn_row_slabs(M, C)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, residual,
+                       y, (long long)M, C, relu, stat_sums, running_mean, running_var, momentum, eps);
     return mt4_check_launch();
 }
 

@@ -889,6 +889,22 @@ def bn_stats_t(x2d, running_mean=None, running_var=None, momentum=0.1, eps=1e-5,
     return mean, invstd
 
 
+def bn_apply_sums(x2d, stat_sums, gamma, beta, residual=None, relu=True, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """fp32 twin of `bn_apply_sums_t`: fp32 convolution output, fp32 activation.  Returns (y, mean, invstd)"""
+    _need_cuda(x2d, stat_sums, gamma, beta, residual)
+    m, c = x2d.shape
+    assert x2d.dtype == torch.float32 and x2d.is_contiguous() and stat_sums.dtype == torch.float64 and stat_sums.numel() == STAT_REPLICAS * 2 * c
+    mean = torch.empty(c, dtype=torch.float32, device=x2d.device)
+    invstd = torch.empty_like(mean)
+    y = torch.empty_like(x2d)
+    check(lib.mt4_bn_apply_sums_f32(x2d.data_ptr(), stat_sums.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                    running_mean.data_ptr() if running_mean is not None else None,
+                                    running_var.data_ptr() if running_var is not None else None, gamma.data_ptr(), beta.data_ptr(),
+                                    residual.data_ptr() if residual is not None else None, y.data_ptr(), m, c, momentum, eps, 1 if relu else 0, _stream()),
+          "mt4_bn_apply_sums_f32")
+    return y, mean, invstd
+
+
 def bn_apply_sums_t(x2d, stat_sums, gamma, beta, residual=None, relu=True, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
     """train-mode BatchNorm of a convolution output from the channel sums the convolution's epilogue left (`conv_nhwc(stat_sums=...)`): ONE launch
     computes mean / invstd (returned for the backward), updates the running statistics and applies y = act((x - mean) * invstd * gamma + beta

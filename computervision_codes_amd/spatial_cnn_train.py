@@ -52,8 +52,8 @@ class SpatialCnnTrainer:
         # bfloat16: the convolutions' GEMM operands (activations, activation gradients, weight copies) are bf16, sums fp32 / fp64, master
         # weights + gradients + SGD fp32 (csrc/train2d_bf16.hip); the stem's 7x7x3 convolution and the heads / KD branch stay fp32
         self.op16 = operand_dtype == torch.bfloat16
-        # bf16 mode: BatchNorm statistics from the producing convolution's epilogue (MT4_NO_EPILOGUE_STATS=1: the separate pass over the map)
-        self.epilogue_stats = self.op16 and not os.environ.get("MT4_NO_EPILOGUE_STATS")
+        # BatchNorm statistics from the producing convolution's epilogue (MT4_NO_EPILOGUE_STATS=1: the separate pass over the map)
+        self.epilogue_stats = not os.environ.get("MT4_NO_EPILOGUE_STATS")
         self.loss_type = loss_type
         self.heads = _ALL_HEADS if loss_type == "all" else tuple(h for h in _ALL_HEADS if h[0] == loss_type)
         self.NH = sum(k for _, k in self.heads)
@@ -258,12 +258,12 @@ class SpatialCnnTrainer:
     # ------------------------------------------------------------------ building blocks
     def _fwd_unit(self, u: _Unit, x, residual=None, relu=True, saved=None):
         w = u.w16 if (self.op16 and u.cin != 4) else u.w            # (bf16 mode: the stem reads the fp32 image with its fp32 weights)
-        if self.op16 and self.epilogue_stats:
+        if self.epilogue_stats:
             # the BatchNorm statistics ride in the convolution's epilogue, mean / invstd are evaluated inside the apply launch: no pass over z
             z = ops.conv_nhwc(x, w, None, kh=u.k, kw=u.k, stride=(u.stride, u.stride), pad=(u.pad, u.pad), stat_sums=u.sums_f)
             b, ho, wo, c = z.shape
-            a, mean, invstd = ops.bn_apply_sums_t(z.view(-1, c), u.sums_f, u.gamma, u.beta, residual.view(-1, c) if residual is not None else None, relu,
-                                                  u.rmean, u.rvar)
+            apply = ops.bn_apply_sums_t if self.op16 else ops.bn_apply_sums
+            a, mean, invstd = apply(z.view(-1, c), u.sums_f, u.gamma, u.beta, residual.view(-1, c) if residual is not None else None, relu, u.rmean, u.rvar)
             a = a.view(b, ho, wo, c)
             if saved is not None:
                 saved.append((u, x, z, mean, invstd, a, relu, residual is not None))

@@ -32,7 +32,7 @@ extern "C" {
 
 /* 9 in this revision (5 -> 6: mt4_stem_maxpool_bf16, mt4_bottleneck_fused_next_bf16, mt4_pack_fragments_bf16, the x2 / fuse_expand fields at the
  * end of mt4_conv_desc; 6 -> 7: mt4_copy_spans_u8; 7 -> 8: mt4_chain_gemm_bf16; 8 -> 9: stat_sums at the end of
- * mt4_conv_desc, mt4_bn_apply_sums_t, mt4_avgpool1d_rows, mt4_interp_linear_rows, `beta` / relu code 2 of mt4_bn_backward_f32, MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup in mt4_refresh_weights).  A binding checks it once at load
+ * mt4_conv_desc, mt4_bn_apply_sums_t / _f32, mt4_avgpool1d_rows, mt4_interp_linear_rows, `beta` / relu code 2 of mt4_bn_backward_f32, MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup in mt4_refresh_weights).  A binding checks it once at load
  * (computervision_codes_amd/_lib.py: ABI_VERSION). */
 int mt4_abi_version(void);
 const char* mt4_strerror(int code);
@@ -337,6 +337,12 @@ int mt4_bn_stats_f32(const float* x, double* sums_zeroed, float* mean, float* in
 /* y = act((x - mean) * invstd * gamma + beta [+ residual]); relu 0/1 (resnet.py:105-119) */
 int mt4_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* residual,
                      float* y, int64_t M, int32_t C, int32_t relu, void* stream);
+/* the statistics step of mt4_bn_stats_f32 + mt4_bn_apply_f32 in ONE launch, from the channel sums a convolution's epilogue left
+ * (mt4_conv_desc.stat_sums, [MT4_STAT_REPLICAS][2][C]); mean / invstd are written for the backward, the running statistics advance: the fp32 twin
+ * of mt4_bn_apply_sums_t */
+int mt4_bn_apply_sums_f32(const float* x, const double* stat_sums, float* mean, float* invstd, float* running_mean, float* running_var,
+                          const float* gamma, const float* beta, const float* residual, float* y, int64_t M, int32_t C, float momentum, float eps,
+                          int32_t relu, void* stream);
 /* backward of the above: dy' = gated dy; dx (w.r.t. x), dres = dy' (w.r.t. residual, may be NULL), dgamma, dbeta.  relu: 0 none; 1 the gate is
  * y_post > 0; 2 it is recomputed from x -- (x - mean) * invstd * gamma + beta > 0, the forward's own fp32 expression = the stored y bit for bit
  * (units WITHOUT a residual input): y_post may be NULL and is not read.  beta: needed for relu 2 only.  sums_zeroed: 2*C float64. */

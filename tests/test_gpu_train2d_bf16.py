@@ -93,6 +93,7 @@ def test_batchnorm_bf16_fwd_bwd(cuda, m, c, relu, res, xf32):
 @pytest.mark.parametrize("b,h,w,cin,cout,k,s,dt,tile", [
     (2, 24, 40, 64, 64, 1, 1, "bf16", 0), (2, 24, 40, 64, 256, 1, 1, "bf16", 0), (3, 13, 21, 128, 128, 3, 1, "bf16", 0), (8, 64, 112, 64, 64, 3, 1, "bf16", 0),
     (2, 30, 52, 256, 512, 1, 2, "bf16", 0), (2, 24, 40, 64, 64, 1, 1, "bf16", 17), (2, 24, 40, 64, 128, 1, 1, "bf16", 5), (1, 40, 72, 4, 64, 7, 2, "f32", 0),
+    (2, 24, 40, 64, 256, 1, 1, "f32", 0), (3, 13, 21, 128, 128, 3, 1, "f32", 0),
     (2, 16, 20, 64, 72, 1, 1, "bf16", 0)])
 def test_conv_epilogue_statistics(cuda, b, h, w, cin, cout, k, s, dt, tile):
     """`mt4_conv_desc.stat_sums`: the replicas add up to the float64 column sums / sums of squares of the map the launch stored (generic tiles,
@@ -121,6 +122,13 @@ def test_conv_epilogue_statistics(cuda, b, h, w, cin, cout, k, s, dt, tile):
     mean0, invstd0 = ops.bn_stats_t(y.view(m, cout), rm0, rv0, sums=torch.zeros(2 * cout, dtype=torch.float64, device=cuda))
     a0 = ops.bn_apply_t(y.view(m, cout), mean0, invstd0, g, bt, res, True)
     assert torch.equal(mean, mean0) and torch.equal(invstd, invstd0) and torch.equal(rm, rm0) and torch.equal(rv, rv0) and torch.equal(a, a0)
+    if dt == "f32":   # the fp32 twin: fp32 residual and activation
+        r32 = res.float()
+        rm1, rv1, rm2, rv2 = torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda), torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda)
+        a1, mean1, invstd1 = ops.bn_apply_sums(y.view(m, cout), sums, g, bt, r32, True, rm1, rv1)
+        mean2, invstd2 = ops.bn_stats(y.view(m, cout), rm2, rv2)
+        a2 = ops.bn_apply(y.view(m, cout), mean2, invstd2, g, bt, r32, True)
+        assert torch.equal(mean1, mean2) and torch.equal(invstd1, invstd2) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2) and torch.equal(a1, a2)
 
 
 def test_conv_epilogue_statistics_refusals(cuda):
