@@ -69,9 +69,8 @@ class TencoTrainer:
         total = sum(sizes)
         self.P = torch.zeros(total, dtype=f32, device=self.dev)
         self.G = torch.zeros(total, dtype=f32, device=self.dev)
-        wt_total = sum(cin * ops.packed_k(cout, 1, taps, f32) for _, cout, cin, taps in specs if _ != "PG.conv_1x1")
-        self.WT = torch.zeros(wt_total, dtype=f32, device=self.dev)
-        off = wo = 0
+        self._tab = ops.RefreshTable(self.dev)   # the transposed, tap-reversed data-gradient operators: ONE launch after every update
+        off = 0
         self._ranges: Dict[str, list] = {}     # flat-buffer range of every gradient bucket: "PG", "Rs.0".."Rs.2", "heads" (FPN lateral + heads)
         for name, cout, cin, taps in specs:
             bucket = name.split(".layers.")[0] if ".layers." in name else ("PG" if name == "PG.conv_1x1" else "heads")
@@ -93,12 +92,8 @@ class TencoTrainer:
                 w, b = sd[name + ".weight"].float(), sd[name + ".bias"].float()
             c.w.copy_(ops.pack_conv_weight(w.to(self.dev).unsqueeze(2), None, f32))
             c.b.copy_(b.to(self.dev))
-            if name != "PG.conv_1x1":   # the input projection needs no data gradient
-                kt = ops.packed_k(cout, 1, taps, f32)
-                c.wt = self.WT[wo:wo + cin * kt].view(cin, kt)
-                wo += cin * kt
-            else:
-                c.wt = None
+            # (the input projection needs no data gradient)
+            c.wt = self._tab.add(c.w, cout, cin, f32, True, [taps - 1 - i for i in range(taps)]) if name != "PG.conv_1x1" else None
             self.convs[name] = c
         trained = {n + suffix for n, *_ in specs for suffix in (".weight", ".bias")} | \
                   {f"conv_out{s}.{p}" for s, _, _ in HEADS for p in ("weight", "bias")}
@@ -107,9 +102,8 @@ class TencoTrainer:
         return self
 
     def _refresh_transposed(self):
-        for c in self.convs.values():
-            if c.wt is not None:
-                ops.transpose_pack_conv1d(c.w, c.cout, c.cin, c.taps, out=c.wt)
+        """(a launch of `mt4_transpose_pack_conv1d_f32` per layer was 98 launches = 0.5 ms of an 8 ms whole-video step)"""
+        self._tab.run()
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """reference layout and key names (`Temporal_tenco/network.py`), on the CPU"""
@@ -257,6 +251,9 @@ class TencoTrainer:
         logits = [self._conv(l, hd) for l in levels]                          # [1,1,T,132], column 131 is padding (= 0)
 
         # ---- loss + dL/dlogits
+        # every weight / bias gradient below ADDS into the flat buffer, zeroed here once: zeroing per tensor in front of its (atomic) sums was
+        # ~150 launches = 0.8 ms of an 8 ms whole-video step
+        self.G.zero_()
         col_scale = self._col_scale(T)
         col_loss = torch.zeros(NH, device=dev)
         dys = []
@@ -268,13 +265,13 @@ class TencoTrainer:
         g = None
         dstage = [None, None, None, None]
         for li, (lv, dy) in enumerate(zip(levels, dys)):
-            ops.wgrad_conv1d(dy.view(T, NHP), lv.view(T, C), hd.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=li > 0)
-            ops.colsum(dy.view(T, NHP), hd.gb, accumulate=li > 0)
+            ops.wgrad_conv1d(dy.view(T, NHP), lv.view(T, C), hd.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True)
+            ops.colsum(dy.view(T, NHP), hd.gb, accumulate=True)
             g = self._conv(dy, hd, transposed=True, residual=g)               # gradient w.r.t. p_{li+1}
             if li < 3:
                 cl_ = stage_out[li]                                            # lateral input c_{li+1}
-                ops.wgrad_conv1d(g.view(T, C), cl_.view(T, C), lat.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=li > 0)
-                ops.colsum(g.view(T, C), lat.gb, accumulate=li > 0)
+                ops.wgrad_conv1d(g.view(T, C), cl_.view(T, C), lat.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True)
+                ops.colsum(g.view(T, C), lat.gb, accumulate=True)
                 dstage[li] = self._conv(g, lat, transposed=True)
             else:
                 dstage[3] = g                                                  # p4 is the last stage's output itself
@@ -289,18 +286,18 @@ class TencoTrainer:
                 p, d, zin, u = saved[idx]
                 w1, wd = cv[p + ".conv_1x1"], cv[p + ".conv_dilated"]
                 do = ops.mul_add(df, lm[p]) if p in lm else df
-                ops.wgrad_conv1d(do.view(T, C), u.view(T, C), w1.gw, batch=1, t=T, taps=1, dil=1, pad=0)
-                ops.colsum(do.view(T, C), w1.gb)
+                ops.wgrad_conv1d(do.view(T, C), u.view(T, C), w1.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True)
+                ops.colsum(do.view(T, C), w1.gb, accumulate=True)
                 du = self._conv(do, w1, transposed=True, residual=u, act="relu_gate")
-                ops.wgrad_conv1d(du.view(T, C), zin.view(T, C), wd.gw, batch=1, t=T, taps=3, dil=d, pad=d)
-                ops.colsum(du.view(T, C), wd.gb)
+                ops.wgrad_conv1d(du.view(T, C), zin.view(T, C), wd.gw, batch=1, t=T, taps=3, dil=d, pad=d, accumulate=True)
+                ops.colsum(du.view(T, C), wd.gb, accumulate=True)
                 df = self._conv(du, wd, dil=d, transposed=True, residual=df)
             if si > 0:
                 df = ops.mul_add(df, torch.ones_like(df), dstage[si - 1])      # + gradient of this stage's input as lateral c
                 self._reduce_bucket(prefix)                                    # this stage's gradients are complete: exchange them behind
         pin = cv["PG.conv_1x1"]                                                #   the backward of the earlier stages
-        ops.wgrad_conv1d(df.view(T, C), h0.view(T, self.D), pin.gw, batch=1, t=T, taps=1, dil=1, pad=0)
-        ops.colsum(df.view(T, C), pin.gb)
+        ops.wgrad_conv1d(df.view(T, C), h0.view(T, self.D), pin.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True)
+        ops.colsum(df.view(T, C), pin.gb, accumulate=True)
         self._reduce_bucket("PG")
         return col_loss
 
