@@ -240,8 +240,8 @@ class MstctTrainer:
         if c.w16 is not None and m % 16 == 0 and dy2d.is_contiguous() and x2d.is_contiguous():    # rows as a [M / 16, 16] pixel grid of one image
             ops.wgrad_conv2d_bf16(self._cast(dy2d, grad=True).view(1, m // 16, 16, c.cout), self._cast(x2d).view(1, m // 16, 16, c.cin), c.gw, 1, 1)
         else:
-            ops.wgrad_conv1d(dy2d, x2d, c.gw, batch=1, t=m, taps=1, dil=1, pad=0)
-        ops.colsum(dy2d, c.gb)
+            ops.wgrad_conv1d(dy2d, x2d, c.gw, batch=1, t=m, taps=1, dil=1, pad=0, accumulate=True)   # (G is zeroed once per step)
+        ops.colsum(dy2d, c.gb, accumulate=True)
 
     def _ln(self, x, name):
         return ops.layernorm(x, self.vecs[name + ".weight"].p, self.vecs[name + ".bias"].p)
@@ -390,8 +390,8 @@ class MstctTrainer:
             dpm = self._ln_bwd(g, st["pm"], m + ".norm")
             pc = L[m + ".proj"]
             xin = st["x_in"]
-            ops.wgrad_conv1d(dpm.view(b, t, c), xin.view(b, t, -1), pc.gw, batch=b, t=t, taps=3, dil=1, pad=1)
-            ops.colsum(dpm, pc.gb)
+            ops.wgrad_conv1d(dpm.view(b, t, c), xin.view(b, t, -1), pc.gw, batch=b, t=t, taps=3, dil=1, pad=1, accumulate=True)
+            ops.colsum(dpm, pc.gb, accumulate=True)
             gnext = ops.conv_nhwc(dpm.view(b, 1, t, c), pc.wt, None, kh=1, kw=3, pad=(0, 1)).view(M, -1) if s > 1 else None
         return col_loss
 
