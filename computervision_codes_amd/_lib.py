@@ -90,7 +90,7 @@ SIGNATURES = {
     "mt4_groupwise_linear": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_dwconv1d_k3": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mt4_kd_mix": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
-    "mt4_wgrad_conv1d_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_wgrad_conv1d_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mt4_colsum_f32": (C.c_int, [_vp, _vp, C.c_int64, _i32, _i32, _i32, _vp]),
     "mt4_bce_logits_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _i32, _vp]),
     "mt4_sgd_step_f32": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float, _vp]),

@@ -17,7 +17,10 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // time in chunks of 32 rows; wave w owns output rows [16w, 16w+16) x 64 columns.
 __global__ __launch_bounds__(256) void wgrad_conv1d_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                float* __restrict__ dw, int B, int T, int Cout, int Cin, int taps,
-                                                               int dil, int pad, int Kpad, int accumulate, long long rows_per_split) {
+                                                               int dil, int pad, int Kpad, int accumulate, long long rows_per_split,
+                                                               float* __restrict__ gb) {
+    // gb (optional): the bias gradient gb[co] += sum over rows of dy[.][co], taken by the workgroups of the first K column tile from the dY rows
+    // they stage anyway (a launch of colsum_f32_kernel per layer was 139 launches = 0.4 ms of a 7.4 ms whole-video step of the TCN trainer)
     // gridDim.z > 1: the time range is split over workgroups that add their partial tile with fp32 atomics (dW zeroed by the host
     // wrapper unless accumulating) -- a 512 x 1536 weight has only 192 tiles, one per CU with nothing to overlap its load latency
     constexpr int KT = 32, LDP = 68;  // 64 columns + 4 pad floats: the 4 k-rows of a fragment read hit distinct banks
@@ -39,6 +42,8 @@ __global__ __launch_bounds__(256) void wgrad_conv1d_f32_kernel(const float* __re
     const long long mb = (long long)blockIdx.z * rows_per_split;
     const long long M = mb + rows_per_split < Mall ? mb + rows_per_split : Mall;
     float4 ry[2], rx[2];
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);           // this thread's share of the column sums of dY (rows sr + 16 i of every chunk)
+    const bool do_gb = gb != nullptr && blockIdx.x == 0;
     auto fetch = [&](long long m0) {   // the next chunk's loads fly while the current chunk runs its MFMAs
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -61,6 +66,7 @@ __global__ __launch_bounds__(256) void wgrad_conv1d_f32_kernel(const float* __re
             const int r = sr + 16 * i;
             *(float4*)(sdy + r * LDP + sc) = ry[i];
             *(float4*)(sx + r * LDP + sc) = rx[i];
+            cs.x += ry[i].x; cs.y += ry[i].y; cs.z += ry[i].z; cs.w += ry[i].w;
         }
         __syncthreads();
         if (m0 + KT < M) fetch(m0 + KT);
@@ -90,6 +96,17 @@ __global__ __launch_bounds__(256) void wgrad_conv1d_f32_kernel(const float* __re
             else *p = accumulate ? *p + acc[n][e] : acc[n][e];
         }
     }
+    if (do_gb) {   // fold the 16 row lanes of every column group through LDS (the operand tiles are dead), one atomic per column and workgroup
+        float* red = sdy;                                   // [16 row lanes][64 columns]
+        *(float4*)(red + sr * 64 + sc) = cs;
+        __syncthreads();
+        if (tid < 64 && co0 + tid < Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += red[r * 64 + tid];
+            atomicAdd(gb + co0 + tid, t);
+        }
+    }
 }
 
 // zero-fill as a KERNEL node: a hipMemsetAsync captured into one of several consecutive hipGraphs of a stream (graph.SegmentedGraph) left parts of
@@ -106,7 +123,7 @@ static inline void zero_f32(float* p, long long n, hipStream_t s) {   // p 16-by
 }
 
 extern "C" int mt4_wgrad_conv1d_f32(const float* dy, const float* x, float* dw_packed, int32_t B, int32_t T, int32_t Cout, int32_t Cin,
-                                    int32_t taps, int32_t dil, int32_t pad, int32_t accumulate, void* stream) {
+                                    int32_t taps, int32_t dil, int32_t pad, int32_t accumulate, float* bias_grad, void* stream) {
     mt4_clear_error();
     if (!dy || !x || !dw_packed || B <= 0 || T <= 0 || Cout <= 0 || Cin <= 0 || taps <= 0 || dil <= 0 || pad < 0) return MT4_EINVAL;
     if (Cin % 4 || Cout % 4 || (((uintptr_t)dy | (uintptr_t)x) & 15)) return MT4_EALIGN;
@@ -122,7 +139,7 @@ extern "C" int mt4_wgrad_conv1d_f32(const float* dy, const float* x, float* dw_p
     splits = (M + rps - 1) / rps;
     if (splits > 1 && !accumulate) zero_f32(dw_packed, (long long)Cout * Kpad, s);
     const dim3 grid(cdiv(Kpad, 64), cdiv(Cout, 64), (unsigned)splits);
-    hipLaunchKernelGGL(wgrad_conv1d_f32_kernel, grid, dim3(256), 0, s, dy, x, dw_packed, B, T, Cout, Cin, taps, dil, pad, Kpad, accumulate, rps);
+    hipLaunchKernelGGL(wgrad_conv1d_f32_kernel, grid, dim3(256), 0, s, dy, x, dw_packed, B, T, Cout, Cin, taps, dil, pad, Kpad, accumulate, rps, bias_grad);
     return mt4_check_launch();
 }
 

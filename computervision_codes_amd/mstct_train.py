@@ -239,9 +239,9 @@ class MstctTrainer:
         m = dy2d.shape[0]
         if c.w16 is not None and m % 16 == 0 and dy2d.is_contiguous() and x2d.is_contiguous():    # rows as a [M / 16, 16] pixel grid of one image
             ops.wgrad_conv2d_bf16(self._cast(dy2d, grad=True).view(1, m // 16, 16, c.cout), self._cast(x2d).view(1, m // 16, 16, c.cin), c.gw, 1, 1)
-        else:
-            ops.wgrad_conv1d(dy2d, x2d, c.gw, batch=1, t=m, taps=1, dil=1, pad=0, accumulate=True)   # (G is zeroed once per step)
-        ops.colsum(dy2d, c.gb, accumulate=True)
+            ops.colsum(dy2d, c.gb, accumulate=True)
+        else:   # (G is zeroed once per step; the bias gradient rides in the weight gradient's launch)
+            ops.wgrad_conv1d(dy2d, x2d, c.gw, batch=1, t=m, taps=1, dil=1, pad=0, accumulate=True, bias_grad=c.gb)
 
     def _ln(self, x, name):
         return ops.layernorm(x, self.vecs[name + ".weight"].p, self.vecs[name + ".bias"].p)
@@ -390,8 +390,7 @@ class MstctTrainer:
             dpm = self._ln_bwd(g, st["pm"], m + ".norm")
             pc = L[m + ".proj"]
             xin = st["x_in"]
-            ops.wgrad_conv1d(dpm.view(b, t, c), xin.view(b, t, -1), pc.gw, batch=b, t=t, taps=3, dil=1, pad=1, accumulate=True)
-            ops.colsum(dpm, pc.gb, accumulate=True)
+            ops.wgrad_conv1d(dpm.view(b, t, c), xin.view(b, t, -1), pc.gw, batch=b, t=t, taps=3, dil=1, pad=1, accumulate=True, bias_grad=pc.gb)
             gnext = ops.conv_nhwc(dpm.view(b, 1, t, c), pc.wt, None, kh=1, kw=3, pad=(0, 1)).view(M, -1) if s > 1 else None
         return col_loss
 

@@ -712,13 +712,15 @@ def kd_mix(s: torch.Tensor, ti: torch.Tensor, tv: torch.Tensor, tt: torch.Tensor
 
 # ----------------------------------------------------------------------------------------- training pieces (fp32)
 def wgrad_conv1d(dy: torch.Tensor, x: torch.Tensor, dw_packed: torch.Tensor, *, batch: int, t: int, taps: int, dil: int, pad: int,
-                 accumulate: bool = False) -> None:
-    _need_cuda(dy, x, dw_packed)
+                 accumulate: bool = False, bias_grad: Optional[torch.Tensor] = None) -> None:
+    """bias_grad [cout] (optional, zeroed by the caller): += the column sums of dy in the same launch (instead of `colsum`)"""
+    _need_cuda(dy, x, dw_packed, bias_grad)
     assert dy.dtype == x.dtype == dw_packed.dtype == torch.float32 and dy.is_contiguous() and x.is_contiguous() and dw_packed.is_contiguous()
     cout, cin = dy.shape[-1], x.shape[-1]
     assert dw_packed.shape == (cout, packed_k(cin, 1, taps, torch.float32)) and dy.numel() == batch * t * cout
+    assert bias_grad is None or (bias_grad.dtype == torch.float32 and bias_grad.numel() >= cout)
     check(lib.mt4_wgrad_conv1d_f32(dy.data_ptr(), x.data_ptr(), dw_packed.data_ptr(), batch, t, cout, cin, taps, dil, pad,
-                                   1 if accumulate else 0, _stream()), "mt4_wgrad_conv1d_f32")
+                                   1 if accumulate else 0, bias_grad.data_ptr() if bias_grad is not None else None, _stream()), "mt4_wgrad_conv1d_f32")
 
 
 def colsum(x2d: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> None:

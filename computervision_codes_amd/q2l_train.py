@@ -304,10 +304,10 @@ class Q2LTrainer:
             x = x if x.is_contiguous() else x.contiguous()
             dy16 = self._cast(dy, grad=True)
             ops.wgrad_conv2d_bf16(dy16.view(1, m // 16, 16, l.cout), self._cast(x).view(1, m // 16, 16, l.cin), l.gw, 1, 1)   # (adds to gw)
-        else:
-            ops.wgrad_conv1d(dy, x, l.gw, batch=1, t=m, taps=1, dil=1, pad=0, accumulate=True)
-        if l.gb is not None:
-            ops.colsum(dy, l.gb, accumulate=True)
+            if l.gb is not None:
+                ops.colsum(dy, l.gb, accumulate=True)
+        else:   # (the bias gradient rides in the weight gradient's launch)
+            ops.wgrad_conv1d(dy, x, l.gw, batch=1, t=m, taps=1, dil=1, pad=0, accumulate=True, bias_grad=l.gb)
         if not need_dx:
             return None
         if mixed and l.wt16 is not None:

@@ -4,7 +4,7 @@ backward and SGD, as `Temporal_tenco/run.py:181-235` does with autograd -- here 
 * forward: the inference kernels (`mt4_conv_nhwc`), keeping each layer's input and ReLU output;
 * data gradients: the SAME implicit-GEMM kernel with transposed / tap-reversed weights (`mt4_transpose_pack_conv1d_f32`),
   the ReLU gate and the residual fan-in fused into its epilogue (act "relu_gate", `residual`);
-* weight gradients: `mt4_wgrad_conv1d_f32` (fp32 MFMA, contraction over time), bias gradients `mt4_colsum_f32`;
+* weight gradients: `mt4_wgrad_conv1d_f32` (fp32 MFMA, contraction over time), the bias gradient (column sums of dY) in the same launch;
 * loss: `mt4_bce_logits_f32` on the concatenated [T][131] heads; optimizer: `mt4_sgd_step_f32` on ONE flat parameter
   buffer (packed layouts), so DDP is ONE all-reduce of the flat gradient buffer over RCCL (videos shard over ranks).
 
@@ -265,13 +265,11 @@ class TencoTrainer:
         g = None
         dstage = [None, None, None, None]
         for li, (lv, dy) in enumerate(zip(levels, dys)):
-            ops.wgrad_conv1d(dy.view(T, NHP), lv.view(T, C), hd.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True)
-            ops.colsum(dy.view(T, NHP), hd.gb, accumulate=True)
+            ops.wgrad_conv1d(dy.view(T, NHP), lv.view(T, C), hd.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True, bias_grad=hd.gb)
             g = self._conv(dy, hd, transposed=True, residual=g)               # gradient w.r.t. p_{li+1}
             if li < 3:
                 cl_ = stage_out[li]                                            # lateral input c_{li+1}
-                ops.wgrad_conv1d(g.view(T, C), cl_.view(T, C), lat.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True)
-                ops.colsum(g.view(T, C), lat.gb, accumulate=True)
+                ops.wgrad_conv1d(g.view(T, C), cl_.view(T, C), lat.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True, bias_grad=lat.gb)
                 dstage[li] = self._conv(g, lat, transposed=True)
             else:
                 dstage[3] = g                                                  # p4 is the last stage's output itself
@@ -286,18 +284,15 @@ class TencoTrainer:
                 p, d, zin, u = saved[idx]
                 w1, wd = cv[p + ".conv_1x1"], cv[p + ".conv_dilated"]
                 do = ops.mul_add(df, lm[p]) if p in lm else df
-                ops.wgrad_conv1d(do.view(T, C), u.view(T, C), w1.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True)
-                ops.colsum(do.view(T, C), w1.gb, accumulate=True)
+                ops.wgrad_conv1d(do.view(T, C), u.view(T, C), w1.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True, bias_grad=w1.gb)
                 du = self._conv(do, w1, transposed=True, residual=u, act="relu_gate")
-                ops.wgrad_conv1d(du.view(T, C), zin.view(T, C), wd.gw, batch=1, t=T, taps=3, dil=d, pad=d, accumulate=True)
-                ops.colsum(du.view(T, C), wd.gb, accumulate=True)
+                ops.wgrad_conv1d(du.view(T, C), zin.view(T, C), wd.gw, batch=1, t=T, taps=3, dil=d, pad=d, accumulate=True, bias_grad=wd.gb)
                 df = self._conv(du, wd, dil=d, transposed=True, residual=df)
             if si > 0:
                 df = ops.mul_add(df, torch.ones_like(df), dstage[si - 1])      # + gradient of this stage's input as lateral c
                 self._reduce_bucket(prefix)                                    # this stage's gradients are complete: exchange them behind
         pin = cv["PG.conv_1x1"]                                                #   the backward of the earlier stages
-        ops.wgrad_conv1d(df.view(T, C), h0.view(T, self.D), pin.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True)
-        ops.colsum(df.view(T, C), pin.gb, accumulate=True)
+        ops.wgrad_conv1d(df.view(T, C), h0.view(T, self.D), pin.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True, bias_grad=pin.gb)
         self._reduce_bucket("PG")
         return col_loss
 

@@ -181,8 +181,11 @@ def test_wgrad_conv1d_long_rows_vs_autograd(cuda, b, t, cout, cin, taps, dil):
     got = dw[:, :taps * cin].reshape(cout, taps, cin).permute(0, 2, 1).cpu()
     assert (got - w.grad).abs().max().item() < 2e-5 * max(1.0, w.grad.abs().max().item())
     assert float(dw[:, taps * cin:].abs().max()) == 0.0 if kp > taps * cin else True
-    ops.wgrad_conv1d(dy.to(cuda), x.to(cuda), dw, batch=b, t=t, taps=taps, dil=dil, pad=pad, accumulate=True)
+    gb = torch.full((cout,), 0.5, device=cuda)                         # the bias gradient rides in the same launch, ADDED to what is there
+    ops.wgrad_conv1d(dy.to(cuda), x.to(cuda), dw, batch=b, t=t, taps=taps, dil=dil, pad=pad, accumulate=True, bias_grad=gb)
     assert (dw[:, :taps * cin].reshape(cout, taps, cin).permute(0, 2, 1).cpu() - 2 * w.grad).abs().max().item() < 4e-5 * max(1.0, w.grad.abs().max().item())
+    colsum = dy.reshape(-1, cout).double().sum(0)
+    assert ((gb.cpu().double() - 0.5) - colsum).abs().max().item() < 2e-5 * max(1.0, colsum.abs().max().item())
 
 
 def test_mstct_bf16_operand_step_vs_reference_fixture(cuda):
