@@ -332,8 +332,7 @@ class SpatialCnnTrainer:
 
     def _linear_bwd(self, name, dy, x, need_dx=True):
         w, b, gw, gb, co, ci = self.lin[name]
-        ops.wgrad_conv1d(dy, x, gw, batch=1, t=x.shape[0], taps=1, dil=1, pad=0)
-        ops.colsum(dy, gb)
+        ops.wgrad_conv1d(dy, x, gw, batch=1, t=x.shape[0], taps=1, dil=1, pad=0, accumulate=True, bias_grad=gb)   # (G is zeroed once per step)
         if not need_dx:
             return None
         wt = ops.transpose_pack_conv1d(w, co, ci, 1)
