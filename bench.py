@@ -127,18 +127,29 @@ def cpu_baseline_spatial(network, h, w, seed):
     sd = synth.fill_from_shapes(shapes.spatial_cnn_shapes(network), seed=seed)
     bs = 8
     img = synth.normalize_frames(synth.synthetic_frames(bs, h, w, seed=seed))
+    reps = []
     with torch.no_grad():
         o_cnn.spatial_cnn_forward(sd, img, network)  # warm-up
-        t0 = time.perf_counter()
-        n = 0
-        while True:
-            o_cnn.spatial_cnn_forward(sd, img, network)
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt > 12.0 or n >= 30:
-                break
-    return dict(value=round(bs * n / dt, 2), unit="frames/s", cores=torch.get_num_threads(), kind="port", cpu=cpu_model(), os_cpu_count=os.cpu_count(),
-                sample=f"{n} batches of {bs} frames {h}x{w}, torch-CPU fp32 oracle, eval, no_grad")
+        o_cnn.spatial_cnn_forward(sd, img, network)
+        t_all = time.perf_counter()
+        # >= 5 independent repeats of ~2.5 s each (the host cores are shared with other tenants of the node: one long loop drifted 133-211
+        # frames/s between driver runs); value = the MEDIAN repeat, the spread is published beside it
+        while len(reps) < 7 and (len(reps) < 5 or time.perf_counter() - t_all < 20.0):
+            t0 = time.perf_counter()
+            n = 0
+            while True:
+                o_cnn.spatial_cnn_forward(sd, img, network)
+                n += 1
+                dt = time.perf_counter() - t0
+                if dt > 2.5 or n >= 30:
+                    break
+            reps.append((bs * n / dt, n))
+    rates = sorted(r for r, _ in reps)
+    med = rates[len(rates) // 2]
+    return dict(value=round(med, 2), unit="frames/s", cores=torch.get_num_threads(), kind="port", cpu=cpu_model(), os_cpu_count=os.cpu_count(),
+                repeats=len(rates), min=round(rates[0], 2), max=round(rates[-1], 2), spread=round((rates[-1] - rates[0]) / med, 3),
+                sample=f"median of {len(rates)} repeats of {reps[0][1]}-{max(n for _, n in reps)} batches of {bs} frames {h}x{w} each "
+                       f"(~{time.perf_counter() - t_all:.0f} s of CPU work), torch-CPU fp32 oracle, eval, no_grad")
 
 
 def _time_call(fn, iters=20):
@@ -729,7 +740,10 @@ def main():
         per_launch = time_conv_kernels(model, frames[:a.batch].contiguous())   # the launches of ONE stream's part of a step
         conv_ms = sum(per_launch)
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_MFMA_TFLOPS
-        achieved = flops_frame * a.batch / (conv_ms * 1e-3) / 1e12
+        # `achieved` / `frac` follow from the TIMED number: algorithmic conv FLOPs of the step's frames / ms_per_step (everything the step does --
+        # preprocess, avgpool, heads -- counts against it).  The conv-launches-only figure (HIP events around each launch) is kept beside it.
+        achieved = flops_frame * nstep / (ms_per_step * 1e-3) / 1e12
+        achieved_conv = flops_frame * a.batch / (conv_ms * 1e-3) / 1e12
         # HBM bytes and MFMA-busy share of the same launches from rocprofv3 PMC passes (tools/collect_traffic.py, tools/collect_mfma_util.py;
         # commands in profiles/README.md), collected OFFLINE and committed: a figure is published only while the sources of the measured
         # kernels are the ones it was collected on (`kernels_sha`), and the line says which collection it is; null otherwise
@@ -761,10 +775,12 @@ def main():
                         peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,
                         mfma_util_pmc=mfma_util, mfma_util_source=mfma_util_source,
                         launches_per_step=len(per_launch), conv_ms_per_step=round(conv_ms, 4), ms_per_step=round(ms_per_step, 4),
+                        achieved_conv_launches=round(achieved_conv, 2), frac_conv_launches=round(achieved_conv / peak, 4),
                         frames_in_conv_ms=a.batch,
                         gflop_per_frame=round(flops_frame / 1e9, 3), traffic_unit="HBM bytes per step (all conv launches)",
-                        note="launch durations from a single-stream pass over one stream's part of the step (HIP events on the launch stream); "
-                             "with --streams 1 that is the whole step: conv_ms_per_step <= ms_per_step, the rest is preprocess + avgpool + heads")
+                        note="achieved / frac = algorithmic conv FLOPs of the step / ms_per_step (the timed region); *_conv_launches = the same FLOPs / the "
+                             "summed durations of the step's conv launches (HIP events on the launch stream, one pair per launch): "
+                             "conv_ms_per_step <= ms_per_step, the rest is preprocess + avgpool + heads")
         if a.per_layer:
             plan = model.conv_plan(a.height, a.width)
             groups = model.launch_groups(a.height, a.width)
@@ -799,19 +815,26 @@ def main():
             # the per-video latency half of the metric, where the driver's parsed record keeps it
             t256, t2000 = res["temporal"]["tenco4_T256"], res["temporal"]["tenco4_T2000"]
             tcn_traffic, tcn_src = committed("traffic.json", "hbm_bytes_per_video", TCN_SOURCES, [("tenco4_f32_T256", 1.0)])
-            roofline["temporal"] = dict(
-                kernel="tcn_conv_kernel / igemm_conv_kernel launches of one Temporal_tenco forward (4 stages, D = 512), hipGraph replay",
-                tenco4_T256_ms=t256["ms_per_video"], tenco4_T256_bf16_ms=t256["ms_per_video_bf16"], tenco4_T2000_ms=t2000["ms_per_video"],
-                tenco4_T2000_bf16_ms=t2000["ms_per_video_bf16"], bound="hbm", algorithmic_MB_T256=t256["algorithmic_MB"],
-                hbm_frac_T256=t256["hbm_frac"], f32_mfma_frac_T256=t256["f32_mfma_frac"], hbm_frac_T2000=t2000["hbm_frac"],
-                f32_mfma_frac_T2000=t2000["f32_mfma_frac"], videos_per_s=res["temporal"].get("tenco4_throughput"),
-                traffic_MB_T256=round(tcn_traffic / 1e6, 1) if tcn_traffic else None,
-                traffic_ratio_T256=round(tcn_traffic / 1e6 / t256["algorithmic_MB"], 2) if tcn_traffic else None, traffic_source=tcn_src,
+            # SCALAR keys (the driver's parsed record keeps scalars of `roofline` only)
+            roofline.update(
+                tcn_kernel="tcn_conv_kernel / igemm_conv_kernel launches of one Temporal_tenco forward (4 stages, D = 512), hipGraph replay",
+                tcn_bound="hbm", tcn_T256_ms=t256["ms_per_video"], tcn_T256_bf16_ms=t256["ms_per_video_bf16"], tcn_T2000_ms=t2000["ms_per_video"],
+                tcn_T2000_bf16_ms=t2000["ms_per_video_bf16"], tcn_algorithmic_MB_T256=t256["algorithmic_MB"],
+                tcn_hbm_frac_T256=t256["hbm_frac"], tcn_f32_mfma_frac_T256=t256["f32_mfma_frac"], tcn_hbm_frac_T2000=t2000["hbm_frac"],
+                tcn_f32_mfma_frac_T2000=t2000["f32_mfma_frac"],
+                tcn_traffic_MB_T256=round(tcn_traffic / 1e6, 1) if tcn_traffic else None,
+                tcn_traffic_ratio_T256=round(tcn_traffic / 1e6 / t256["algorithmic_MB"], 2) if tcn_traffic else None, tcn_traffic_source=tcn_src,
+                tcn_cpu_T256_ms=t256.get("cpu_ms_per_video"), tcn_cpu_T2000_ms=t2000.get("cpu_ms_per_video"),
+                config1_T256_ms=res["temporal"]["config1_T256"]["ms_per_video"],
                 mstct_T256_ms=res["temporal"]["mstct_T256"]["ms_per_window"])
+            for k_, v_ in (res["temporal"].get("tenco4_throughput") or {}).items():
+                roofline[f"tcn_videos_per_s_{k_}"] = v_["videos_per_s"]
             if dtype == torch.bfloat16 and a.network == "resnet50":
                 res["native_256x448"] = native_resolution_bench(dev, model, a.streams)
                 res["student_resnet18"] = student_resnet18_bench(dev, a.streams)
             res["swin_q2l"] = swin_bench(dev)
+            sw = res["swin_q2l"].get("swin_B_384_22k_all") or {}
+            roofline.update(swin_b384_all_fps=sw.get("frames_per_s"), swin_b384_all_frac=sw.get("mfma_frac"))
             res["spatial_train"] = spatial_train_bench(dev)
             res["e2e_script"] = e2e_script_bench(dev)
             res["parity_mode_f32"] = parity_mode_bench(dev, a.network, a.height, a.width)
