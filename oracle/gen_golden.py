@@ -251,6 +251,9 @@ Q2L_CASES = {
     "q2l_swinB_384_t": dict(backbone="swin_B_384_22k", img=384, hidden=1024, loss_type="t", B=1, seed=303),
     # BASELINE configs[2] as a composite: Swin-B + the four decoders (triplet head K = 100, shared transformer) + the always-on KD mixing
     "q2l_swinB_384_all": dict(backbone="swin_B_384_22k", img=384, hidden=1024, loss_type="all", B=1, seed=305),
+    # the SHIPPED teacher (`Scripts/train_fold1.sh:5-12`: swin_L_384_22k, --hidden_dim 1536, --loss_type i; `swin_transformer.py:623-628`):
+    # C = 192, heads 6 / 12 / 24 / 48, Q2L d = 1536
+    "q2l_swinL_384_i": dict(backbone="swin_L_384_22k", img=384, hidden=1536, loss_type="i", B=1, seed=306),
 }
 
 
@@ -319,6 +322,8 @@ MSTCT_CASES = {
     "mstct_tiny": dict(D=64, inter=(32, 48, 64, 96), final=32, T=40, B=2, loss_type="ivt", seed=401),
     "mstct_full_i": dict(D=1024, inter=(256, 384, 576, 864), final=512, T=256, B=1, loss_type="i", seed=402),
     "mstct_full_ivt_ragged": dict(D=2048, inter=(256, 384, 576, 864), final=512, T=101, B=2, loss_type="ivt", seed=403),
+    # the shipped MS-TCT teacher reads the Swin-L features: `Scripts/train_fold1.sh:16-17` --input_dim 1536 --loss_type i
+    "mstct_D1536_i": dict(D=1536, inter=(256, 384, 576, 864), final=512, T=256, B=2, loss_type="i", seed=404),
 }
 
 
@@ -506,6 +511,7 @@ def gen_cnn_train(name):
 MSTCT_TRAIN_CASES = {
     "mstct_train_tiny": dict(D=64, inter=(32, 48, 64, 96), final=32, T=40, B=3, loss_type="v", seed=701, lr=0.1),
     "mstct_train_full": dict(D=512, inter=(256, 384, 576, 864), final=512, T=256, B=2, loss_type="ivt", seed=702, lr=0.1),
+    "mstct_train_D1536_i": dict(D=1536, inter=(256, 384, 576, 864), final=512, T=256, B=2, loss_type="i", seed=703, lr=0.1),   # shipped width
 }
 
 
@@ -579,6 +585,8 @@ def gen_mstct_train(name):
 Q2L_TRAIN_CASES = {
     "q2l_train_swinT_i": dict(backbone="swin_T_224_1k", img=224, hidden=768, loss_type="i", B=2, seed=801, lr=0.05),
     "q2l_train_swinT_t": dict(backbone="swin_T_224_1k", img=224, hidden=768, loss_type="t", B=3, seed=802, lr=0.05),
+    # one step of the shipped teacher recipe (`Scripts/train_fold1.sh:12`): Swin-L / 384, hidden 1536, task i
+    "q2l_train_swinL_i": dict(backbone="swin_L_384_22k", img=384, hidden=1536, loss_type="i", B=2, seed=803, lr=0.05),
 }
 
 

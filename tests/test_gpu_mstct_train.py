@@ -105,7 +105,7 @@ def _trainer(cfg, **kw):
     return tr, sd, table
 
 
-@pytest.mark.parametrize("name", ["mstct_train_tiny", "mstct_train_full"])
+@pytest.mark.parametrize("name", ["mstct_train_tiny", "mstct_train_full", "mstct_train_D1536_i"])
 def test_mstct_train_step_vs_reference_autograd(cuda, name):
     """loss within 1e-4, every parameter's gradient norm within 2e-4 (relative; floor 1e-6 of the largest norm), sampled parameter deltas of
     the SGD step within 2e-4 of the reference's torch.optim.SGD step"""

@@ -96,7 +96,7 @@ def _trainer(cfg, **kw):
     return tr, sd, table
 
 
-@pytest.mark.parametrize("name", ["q2l_train_swinT_i", "q2l_train_swinT_t"])
+@pytest.mark.parametrize("name", ["q2l_train_swinT_i", "q2l_train_swinT_t", "q2l_train_swinL_i"])   # (swinL: the shipped recipe, Scripts/train_fold1.sh:12)
 def test_q2l_train_step_vs_reference_autograd(cuda, name):
     """loss within 1e-4, every parameter's gradient norm within 2e-4 (relative; floor 1e-6 of the largest norm), sampled parameter deltas of
     the SGD step within 2e-4 of the reference's torch.optim.SGD step"""

@@ -87,7 +87,20 @@ def test_q2l_oracle_matches_reference_outputs():
         _close(got, z[key], tol=1e-4)
 
 
-@pytest.mark.parametrize("name", ["mstct_tiny", "mstct_full_ivt_ragged"])
+def test_q2l_oracle_matches_reference_outputs_shipped_teacher():
+    """the shipped teacher configuration (`Scripts/train_fold1.sh:5-12`: swin_L_384_22k, hidden 1536, task i; `swin_transformer.py:623-628`)"""
+    from oracle import swin_q2l as o_q
+    z, cfg = load_golden("q2l_swinL_384_i")
+    assert (cfg["backbone"], cfg["img"], cfg["hidden"]) == ("swin_L_384_22k", 384, 1536)
+    sd = synth.fill_from_shapes(shapes.q2l_param_shapes(cfg["backbone"], cfg["img"], cfg["hidden"], cfg["loss_type"]), seed=cfg["seed"])
+    img = synth.normalize_frames(synth.synthetic_frames(cfg["B"], cfg["img"], cfg["img"], seed=cfg["seed"]))
+    with torch.no_grad():
+        out = o_q.q2l_forward(sd, img, cfg["backbone"], cfg["img"], cfg["hidden"], cfg["loss_type"])
+    _close(out[0][1], z["logits"], tol=1e-4)
+    _close(out[3][0], z["feat"], tol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["mstct_tiny", "mstct_full_ivt_ragged", "mstct_D1536_i"])
 def test_mstct_oracle_matches_reference_outputs(name):
     from oracle import mstct as o_m
     z, cfg = load_golden(name)
@@ -161,7 +174,7 @@ def test_spatial_cnn_train_oracle_matches_reference_step(name):
             assert err <= 2e-4 * ref.abs().max().item() + ulp, (k, err, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("name", ["mstct_train_tiny"])
+@pytest.mark.parametrize("name", ["mstct_train_tiny", "mstct_train_D1536_i"])
 def test_mstct_train_oracle_matches_reference_step(name):
     """one Temporal_mstct step (`run.py:147-235`, dropout off) vs the fixture captured from the reference VideoNas + torch autograd + SGD"""
     from oracle import mstct_train as o_mt
