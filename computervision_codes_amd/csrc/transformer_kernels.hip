@@ -730,27 +730,30 @@ extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* 
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || hd <= 0) return MT4_EINVAL;
     if (dtype != MT4_F32 && dtype != MT4_BF16) return MT4_EUNSUPPORTED;
     if (mask && nW <= 0) return MT4_EINVAL;
-    if (hd > 256 || B > 65535 || H > 65535) return MT4_EUNSUPPORTED;
+    if (hd > 512 || B > 65535 || H > 65535) return MT4_EUNSUPPORTED;
     const int es = dtype == MT4_BF16 ? 2 : 4;
     // 4-element vector staging needs every (row, head) start 4-element aligned
     const int vec_ok = (hd % 4 == 0) && (k_stride * es) % (4 * es) == 0 && (v_stride * es) % (4 * es) == 0 &&
                        (((uintptr_t)k | (uintptr_t)v) & (4 * es - 1)) == 0;
     hipStream_t s = (hipStream_t)stream;
     // large head dim, bf16, no bias / mask, keys fit one workgroup's score registers: matrix-unit kernel (MT4_NO_MHA_MFMA=1: VALU kernel)
-    if (dtype == MT4_BF16 && hd == 256 && !bias && !mask && Nk <= 160 && (q_stride % 8) == 0 && (k_stride % 8) == 0 && (v_stride % 8) == 0 &&
+    // (head dim 256: Q2L over Swin-B, d = 1024 / 4 heads; 384: over Swin-L, d = 1536 -- the shipped teacher, Scripts/train_fold1.sh:5-12)
+    if (dtype == MT4_BF16 && (hd == 256 || hd == 384) && !bias && !mask && Nk <= 160 && (q_stride % 8) == 0 && (k_stride % 8) == 0 && (v_stride % 8) == 0 &&
         (o_stride % 4) == 0 && ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0) && (((uintptr_t)out & 7) == 0) && cdiv(Nq, 64) <= 65535) {
         static const bool off = getenv("MT4_NO_MHA_MFMA") != nullptr;
         if (!off) {
             const int nkt = cdiv(Nk, 16);
             const dim3 grid(H, B, cdiv(Nq, 64)), block(256);
-#define MHA_LAUNCH(NKTV) { constexpr int nkp = NKTV * 16, nkp2 = ((NKTV + 1) / 2) * 32; const size_t lds = (size_t)nkp * 144 + 64 * ((nkp2 + 8) * 2); \
-            hipLaunchKernelGGL((mha_mfma_kernel<NKTV, 256>), grid, block, lds, s, (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, Nq, Nk, \
+#define MHA_LAUNCH_HD(NKTV, HDV) { constexpr int nkp = NKTV * 16, nkp2 = ((NKTV + 1) / 2) * 32; const size_t lds = (size_t)nkp * 144 + 64 * ((nkp2 + 8) * 2); \
+            hipLaunchKernelGGL((mha_mfma_kernel<NKTV, HDV>), grid, block, lds, s, (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, Nq, Nk, \
                                q_stride, k_stride, v_stride, o_stride, scale); }
+#define MHA_LAUNCH(NKTV) { if (hd == 256) MHA_LAUNCH_HD(NKTV, 256) else MHA_LAUNCH_HD(NKTV, 384) }
             switch (nkt) {
                 case 1: MHA_LAUNCH(1) break; case 2: MHA_LAUNCH(2) break; case 3: MHA_LAUNCH(3) break; case 4: MHA_LAUNCH(4) break;
                 case 5: MHA_LAUNCH(5) break; case 6: MHA_LAUNCH(6) break; case 7: MHA_LAUNCH(7) break; case 8: MHA_LAUNCH(8) break;
                 case 9: MHA_LAUNCH(9) break; default: MHA_LAUNCH(10) break;
             }
+#undef MHA_LAUNCH_HD
 #undef MHA_LAUNCH
             return mt4_check_launch();
         }
@@ -789,10 +792,14 @@ extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* 
     }
     // (DPL, LPQ) with DPL*LPQ >= hd, fewest lanes per query first
     static const int cfgs[][2] = {{32, 1}, {24, 2}, {32, 2}, {20, 4}, {28, 4}, {32, 4}, {32, 8},
-                                  {4, 8}, {8, 8}, {12, 8}, {16, 8}, {24, 8}};   // 8 lanes per query, few dims per lane
+                                  {4, 8}, {8, 8}, {12, 8}, {16, 8}, {24, 8},   // 8 lanes per query, few dims per lane
+                                  {48, 8}, {64, 8}};                           // head dims 257 .. 512 (Q2L over Swin-L: 1536 / 4 heads = 384)
     int ci = -1;
     for (int i = 0; i < 7; ++i)
         if (cfgs[i][0] * cfgs[i][1] >= hd) { ci = i; break; }
+    if (ci < 0)
+        for (int i = 12; i < 14; ++i)
+            if (cfgs[i][0] * cfgs[i][1] >= hd) { ci = i; break; }
     if (ci < 0) return MT4_EUNSUPPORTED;
     int threads = ((Nq * cfgs[ci][1] + 63) / 64) * 64;
     if (threads > 256) threads = 256;
@@ -814,7 +821,7 @@ extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* 
 #define ATT_DISPATCH(TT) switch (ci) { case 0: ATT_LAUNCH(TT, 32, 1); break; case 1: ATT_LAUNCH(TT, 24, 2); break; case 2: ATT_LAUNCH(TT, 32, 2); break; \
         case 3: ATT_LAUNCH(TT, 20, 4); break; case 4: ATT_LAUNCH(TT, 28, 4); break; case 5: ATT_LAUNCH(TT, 32, 4); break; case 6: ATT_LAUNCH(TT, 32, 8); break; \
         case 7: ATT_LAUNCH(TT, 4, 8); break; case 8: ATT_LAUNCH(TT, 8, 8); break; case 9: ATT_LAUNCH(TT, 12, 8); break; case 10: ATT_LAUNCH(TT, 16, 8); break; \
-        default: ATT_LAUNCH(TT, 24, 8); }
+        case 11: ATT_LAUNCH(TT, 24, 8); break; case 12: ATT_LAUNCH(TT, 48, 8); break; default: ATT_LAUNCH(TT, 64, 8); }
     if (dtype == MT4_BF16) { ATT_DISPATCH(u16) } else { ATT_DISPATCH(float) }
 #undef ATT_DISPATCH
 #undef ATT_LAUNCH

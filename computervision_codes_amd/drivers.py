@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import cholect, extract, featfile
-from .metrics import Recognition
+from .metrics import Recognition, final_report, gather_recognition, recognition_from
 
 
 def _common(p: argparse.ArgumentParser):
@@ -72,7 +72,77 @@ def _sigmoid(x: torch.Tensor) -> np.ndarray:
     return torch.sigmoid(x.float()).cpu().numpy()
 
 
+def _write_report(logfile: str, m, loss_type: str, chlg: bool, style: str, pckl: str = None) -> Dict[str, float]:
+    """the reference's closing report (`metrics.final_report`: per-category AP vectors, the mean-AP row with I / V / T disentangled from the
+    triplet head, top-K rows) into the log file, and -- temporal drivers -- the pickled metric objects (`Temporal_tenco/run.py:529-533`:
+    `{'ivt': mAP, 'i': mAPi, 'v': mAPv, 't': mAPt}`, here `metrics.Recognition` objects with ivtmetrics' attribute names)"""
+    if pckl:
+        os.makedirs(os.path.dirname(os.path.abspath(pckl)), exist_ok=True)
+        with open(pckl, "wb") as f:
+            pickle.dump({k: m[k] for k in ("ivt", "i", "v", "t")}, f)
+    lines, res = final_report(m, loss_type, chlg, style)
+    for ln in lines:
+        _log(logfile, ln)
+    return res
+
+
 # ------------------------------------------------------------------------------------------------ Spatial_cnn/test.py
+def _spatial_cnn_videos(F, model, vids, labels):
+    """the per-video loop of `test_loop` (`Spatial_cnn/test.py:143-177`, `run.py:226-256`) over `vids`: -> ({video key -> feat [N,D]},
+    {video -> {head -> (labels [N,K], sigmoid scores [N,K])}})"""
+    feats_local: Dict[str, np.ndarray] = {}
+    scores_local = {}
+    for v in vids:
+        lab = labels[v]
+        ids_all = lab["ivt"][:, 0]                             # file order, no shuffle, drop_last False (`test.py:227-242`)
+        load = lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.image_height, F.image_width,   # decode on the
+                                                       workers=F.decode_workers, decode=F.png_decode)          # host (or device), Resize on the GPU
+        # (the device PNG decoder runs one wave per frame and needs >= 1024 frames to fill the chip: it is handed several passes' worth at once,
+        # and two loads run ahead, so that gathering one load's compressed bytes on the host overlaps the inflate of the load before it)
+        dev_dec = F.png_decode == "device"
+        feat, lgs = extract.extract_video_device(model, len(ids_all), load, F.device_batch, prefetch=2 if dev_dec else 1,
+                                                 load_batch=1024 if dev_dec else None)
+        scores_local[v] = {key: (lab[key][:, 1:], torch.sigmoid(torch.from_numpy(lg)).numpy())       # `test.py:162-169`
+                           for key, lg in zip(("i", "v", "t", "ivt"), lgs)}
+        feats_local[featfile.video_key(v)] = np.array(feat)    # (own copy: the pinned staging buffer is released)
+    return feats_local, scores_local
+
+
+def spatial_cnn_eval(argv=None) -> Dict[str, float]:
+    """`Spatial_cnn/run.py -e` (:503-560): the TEST-split videos through the best checkpoint and the closing report -- per-category AP, the
+    mean-AP row (I / V / T disentangled from the 100-way triplet head when --loss_type all, head-wise otherwise, `:518-525`), top-5 / 10 / 20
+    per component.  Under torchrun whole videos are sharded over the ranks and their (labels, scores) meet in one host-side gather, so N
+    ranks log exactly the single-rank report; rank 0 writes it."""
+    from .spatial_cnn import VideoNas
+    p = argparse.ArgumentParser()
+    _common(p)
+    p.add_argument("--network", type=str, default="resnet18")
+    p.add_argument("--student_dim", type=int, default=512)
+    p.add_argument("--teacher_dim", type=int, default=1536)
+    F, _ = p.parse_known_args(argv)
+    F.train = False
+    rank, world = _dist()
+    kfold = F.kfold if "crossval" in F.dataset_variant else 0
+    modelname = f"{F.model}_l{F.dataset_variant}_cholect{kfold}"
+    model_dir = f"./__checkpoint__/run_{F.version}"
+    logfile = os.path.join(model_dir, modelname + ".log")
+    ckpt = F.test_ckpt or os.path.join(model_dir, modelname + ".pth")
+    model = VideoNas(args=F, dtype=torch.float32 if F.dtype == "fp32" else torch.bfloat16).eval()
+    model.load_state_dict(torch.load(ckpt, map_location="cpu"))
+    _, _, videos = cholect.split_videos(F.dataset_variant, kfold)
+    labels = {v: cholect.load_labels(F.data_dir, v) for v in videos}
+    mine = extract.shard_videos(videos, [len(labels[v]["ivt"]) for v in videos], rank, world)
+    _, scores_local = _spatial_cnn_videos(F, model, [videos[vi] for vi in mine], labels)
+    m = gather_recognition(scores_local, videos)
+    res = {}
+    try:
+        if rank == 0:
+            res = _write_report(logfile, m, F.loss_type, _chlg(F), "spatial_cnn")
+    finally:
+        _barrier()
+    return res
+
+
 def spatial_cnn_test(argv=None) -> Dict[str, np.ndarray]:
     from .spatial_cnn import VideoNas
     p = argparse.ArgumentParser()
@@ -93,29 +163,14 @@ def spatial_cnn_test(argv=None) -> Dict[str, np.ndarray]:
     labels = {v: cholect.load_labels(F.data_dir, v) for v in videos}
     mine = extract.shard_videos(videos, [len(labels[v]["ivt"]) for v in videos], rank, world)
     t0 = time.time()
-    m = {k: Recognition(n) for k, n in (("i", 6), ("v", 10), ("t", 15), ("ivt", 100))}
-    feats_local: Dict[str, np.ndarray] = {}
-    for vi in mine:
-        v = videos[vi]
-        lab = labels[v]
-        ids_all = lab["ivt"][:, 0]                             # file order, no shuffle, drop_last False (`test.py:227-242`)
-        load = lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.image_height, F.image_width,   # decode on the
-                                                       workers=F.decode_workers, decode=F.png_decode)          # host (or device), Resize on the GPU
-        # (the device PNG decoder runs one wave per frame and needs >= 1024 frames to fill the chip: it is handed several passes' worth at once,
-        # and two loads run ahead, so that gathering one load's compressed bytes on the host overlaps the inflate of the load before it)
-        dev_dec = F.png_decode == "device"
-        feat, lgs = extract.extract_video_device(model, len(ids_all), load, F.device_batch, prefetch=2 if dev_dec else 1,
-                                                 load_batch=1024 if dev_dec else None)
-        for key, lg in zip(("i", "v", "t", "ivt"), lgs):
-            m[key].update(lab[key][:, 1:], torch.sigmoid(torch.from_numpy(lg)).numpy())   # `test.py:162-169`
-            m[key].video_end()
-        feats_local[featfile.video_key(v)] = np.array(feat)    # (own copy: the pinned staging buffer is released)
+    feats_local, scores_local = _spatial_cnn_videos(F, model, [videos[vi] for vi in mine], labels)
     merged = extract.gather_feats(feats_local)
+    m = gather_recognition(scores_local, videos)               # the videos of ALL ranks in file order: N ranks log the 1-rank numbers
     all_feats = {featfile.video_key(v): merged[featfile.video_key(v)] for v in videos}
     if rank == 0:
         featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type), all_feats)
         _log(logfile, f"save time:::::: : {time.time() - t0:.4f} secs")
-        _log(logfile, " ".join(f"AP_{k}={m[k].compute_video_AP(ignore_null=_chlg(F))['mAP']:.4f}" for k in m) + f" (rank-0 videos, world={world})")
+        _log(logfile, " ".join(f"AP_{k}={m[k].compute_video_AP(ignore_null=_chlg(F))['mAP']:.4f}" for k in m) + f" (all {len(videos)} videos, world={world})")
     return all_feats
 
 
@@ -305,20 +360,23 @@ def _tenco_eval_rank0(F) -> Dict[str, float]:
     model.load_state_dict({k: v for k, v in sd.items() if k in dict(model._table)}, strict=False)   # `run.py:520`
     _, _, test_videos = cholect.split_videos(F.dataset_variant, F.kfold)
     feats = featfile.read_feats(featfile.feats_path("..", F.version1, F.kfold, "all"))
-    m = {k: Recognition(n) for k, n in (("i", 6), ("v", 10), ("t", 15), ("ivt", 100))}
     t0 = time.time()
-    for v in test_videos:
-        lab = cholect.load_labels(F.data_dir, v)
+    m = recognition_from(_tenco_scores(model, feats, test_videos, F.data_dir), test_videos)     # (rank 0 alone runs this pass)
+    _log(logfile, f"eta {time.time() - t0:.3f} secs")
+    # `run.py:529-570`: the pickled metric objects, then head-wise ('singletest') and disentangled per-category AP and both mean-AP rows
+    res = _write_report(logfile, m, F.loss_type, _chlg(F), "temporal_tenco", pckl=os.path.join(model_dir, f"mAPs_k{F.kfold}.pckl"))
+    return res
+
+
+def _tenco_scores(model, feats, vids, data_dir):
+    """`test_loop` of `Temporal_tenco/run.py:238-270`: whole video, batch 1, the finest FPN level's logits [K,T] -> sigmoid [T,K]"""
+    out_scores = {}
+    for v in vids:
+        lab = cholect.load_labels(data_dir, v)
         x = torch.from_numpy(feats[featfile.video_key(v)]).unsqueeze(0).cuda()
         out, out_i, out_v, out_t, _, _ = model(x, False)
-        for key, lg in (("ivt", out), ("i", out_i), ("v", out_v), ("t", out_t)):   # finest FPN level, [K,T] -> [T,K]
-            m[key].update(lab[key][:, 1:], _sigmoid(lg[0][0].transpose(0, 1)))
-            m[key].video_end()
-    res = {f"AP_{k}": m[k].compute_video_AP(ignore_null=_chlg(F))["mAP"] for k in m}
-    _log(logfile, f"eta {time.time() - t0:.3f} secs " + " ".join(f"{k}={v:.4f}" for k, v in res.items()))
-    with open(os.path.join(model_dir, modelname + "_test_mAP.pkl"), "wb") as f:
-        pickle.dump({k: {"targets": m[k].global_targets, "predictions": m[k].global_predictions} for k in m}, f)
-    return res
+        out_scores[v] = {key: (lab[key][:, 1:], _sigmoid(lg[0][0].transpose(0, 1))) for key, lg in (("ivt", out), ("i", out_i), ("v", out_v), ("t", out_t))}
+    return out_scores
 
 
 def _tenco_train(F):

@@ -94,14 +94,103 @@ class Recognition:
             ap = np.nanmean(np.stack(per_video, 0), axis=0) if per_video else np.full(self.num_class, np.nan)
             return {"AP": ap, "mAP": float(np.nanmean(ap)) if np.isfinite(ap).any() else float("nan")}
 
-    def topK(self, k: int = 5) -> float:
-        """fraction of frames whose positive classes intersect the top-k scores (`run.py:543-548`)"""
-        hits, n = 0, 0
+    def topK(self, k: int = 5, component: str = "ivt") -> float:
+        """`mAP.topK(k, component)` (`Spatial_cnn/run.py:543-548`) as the reference spells it out itself in `Temporal_mstct/run.py:507-523`
+        (`topk`): over ALL frames seen, (number of positive classes that are among the frame's k highest scores) / (number of positive
+        classes); 0 / 1 when nothing is positive.  `component` disentangles 100-way triplet scores and labels first (`disentangle`)."""
+        if component != "ivt" and self.num_class != 100:
+            raise ValueError("component disentangling needs the 100-way triplet scores")
+        correct, total = 0, 0
         for t, p in zip(self.global_targets, self.global_predictions):
-            top = np.argsort(-p, axis=1)[:, :k]
-            for i in range(t.shape[0]):
-                pos = np.nonzero(t[i])[0]
-                if len(pos):
-                    n += 1
-                    hits += int(len(np.intersect1d(pos, top[i])) > 0)
-        return hits / n if n else float("nan")
+            t, p = disentangle(t, component), disentangle(p, component)
+            top = np.argsort(-p, axis=1, kind="stable")[:, :k]
+            hit = np.take_along_axis(t != 0, top, axis=1)
+            correct += int(hit.sum())
+            total += int((t != 0).sum())
+        return correct / (total if total else 1)
+
+    # ---- the per-video record, for merging the videos of several ranks (host side; no reference counterpart: its drivers are single-process)
+    def videos(self):
+        return list(zip(self.global_targets, self.global_predictions))
+
+    def set_videos(self, vids):
+        self.reset_global()
+        for t, p in vids:
+            self.global_targets.append(np.asarray(t, dtype=np.float64).reshape(-1, self.num_class))
+            self.global_predictions.append(np.asarray(p, dtype=np.float64).reshape(-1, self.num_class))
+        return self
+
+
+HEADS = (("i", 6), ("v", 10), ("t", 15), ("ivt", 100))
+
+
+def gather_recognition(local, order, group=None):
+    """local: {video key -> {head -> (targets [N,K], predictions [N,K])}} of THIS rank's videos.  Returns {head -> Recognition} holding the
+    videos of ALL ranks in `order` (the single-process order), identical on every rank: an N-rank evaluation reports the 1-rank numbers.
+    One host-side object gather, like `extract.gather_feats` (videos are independent units: no data-path collective)."""
+    import torch.distributed as dist
+    parts = [dict(local)]
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        parts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(parts, dict(local), group=group)
+    merged = {}
+    for part in parts:
+        for k, v in part.items():
+            if k in merged:
+                raise ValueError(f"video {k} evaluated by two ranks")
+            merged[k] = v
+    return recognition_from(merged, order)
+
+
+def recognition_from(scores, order):
+    """{video -> {head -> (targets, predictions)}} -> {head -> Recognition} with the videos in `order` (no communication)"""
+    missing = [k for k in order if k not in scores]
+    if missing:
+        raise KeyError(f"videos without predictions: {missing[:4]}")
+    heads = [h for h, _ in HEADS if all(h in scores[k] for k in order)]
+    return {h: Recognition(dict(HEADS)[h]).set_videos([scores[k][h] for k in order]) for h in heads}
+
+
+def final_report(m, loss_type: str = "all", ignore_null: bool = False, style: str = "spatial_cnn"):
+    """The lines of the reference's closing evaluation report, in order (the drivers write them to the log file):
+    `style` 'spatial_cnn'          `Spatial_cnn/run.py:517-560` -- I / V / T from the component heads when `loss_type` is i | v | t, else DISENTANGLED from
+                                   the 100-way triplet head; IV / IT / IVT from the triplet head; per-category vectors, mean-AP row, top-5 / 10 / 20 rows
+          'spatial_transformer'    `Spatial_transformer/run.py:500-527` -- the same without top-K numbers (it prints the 'top 5' header only)
+          'temporal_tenco'         `Temporal_tenco/run.py:534-570` -- head-wise ('singletest') AND disentangled vectors, both mean-AP rows
+          'temporal_mstct'         `Temporal_mstct/run.py:550-580` -- head-wise vectors, both mean-AP rows
+    m: {head -> Recognition} ('ivt' + the component heads).  Returns (lines, {name -> mAP}) -- the numbers of the README table (`readme.md:111-113`)."""
+    ap = lambda head, comp=None: (m[head].compute_video_AP(ignore_null=ignore_null) if comp is None
+                                  else m[head].compute_video_AP(comp, ignore_null=ignore_null))
+    single = {c: ap(c) for c in ("i", "v", "t")}                       # the component heads' own AP
+    dis = {c: ap("ivt", c) for c in ("i", "v", "t")}                   # disentangled from the triplet head
+    iv, it, ivt = ap("ivt", "iv"), ap("ivt", "it"), ap("ivt", "ivt")
+    row = lambda a: f':::::: : {a[0]:.4f} | {a[1]:.4f} | {a[2]:.4f} | {a[3]:.4f} | {a[4]:.4f} | {a[5]:.4f} '
+    head_row = lambda name: f'{name}:  I  |  V  |  T  |  IV  |  IT  |  IVT '
+    L = ['-' * 50, 'Test Results\nPer-category AP: ']
+    if style in ("spatial_cnn", "spatial_transformer"):
+        comp = single if loss_type in ("i", "v", "t") else dis
+        L += [f'I   : {comp["i"]["AP"]}', f'V   : {comp["v"]["AP"]}', f'T   : {comp["t"]["AP"]}', f'IV  : {iv["AP"]}', f'IT  : {it["AP"]}',
+              f'IVT : {ivt["AP"]}', '-' * 50, head_row('Mean AP'),
+              row([comp["i"]["mAP"], comp["v"]["mAP"], comp["t"]["mAP"], iv["mAP"], it["mAP"], ivt["mAP"]])]
+        res = {"AP_i": comp["i"]["mAP"], "AP_v": comp["v"]["mAP"], "AP_t": comp["t"]["mAP"]}
+        if style == "spatial_cnn":
+            for k in (5, 10, 20):
+                L += [head_row(f'top {k}'), row([m["ivt"].topK(k, c) for c in ("i", "v", "t", "iv", "it", "ivt")])]
+                res.update({f"top{k}_{c}": m["ivt"].topK(k, c) for c in ("i", "v", "t", "iv", "it", "ivt")})
+        else:
+            L += [head_row('top 5')]
+    else:
+        if style == "temporal_tenco":
+            L += ['------------singletest-------------', f'I   : {single["i"]["AP"]}', f'V   : {single["v"]["AP"]}', f'T   : {single["t"]["AP"]}',
+                  '-' * 50, 'Test Results\nPer-category AP: ', f'I   : {dis["i"]["AP"]}', f'V   : {dis["v"]["AP"]}', f'T   : {dis["t"]["AP"]}']
+        else:
+            L += [f'I   : {single["i"]["AP"]}', f'V   : {single["v"]["AP"]}', f'T   : {single["t"]["AP"]}']
+        L += [f'IV  : {iv["AP"]}', f'IT  : {it["AP"]}', f'IVT : {ivt["AP"]}', '-' * 50, head_row('Mean AP'),
+              row([dis["i"]["mAP"], dis["v"]["mAP"], dis["t"]["mAP"], iv["mAP"], it["mAP"], ivt["mAP"]]),
+              '------------singletest-------------', head_row('Mean AP'),
+              row([single["i"]["mAP"], single["v"]["mAP"], single["t"]["mAP"], iv["mAP"], it["mAP"], ivt["mAP"]])]
+        res = {"AP_i": dis["i"]["mAP"], "AP_v": dis["v"]["mAP"], "AP_t": dis["t"]["mAP"],
+               "AP_i_single": single["i"]["mAP"], "AP_v_single": single["v"]["mAP"], "AP_t_single": single["t"]["mAP"]}
+    L.append('=' * 50)
+    res.update({"AP_iv": iv["mAP"], "AP_it": it["mAP"], "AP_ivt": ivt["mAP"]})
+    return L, res

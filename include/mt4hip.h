@@ -259,7 +259,7 @@ int mt4_layernorm(const void* x, const float* gamma, const float* beta, void* y,
  * mask [nW][Nq][Nk] are float32 or NULL.  Replaces WindowAttention's core (swin_transformer.py:120-141, with the
  * relative-position bias gathered to dense form at load time and the -100 shift mask), nn.MultiheadAttention's
  * core in the Q2L transformer (transformer.py:186-189,275-283) and Global_Relational_Block (Temporal_Encoder.py:
- * 80-86).  hd <= 256.  bf16 with hd == 256, no bias / mask and Nk <= 160 runs on the matrix units (probabilities rounded to bf16
+ * 80-86).  hd <= 512.  bf16 with hd == 256 or 384 (Q2L over Swin-B / the shipped Swin-L teacher: 1536 / 4 heads), no bias / mask and Nk <= 160 runs on the matrix units (probabilities rounded to bf16
  * before the PV product, like the window kernel); fp32 with hd <= 128, hd % 4 == 0, no bias / mask and Nk <= 256 on the exact-fp32
  * matrix instruction (MS-TCT's global block). */
 int mt4_attention(const void* q, const void* k, const void* v, void* out, const float* bias, const float* mask, int32_t B,

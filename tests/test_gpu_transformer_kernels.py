@@ -82,6 +82,9 @@ def _attn_ref(q, k, v, scale, bias, mask, nw):
     dict(B=2, H=8, Nq=40, Nk=40, hd=6, bias=False, nw=0),       # odd head dim -> element-wise staging
     dict(B=3, H=4, Nq=6, Nk=144, hd=256, bias=False, nw=0),     # Q2L decoder cross-attention, multi-chunk keys
     dict(B=2, H=4, Nq=144, Nk=144, hd=192, bias=False, nw=0),   # Q2L encoder (Swin-T hidden 768)
+    dict(B=2, H=4, Nq=144, Nk=144, hd=384, bias=False, nw=0),   # Q2L encoder over Swin-L (hidden 1536: the shipped teacher, Scripts/train_fold1.sh:5-12)
+    dict(B=3, H=4, Nq=6, Nk=144, hd=384, bias=False, nw=0),     # ... its decoder cross-attention (6 queries: task i)
+    dict(B=1, H=2, Nq=20, Nk=33, hd=512, bias=True, nw=0),      # the widest head the core takes
 ])
 def test_attention_core(cuda, cfg, dtype):
     from computervision_codes_amd import ops
@@ -105,12 +108,12 @@ def test_attention_core(cuda, cfg, dtype):
     assert (out.float().cpu() - ref).abs().max().item() < _tol(dtype, 2e-5, 2e-2)
 
 
+@pytest.mark.parametrize("hd", [256, 384])
 @pytest.mark.parametrize("B,H,Nq,Nk", [(3, 4, 144, 144), (2, 4, 100, 144), (5, 4, 6, 144), (2, 2, 15, 49), (1, 4, 70, 160), (2, 1, 10, 7)])
-def test_mha_mfma_head_dim_256(cuda, B, H, Nq, Nk):
-    """the matrix-unit core behind `mt4_attention` for bf16, head dim 256, no bias / mask (Q2L encoder self-attention and decoder
-    cross-attention, `transformer.py:186-189,275-283`): fp32 oracle on the same bf16-rounded q/k/v; ragged query blocks and key tiles"""
+def test_mha_mfma_head_dim_256(cuda, B, H, Nq, Nk, hd):
+    """the matrix-unit core behind `mt4_attention` for bf16, head dim 256 (Swin-B, d = 1024) / 384 (Swin-L, d = 1536), no bias / mask (Q2L encoder
+    self-attention and decoder cross-attention, `transformer.py:186-189,275-283`): fp32 oracle on the same bf16-rounded q/k/v; ragged query blocks and key tiles"""
     from computervision_codes_amd import ops
-    hd = 256
     c = H * hd
     q = _rand((B * Nq, c), 81, 1.0).to(torch.bfloat16)
     kv = _rand((B * Nk, 2 * c), 82, 1.0).to(torch.bfloat16)
