@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """MI355X entry point for `MT4MTLKD/Temporal_mstct/run.py` (same flags, paths and files; see computervision_codes_amd/drivers.py):
--t trains the MS-TCT teacher, -e without -t runs the evaluation / extraction pass of test.py."""
+-t trains the MS-TCT teacher, -e evaluates the test split and writes `mAPs.pckl` + the closing report (`run.py:527-580`); the teacher
+feature / prediction files come from test.py."""
 import os
 import sys
 

@@ -62,6 +62,7 @@ _FLOAT3 = C.c_float * 3
 # name -> (restype, argtypes); must list every symbol of include/mt4hip.h
 SIGNATURES = {
     "mt4_abi_version": (C.c_int, []),
+    "mt4_source_digest": (C.c_char_p, []),
     "mt4_strerror": (C.c_char_p, [C.c_int]),
     "mt4_last_hip_error": (C.c_int, []),
     "mt4_conv_nhwc": (C.c_int, [C.POINTER(ConvDesc), _vp]),
@@ -167,12 +168,27 @@ def _load() -> C.CDLL:
     return lib
 
 
-ABI_VERSION = 9         # what mt4_abi_version() of a matching libmt4hip.so returns (csrc/misc_kernels.hip)
+ABI_VERSION = 10        # what mt4_abi_version() of a matching libmt4hip.so returns (csrc/misc_kernels.hip)
 lib = _load()
 if lib.mt4_abi_version() != ABI_VERSION:      # a stale libmt4hip.so next to newer Python: fail at import, not in the first launch
     raise ImportError(f"libmt4hip.so reports ABI {lib.mt4_abi_version()}, this package binds ABI {ABI_VERSION}: rebuild (make -C computervision_codes_amd/csrc)")
 
 
+
+
+def _check_sources():
+    """the loaded binary must be built from the sources beside it: every test, every committed PMC figure and `bench.py` speak about THOSE"""
+    from .srcdigest import library_digest
+    lib.mt4_source_digest.restype = C.c_char_p
+    lib.mt4_source_digest.argtypes = []
+    baked, now = lib.mt4_source_digest().decode(), library_digest()
+    if baked != now and os.environ.get("MT4_ALLOW_STALE") != "1":
+        raise ImportError(f"libmt4hip.so was built from sources {baked}, the sources in {os.path.join(_HERE, 'csrc')} are {now}: rebuild "
+                          "(make -C computervision_codes_amd/csrc) or set MT4_ALLOW_STALE=1 to load the stale library anyway")
+    return baked
+
+
+SOURCE_DIGEST = _check_sources()
 MT4_EUNSUPPORTED = -4   # include/mt4hip.h
 
 

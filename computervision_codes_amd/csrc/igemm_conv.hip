@@ -688,9 +688,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel
 // the fragment-ordered expansion weights (a.f_w, 128-channel chunks of a.f_cout outputs); each chunk goes through the fp32 staging with the
 // block's residual (a.res, pitch f_cout) and is stored to a.f_y.  a.y is not written: the 128-channel map never reaches memory.  Same K order
 // and bias-initialised accumulators as the stand-alone 1x1 launch: bit-identical.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int WS, bool EXPAND = false>
+// STATS: the epilogue also adds the channel sums of the stored values to a.stat_sums -- a separate instantiation, like the generic kernel's, so
+// that the float64 accumulators cost the inference launches no registers.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WS, bool EXPAND = false, bool STATS = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 : 1) void conv3x3_patch_kernel(const ConvK a, const int pra, const int npatch) {
     static_assert(!EXPAND || BN == 128, "the expansion needs a pixel's whole channel vector in the tile");
+    static_assert(!(EXPAND && STATS), "the expansion form takes no statistics");
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int NTH = NW * 64;
     constexpr int RPP = NTH / 8;
@@ -977,9 +980,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 
         }
         return;
     }
-    double cs[8], cq[8];
+    double cs[STATS ? 8 : 1], cq[STATS ? 8 : 1];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.0;
+    for (int e = 0; e < (STATS ? 8 : 1); ++e) cs[e] = cq[e] = 0.0;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         // residual rows of the pass (the second conv of a BasicBlock) go in flight before the LDS hand-off, like in the generic kernel
@@ -1025,7 +1028,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 
             char* yp = a.y + ((long long)m * a.y_ld + n) * 2;
             if (a.nt_epi) __builtin_nontemporal_store(ov, (u32x4*)yp);
             else *(uint4*)yp = make_uint4(ov.x, ov.y, ov.z, ov.w);
-            if (a.stat_sums) {
+            if constexpr (STATS) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const double lo = (double)__uint_as_float(ov[e] << 16), hi = (double)__uint_as_float(ov[e] & 0xffff0000u);
@@ -1034,7 +1037,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 
             }
         }
     }
-    if (a.stat_sums) colstat_flush<TPR, NTH, 8, BN>(cs, cq, smem, a.stat_sums + (long long)(tile_m & (MT4_STAT_REPLICAS - 1)) * 2 * a.Cout, n0, a.Cout, tid);
+    if constexpr (STATS) colstat_flush<TPR, NTH, 8, BN>(cs, cq, smem, a.stat_sums + (long long)(tile_m & (MT4_STAT_REPLICAS - 1)) * 2 * a.Cout, n0, a.Cout, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ stem patch kernel
@@ -1554,7 +1557,17 @@ int launch_patch3x3(const ConvK& k, hipStream_t s) {
     if (WS == 9 && k.SPT != 1) return MT4_EUNSUPPORTED;
     if (lds > 160 * 1024 || (k.SPT > 1 && cdiv(pra, rpp) > 11 - WS)) return MT4_EUNSUPPORTED;   // (next-slice patch pieces ride along with taps 0..)
     if (k.stat_sums && (EXPAND || (k.Cout & 7))) return MT4_EUNSUPPORTED;
-    auto fn = conv3x3_patch_kernel<BM, BN, WM_, WN_, WS, EXPAND>;
+    if constexpr (!EXPAND) {
+        if (k.stat_sums) {       // the train-mode launch: its own instantiation (float64 channel sums in the epilogue)
+            auto fs = conv3x3_patch_kernel<BM, BN, WM_, WN_, WS, false, true>;
+            if (lds > 65536) {
+                MT4_RAISE_LDS(fs);
+            }
+            hipLaunchKernelGGL(fs, dim3(kk.total_tiles), dim3(threads), lds, s, kk, pra, npatch);
+            return mt4_check_launch();
+        }
+    }
+    auto fn = conv3x3_patch_kernel<BM, BN, WM_, WN_, WS, EXPAND, false>;
     if (lds > 65536) {
         MT4_RAISE_LDS(fn);
     }

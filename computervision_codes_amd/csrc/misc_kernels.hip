@@ -3,7 +3,11 @@
 
 thread_local int g_mt4_last_hip_error = 0;
 
-extern "C" int mt4_abi_version(void) { return 9; }   // 6: + mt4_stem_maxpool_bf16, mt4_conv_desc.x2 (second K source), mt4_bottleneck_fused_next_bf16; 7: + mt4_copy_spans_u8; 8: + mt4_chain_gemm_bf16; 9: + mt4_conv_desc.stat_sums, mt4_bn_apply_sums_t, mt4_refresh_weights moves MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup, mt4_avgpool1d_rows, mt4_interp_linear_rows
+#ifndef MT4_SOURCE_DIGEST
+#error "build through csrc/Makefile: it passes -DMT4_SOURCE_DIGEST (srcdigest.library_digest of the sources)"
+#endif
+extern "C" const char* mt4_source_digest(void) { return MT4_SOURCE_DIGEST; }
+extern "C" int mt4_abi_version(void) { return 10; }   // 6: + mt4_stem_maxpool_bf16, mt4_conv_desc.x2 (second K source), mt4_bottleneck_fused_next_bf16; 7: + mt4_copy_spans_u8; 8: + mt4_chain_gemm_bf16; 9: + mt4_conv_desc.stat_sums, mt4_bn_apply_sums_t, mt4_refresh_weights moves MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup, mt4_avgpool1d_rows, mt4_interp_linear_rows; 10: + mt4_source_digest, mt4_attention head dims up to 512
 extern "C" int mt4_last_hip_error(void) { return g_mt4_last_hip_error; }
 extern "C" const char* mt4_strerror(int code) {
     switch (code) {

@@ -113,13 +113,18 @@ __global__ __launch_bounds__(256) void wgrad_conv1d_f32_kernel(const float* __re
 // its range unwritten on replay (every fourth dword of the bias gradients, a different vector each run; the single-graph capture was fine), so
 // the zeroing in front of an atomic accumulation is a launch of our own
 __global__ void zero_f32_kernel(float* __restrict__ p, long long n) {
-    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i + 4 <= n) *(float4*)(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    else
-        for (long long k = i; k < n; ++k) p[k] = 0.f;
+    // any 4-byte aligned p: a scalar head up to the first 16-byte boundary, float4 stores, a scalar tail
+    long long head = (long long)(((16 - ((uintptr_t)p & 15)) & 15) >> 2);
+    if (head > n) head = n;
+    const long long nv = (n - head) >> 2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nv) ((float4*)(p + head))[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < head) p[i] = 0.f;
+    const long long t0 = head + nv * 4;
+    if (i < 4 && t0 + i < n) p[t0 + i] = 0.f;
 }
-static inline void zero_f32(float* p, long long n, hipStream_t s) {   // p 16-byte aligned
-    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, p, n);
+static inline void zero_f32(float* p, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, p, n);
 }
 
 extern "C" int mt4_wgrad_conv1d_f32(const float* dy, const float* x, float* dw_packed, int32_t B, int32_t T, int32_t Cout, int32_t Cin,
@@ -162,10 +167,7 @@ extern "C" int mt4_colsum_f32(const float* x, float* out, int64_t M, int32_t C, 
     mt4_clear_error();
     if (!x || !out || M <= 0 || C <= 0 || ld < C) return MT4_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate) {
-        if ((uintptr_t)out & 15) return MT4_EALIGN;
-        zero_f32(out, C, s);
-    }
+    if (!accumulate) zero_f32(out, C, s);      // (any float-aligned `out`: bias slices of a flat gradient buffer)
     long long slabs = (M + 63) / 64;                     // >= 16 rows per wave and slab
     const long long cap = (1024 + cdiv(C, 64) - 1) / cdiv(C, 64);
     if (slabs > cap) slabs = cap;

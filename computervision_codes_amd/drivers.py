@@ -406,7 +406,9 @@ def _tenco_train(F):
     else:   # no torch.nn init here: deterministic synthetic start (the reference starts from torch's default init)
         tr.load_state_dict(synth.fill_from_shapes(shapes.tenco_shapes(F.num_layers_PG, F.num_layers_R, F.num_R, 512, F.input_dim, 100, fpn=True),
                                                   seed=F.seed))
-    train_videos, _, _ = cholect.split_videos(F.dataset_variant, F.kfold)
+    train_videos, val_videos, _ = cholect.split_videos(F.dataset_variant, F.kfold)
+    val_interval = F.epochs - 1 if F.val_interval == -1 else max(1, F.val_interval)
+    best, best_path, vmodel = 0.0, os.path.join(model_dir, modelname + ".pth"), None
     feats = featfile.read_feats(featfile.feats_path("..", F.version1, F.kfold, "all"))
     # features and labels of every training video are uploaded ONCE (a per-step pageable host->device copy stalls the step)
     xs, zs = {}, {}
@@ -432,8 +434,25 @@ def _tenco_train(F):
             tot += loss
         if rank == 0:
             _log(logfile, f"Traning | lr: {tr.lr:.6f} | epoch {epoch} | loss {tot / steps:.4f} | {time.time() - t0:.2f} secs")
-            torch.save(tr.state_dict(), init + ".tmp")
+            state = tr.state_dict()
+            torch.save(state, init + ".tmp")
             os.replace(init + ".tmp", init)                        # readers never see a half-written checkpoint
+            if epoch % val_interval == 0:                          # validation + `weight_mgt` (`run.py:416-452,270-282`): best `.pth` by the triplet mAP
+                t1 = time.time()
+                if vmodel is None:
+                    from .temporal_tenco import VideoNas
+                    vmodel = VideoNas(F, F.num_layers_PG, F.num_layers_R, F.num_R, 512, F.input_dim, 100).eval()
+                vmodel.load_state_dict(state)
+                vm = recognition_from(_tenco_scores(vmodel, feats, val_videos, F.data_dir), val_videos) if val_videos else None
+                head = F.loss_type if F.loss_type in ("i", "v", "t") else "ivt"
+                score = float(vm[head].compute_video_AP()["mAP"]) if vm else 0.0
+                if score > best or not os.path.exists(best_path):
+                    best = max(best, score)
+                    torch.save(state, best_path + ".tmp")
+                    os.replace(best_path + ".tmp", best_path)
+                    _log(logfile, f">>> Saving checkpoint for epoch {epoch + 1} at {best_path}, time {time.ctime()} ")
+                ivt = float(vm["ivt"].compute_video_AP("ivt", ignore_null=_chlg(F))["mAP"]) if vm else 0.0
+                _log(logfile, f"\t\t\t\t\t\t\t video-wise | eta {time.time() - t1:.2f} secs | mAP => ivt: [{ivt:.5f}] ")
     _barrier()                                                     # the last checkpoint is on disk before any rank goes on to -e
 
 
@@ -476,6 +495,61 @@ def spatial_transformer_test(argv=None) -> Dict[str, np.ndarray]:
     if rank == 0:
         featfile.write_feats(featfile.feats_path("..", F.version, F.kfold, F.loss_type), merged)
     return merged
+
+
+def _q2l_scores(F, model, vids, labels):
+    """`test_loop` of `Spatial_transformer/run.py:231-262` over `vids`: device batches in file order, the teacher features the loader hands a
+    `loss_type all` model off the train split are zeros (`dataloader.py:240-246`) -> {video -> {head -> (labels, sigmoid scores)}}; heads the
+    model does not have score sigmoid(0) like the reference's zero logits (`network.py:84-89`)"""
+    out_scores = {}
+    single = F.loss_type != "all"
+    for v in vids:
+        ids_all = labels[v]["ivt"][:, 0]
+        step = max(1, min(F.device_batch, 256))
+        load = lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.img_size, F.img_size, workers=F.decode_workers, decode=F.png_decode)
+        spans = [(s, min(len(ids_all), s + step)) for s in range(0, len(ids_all), step)]
+        acc = {k: [] for k in ("i", "v", "t", "ivt")}
+        for span in extract.iter_chunks(spans, load, 1):
+            zt = [] if single else [torch.zeros((span.shape[0], F.teacher_dim), device=span.device)] * 3
+            o = model(span, *zt)
+            for gi, key in enumerate(("i", "v", "t", "ivt")):
+                acc[key].append(_sigmoid(o[gi][1]))
+        out_scores[v] = {key: (labels[v][key][:, 1:], np.concatenate(acc[key])) for key in acc}
+    return out_scores
+
+
+def spatial_transformer_eval(argv=None) -> Dict[str, float]:
+    """`Spatial_transformer/run.py -e` (:482-527): the TEST-split videos through the best checkpoint of run_<version>[_<task>]/ and the closing
+    report (per-category AP, mean-AP row; I / V / T from the component heads for a single-task teacher, disentangled from the triplet head for
+    --loss_type all).  Videos sharded over the ranks, (labels, scores) gathered on the host, rank 0 writes: N ranks log the 1-rank report."""
+    from .spatial_transformer import build_q2l
+    p = argparse.ArgumentParser()
+    _common(p)
+    p.add_argument("--backbone", type=str, default="swin_L_384_22k")
+    p.add_argument("--img_size", type=int, default=384)
+    p.add_argument("--hidden_dim", type=int, default=1536)
+    p.add_argument("--teacher_dim", type=int, default=512)
+    F, _ = p.parse_known_args(argv)
+    rank, world = _dist()
+    kfold = F.kfold if "crossval" in F.dataset_variant else 0
+    single = F.loss_type != "all"
+    modelname = f"{F.model}_l{F.dataset_variant}_cholect{kfold}"
+    model_dir = f"./__checkpoint__/run_{F.version}" + (f"_{F.loss_type}" if single else "")   # `run.py:86-88`
+    logfile = os.path.join(model_dir, modelname + ".log")
+    ckpt = F.test_ckpt or os.path.join(model_dir, modelname + ".pth")
+    model = build_q2l(F, dtype=torch.float32 if F.dtype == "fp32" else torch.bfloat16).eval()
+    model.load_state_dict(torch.load(ckpt, map_location="cpu"), strict=True)
+    _, _, videos = cholect.split_videos(F.dataset_variant, kfold)
+    labels = {v: cholect.load_labels(F.data_dir, v) for v in videos}
+    mine = extract.shard_videos(videos, [len(labels[v]["ivt"]) for v in videos], rank, world)
+    m = gather_recognition(_q2l_scores(F, model, [videos[vi] for vi in mine], labels), videos)
+    res = {}
+    try:
+        if rank == 0:
+            res = _write_report(logfile, m, F.loss_type, _chlg(F), "spatial_transformer")
+    finally:
+        _barrier()
+    return res
 
 
 # ------------------------------------------------------------------------------------------------ Temporal_mstct/test.py
@@ -531,15 +605,56 @@ def mstct_test(argv=None):
     return out_feats, out_preds
 
 
+def _mstct_scores(model, feats, vids, data_dir, loss_type):
+    """`test_loop` of `Temporal_mstct/run.py:237-262` behind its batch-256 loaders (`:371,378`): non-overlapping 256-frame chunks, each an
+    independent window; the heads the single-task model lacks are zero logits (`network.py:85-99`) = sigmoid 0.5"""
+    out_scores = {}
+    gi = {"i": 0, "v": 1, "t": 2, "ivt": 3}[loss_type]
+    for v in vids:
+        lab = cholect.load_labels(data_dir, v)
+        key = featfile.video_key(v)
+        f = feats[key] if key in feats else feats[v[3:]]
+        ps = []
+        for s in range(0, f.shape[0], 256):
+            o = model.forward_btd(torch.from_numpy(f[s:s + 256]).unsqueeze(0).cuda())
+            ps.append(_sigmoid(o[gi][0][0]))
+        p_own = np.concatenate(ps)
+        out_scores[v] = {h: (lab[h][:, 1:], p_own if h == loss_type else np.full(lab[h][:, 1:].shape, 0.5)) for h in ("i", "v", "t", "ivt")}
+    return out_scores
+
+
+def mstct_eval(argv=None) -> Dict[str, float]:
+    """`Temporal_mstct/run.py -e` (:527-580): the TEST-split videos in 256-frame chunks through the checkpoint of run_<version>[_<task>]/ (best
+    `.pth`, else `latest.pth`), the pickled metric objects (`mAPs.pckl` in the working directory, `:546-549`) and the closing report.  Rank 0
+    alone (a window takes < 1 ms)."""
+    from .temporal_mstct import VideoNas
+    p = argparse.ArgumentParser()
+    _common(p)
+    p.add_argument("--input_dim", type=int, default=1536)
+    p.add_argument("--final_embedding_dim", type=int, default=512)
+    F, _ = p.parse_known_args(argv)
+    if _dist()[0] != 0:
+        _barrier()
+        return {}
+    try:
+        model_dir = f"./__checkpoint__/run_{F.version}" + ("_" + F.loss_type if F.loss_type != "all" else "")
+        modelname = f"{F.model}_l8_cholect{F.dataset_variant}_k{F.kfold}_batchnorm_lowres"
+        logfile = os.path.join(model_dir, modelname + ".log")
+        ckpt = F.test_ckpt or os.path.join(model_dir, modelname + ".pth")
+        if not os.path.exists(ckpt):
+            ckpt = os.path.join(model_dir, modelname + "latest.pth")                         # no underscore (`run.py:268`)
+        model = VideoNas(F, [256, 384, 576, 864], 2, 8, 8, F.input_dim, F.final_embedding_dim,
+                         dtype=torch.float32 if F.dtype == "fp32" else torch.bfloat16).eval()
+        model.load_state_dict(torch.load(ckpt, map_location="cpu"))
+        feats = featfile.read_feats(featfile.feats_path("..", F.version1, F.kfold, F.loss_type))
+        _, _, test_videos = cholect.split_videos(F.dataset_variant, F.kfold)
+        m = recognition_from(_mstct_scores(model, feats, test_videos, F.data_dir, F.loss_type), test_videos)
+        return _write_report(logfile, m, F.loss_type, _chlg(F), "temporal_mstct", pckl="mAPs.pckl")
+    finally:
+        _barrier()
+
+
 # ------------------------------------------------------------------------------------------------ teacher run.py entry points
-class StageNotBuilt(SystemExit):
-    """a stage of the recipe whose training loop is not part of this build: exit code 3 and a message naming the reference lines"""
-
-    def __init__(self, msg: str):
-        print(msg, file=sys.stderr)
-        super().__init__(3)
-
-
 def _wants_train(argv) -> bool:
     argv = list(sys.argv[1:] if argv is None else argv)
     return "-t" in argv or "--train" in argv
@@ -681,26 +796,31 @@ def spatial_transformer_train(argv=None) -> Dict[str, float]:
     return last
 
 
+def _wants_test(argv) -> bool:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    return "-e" in argv or "--test" in argv
+
+
+def spatial_cnn_run(argv=None):
+    """`Spatial_cnn/run.py`: -t trains the student (`spatial_cnn_train`), -e evaluates the test split and writes the closing report
+    (`spatial_cnn_eval`, `run.py:503-560`); the extraction pass over all videos is `test.py` (`spatial_cnn_test`)."""
+    last = spatial_cnn_train(argv) if _wants_train(argv) else None
+    return spatial_cnn_eval(argv) if _wants_test(argv) else last
+
+
 def spatial_transformer_run(argv=None):
-    """`Spatial_transformer/run.py`: -t trains the single-task teacher (`spatial_transformer_train`), -e alone = the extraction /
-    evaluation pass (`spatial_transformer_test`)."""
-    if _wants_train(argv):
-        last = spatial_transformer_train(argv)
-        if "-e" not in (sys.argv[1:] if argv is None else argv) and "--test" not in (sys.argv[1:] if argv is None else argv):
-            return last
-    return spatial_transformer_test(argv)
+    """`Spatial_transformer/run.py`: -t trains the teacher (`spatial_transformer_train`), -e evaluates the test split and writes the closing
+    report (`spatial_transformer_eval`, `run.py:482-527`); the extraction pass over all videos is `test.py` (`spatial_transformer_test`)."""
+    last = spatial_transformer_train(argv) if _wants_train(argv) else None
+    return spatial_transformer_eval(argv) if _wants_test(argv) else last
 
 
 def mstct_run(argv=None):
-    """`Temporal_mstct/run.py`: -t trains the MS-TCT teacher on random 256-frame windows (`run.py:147-235`), -e evaluates / extracts."""
+    """`Temporal_mstct/run.py`: -t trains the MS-TCT teacher on random 256-frame windows (`run.py:147-235`), -e evaluates the test split and
+    writes the closing report + `mAPs.pckl` (`mstct_eval`, `run.py:527-580`); features / raw predictions for the student come from `test.py`
+    (`mstct_test`)."""
+    last = None
     if _wants_train(argv):
-        try:
-            from . import mstct_train
-        except ImportError:
-            raise StageNotBuilt("Temporal_mstct/run.py -t: training of the MS-TCT teacher (reference Temporal_mstct/run.py:147-235) is not built on "
-                                "MI355X yet.  Put a trained checkpoint under ./__checkpoint__/run_<version>[_<task>]/ and re-run with "
-                                "SKIP_TEACHER_TRAIN=1 (Scripts/train_fold1.sh), or run test.py -e directly.")
+        from . import mstct_train
         mstct_train.train_driver(sys.argv[1:] if argv is None else argv)
-        if "-e" not in (sys.argv[1:] if argv is None else argv):
-            return None
-    return mstct_test(argv)
+    return mstct_eval(argv) if _wants_test(argv) else last

@@ -37,16 +37,30 @@ def extract_video(frames: torch.Tensor, forward: Callable[[torch.Tensor], torch.
     return torch.vstack(out).numpy() if out else np.zeros((0, 0), np.float32)
 
 
-_POOLS: Dict[int, ThreadPoolExecutor] = {}          # helper threads by prefetch depth, kept for the life of the process: a thread's pinned staging
-                                                     # buffer (`pngdec._staging`, >= 64 MB per thread) is page-locked once, not once per video
+_POOLS: Dict[tuple, ThreadPoolExecutor] = {}        # helper threads by (device, prefetch depth), kept for the life of the process: a thread's pinned
+                                                     # staging buffer (`pngdec._staging`, >= 64 MB per thread) is page-locked once, not once per video
+
+
+def _shutdown_pools():
+    for pool in _POOLS.values():
+        pool.shutdown(wait=False, cancel_futures=True)
+    _POOLS.clear()
+
+
+import atexit  # noqa: E402
+
+atexit.register(_shutdown_pools)
 
 
 def iter_chunks(spans: Sequence[tuple], load_chunk: Callable[[int, int], torch.Tensor], prefetch=1):
     """Yield `load_chunk(s, e)` for every span in order.  With `prefetch` = k > 0 the next k spans are read and decoded on helper threads
     while the caller works on this one (the reference's DataLoader workers run ahead of the model the same way, `Spatial_cnn/test.py:240-241`);
     k = 2 lets the host part of one load (file reads, gathering the compressed bytes) overlap the device part of the load before it.
-    The helpers launch on a SIDE stream of their own (a loader that ends in a blocking status read -- the device PNG decoder -- then waits for
-    its own kernels only, not for every model pass the caller has queued); a chunk is handed over with an event the caller's stream waits on."""
+    The helpers launch on ONE side stream per generator (a loader that ends in a blocking status read -- the device PNG decoder -- then waits
+    for its own kernels only, not for every model pass the caller has queued): the device parts of k loads in flight serialise on it, what
+    overlaps is one load's host part with another's device part.  A chunk is handed over with an event the CALLER'S CURRENT stream waits on
+    (and `record_stream` for that stream): a consumer that fans out over streams of its own (`extract_u8(streams > 1)`) must order them
+    behind the current stream, as `VideoNas.extract_u8` does (`st.wait_stream(main)`)."""
     depth = int(prefetch)
     if depth <= 0 or len(spans) < 2 or not torch.cuda.is_available():
         for s, e in spans:
@@ -63,9 +77,9 @@ def iter_chunks(spans: Sequence[tuple], load_chunk: Callable[[int, int], torch.T
             ev.record(side)
         return fr, ev
     depth = min(depth, len(spans))
-    pool = _POOLS.get(depth)
+    pool = _POOLS.get((dev, depth))
     if pool is None:
-        pool = _POOLS[depth] = ThreadPoolExecutor(depth, thread_name_prefix="mt4-load")
+        pool = _POOLS[(dev, depth)] = ThreadPoolExecutor(depth, thread_name_prefix=f"mt4-load-{dev}")
     pending = [pool.submit(ahead, *spans[i]) for i in range(depth)]
     try:
         for i in range(len(spans)):

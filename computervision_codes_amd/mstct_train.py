@@ -504,7 +504,9 @@ def train_driver(argv=None):
         tr.load_state_dict(torch.load(latest, map_location="cpu"))
     else:   # no torch.nn init here: deterministic synthetic start (the reference starts from its trunc_normal_ init)
         tr.load_state_dict(synth.fill_from_shapes(shapes.mstct_shapes(F.input_dim, (256, 384, 576, 864), 2, 8, F.final_embedding_dim, lt), seed=F.seed))
-    train_videos, _, _ = cholect.split_videos(F.dataset_variant, F.kfold)
+    train_videos, val_videos, _ = cholect.split_videos(F.dataset_variant, F.kfold)
+    val_interval = F.epochs - 1 if F.val_interval == -1 else max(1, F.val_interval)
+    best, best_path, vmodel = 0.0, os.path.join(model_dir, modelname + ".pth"), None
     feats = featfile.read_feats(featfile.feats_path("..", F.version1, F.kfold, lt))                # `dataloader.py:220-222`
     lab_name = {"i": "i", "v": "v", "t": "t", "ivt": "ivt"}[lt]
     xs, zs = {}, {}
@@ -535,7 +537,24 @@ def train_driver(argv=None):
         if rank == 0:
             _log(logfile, f"Traning | lr: {tr.lr:.6f} | epoch {epoch} | loss {tot / steps:.4f} | {time.time() - t0:.2f} secs")
             os.makedirs(model_dir, exist_ok=True)
-            torch.save(tr.state_dict(), latest + ".tmp")
+            state = tr.state_dict()
+            torch.save(state, latest + ".tmp")
             os.replace(latest + ".tmp", latest)
+            if epoch % val_interval == 0:                          # validation + `weight_mgt` (`run.py:416-452,265-277`): best `.pth` by the task's mAP
+                from .drivers import _chlg, _mstct_scores
+                from .metrics import recognition_from
+                t1 = time.time()
+                if vmodel is None:
+                    from .temporal_mstct import VideoNas
+                    vmodel = VideoNas(F, [256, 384, 576, 864], 2, 8, 8, F.input_dim, F.final_embedding_dim).eval()
+                vmodel.load_state_dict(state)
+                vm = recognition_from(_mstct_scores(vmodel, feats, val_videos, F.data_dir, lt), val_videos) if val_videos else None
+                score = float(vm[lt].compute_video_AP(ignore_null=_chlg(F))["mAP"]) if vm else 0.0
+                if score > best or not os.path.exists(best_path):
+                    best = max(best, score)
+                    torch.save(state, best_path + ".tmp")
+                    os.replace(best_path + ".tmp", best_path)
+                    _log(logfile, f">>> Saving checkpoint for epoch {epoch + 1} at {best_path}, time {time.ctime()} ")
+                _log(logfile, f"\t\t\t\t\t\t\t video-wise | eta {time.time() - t1:.2f} secs | mAP => {lt}: [{score:.5f}] ")
     _barrier()
     return tr

@@ -185,6 +185,17 @@ def chain_gemm_supported(k1: int, n1: int, n2: int, conv: bool) -> bool:
     return (k1, n1, n2) in ((256, 1024, 256), (128, 512, 128)) or (conv and (k1, n1, n2) == (128, 512, 256))
 
 
+CHAIN_MIN_TILES = 192   # 128-row tiles below which the chained launch is not used (see chain_gemm_pays)
+
+
+def chain_gemm_pays(rows: int) -> bool:
+    """`mt4_chain_gemm_bf16` runs ONE 128-row, 8-wave workgroup per CU and walks the whole K1 -> N1 -> N2 chain serially inside it, with no
+    tile choice: below about a round of the 256 CUs (ResNet-50 at batch 1: 7 workgroups in layer2, 2 in layer3) the two `conv_nhwc` / `linear`
+    launches, whose small tiles spread the same work over the chip, are faster -- and bit-identical, so callers simply fall back.  The
+    threshold is measured (`profiles/r04_chain_small_batch_ab.txt`); latency contexts (`latency_tiles`) never chain."""
+    return (rows + 127) // 128 >= CHAIN_MIN_TILES and not _LATENCY_TILES.get()
+
+
 def chain_gemm(x2d: torch.Tensor, w1_frag: torch.Tensor, b1: torch.Tensor, w2_frag: torch.Tensor, b2: torch.Tensor, *, r1: Optional[torch.Tensor] = None,
                r2: Optional[torch.Tensor] = None, y1: Optional[torch.Tensor] = None, y2: Optional[torch.Tensor] = None):
     """Two dependent 1x1 convolutions / linear layers in one launch (`mt4_chain_gemm_bf16`), bit-identical to the two `conv_nhwc` launches.

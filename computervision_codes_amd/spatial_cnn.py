@@ -196,7 +196,7 @@ class VideoNas:
                     pending = None
                     nq = f"{pre}layer{li}.{bi + 1}." if bi + 1 < n else (f"{pre}layer{li + 1}.0." if li < last else None)
                     if (li in self.chain_layers and nq is not None and o_buf is None and self.dtype == torch.bfloat16 and (q + "conv3frag") in self._p
-                            and (nq + "conv1frag") in self._p
+                            and (nq + "conv1frag") in self._p and ops.chain_gemm_pays(o.shape[0] * ((o.shape[1] - 1) // s + 1) * ((o.shape[2] - 1) // s + 1))
                             and ops.chain_gemm_supported(self._p[q + "conv3frag"].shape[1], self._p[q + "conv3frag"].shape[0], self._p[nq + "conv1frag"].shape[0], True)):
                         # conv2, then conv3 + add + ReLU and the NEXT block's conv1 + ReLU in one launch: this block's output map is written once
                         # (the next block's residual) and never read back
@@ -255,8 +255,9 @@ class VideoNas:
                 cin, hh, ww = cout, h2, w2
         return plan
 
-    def launch_groups(self, h: int, w: int):
-        """indices into `conv_plan(h, w)` per kernel launch of one forward at bench batch sizes, in launch order (the walk of `_layers`): one conv
+    def launch_groups(self, h: int, w: int, batch: Optional[int] = None):
+        """indices into `conv_plan(h, w)` per kernel launch of one forward at bench batch sizes (or at `batch` frames: the chained launches are
+        gated on the row count like `_layers` gates them, `ops.chain_gemm_pays`), in launch order (the walk of `_layers`): one conv
         per launch, except (bf16 ResNet-50) the layer1 Bottlenecks (one `mt4_bottleneck_fused_bf16` launch each, the last one carrying layer2.0's
         conv1), conv3 + downsample of the strided blocks (one GEMM), conv2 + conv3 of layer2's identity blocks (`mt4_conv_desc.fuse_expand`) and
         conv3 + the next block's conv1 in the layers of `chain_layers` (`mt4_chain_gemm_bf16`)"""
@@ -295,7 +296,8 @@ class VideoNas:
                     groups.append([idx[q + "conv1"]])
                 pending = False
                 nplanes = planes[li - 1] if bi + 1 < n else (planes[li] if li < 4 else 0)
-                if (li in self.chain_layers and nq is not None and not has_ds and li in (2, 3)
+                rows = None if batch is None else batch * plan[idx[q + "conv3"]]["Ho"] * plan[idx[q + "conv3"]]["Wo"]
+                if (li in self.chain_layers and nq is not None and not has_ds and li in (2, 3) and (rows is None or ops.chain_gemm_pays(rows))
                         and ops.chain_gemm_supported(planes[li - 1], 4 * planes[li - 1], nplanes, True)):
                     groups += [[idx[q + "conv2"]], [idx[q + "conv3"], idx[nq + "conv1"]]]
                     pending = True

@@ -241,7 +241,7 @@ class Qeruy2Label:
                               q_stride=3 * c, k_stride=3 * c, v_stride=3 * c, scale=(c // nh) ** -0.5, bias=blk["bias"], mask=blk["mask"])
         x = ops.linear(a, *blk["proj"], residual=x, out_row_map=blk["row_map"])
         y = ops.layernorm(x, *blk["norm2"])
-        if blk["mlp_frag"] is not None:
+        if blk["mlp_frag"] is not None and ops.chain_gemm_pays(y.shape[0]):
             return ops.chain_gemm(y, blk["mlp_frag"][0], blk["fc1"][1], blk["mlp_frag"][1], blk["fc2"][1], r2=x)[1]
         h = ops.linear(y, *blk["fc1"], act="gelu")
         return ops.linear(h, *blk["fc2"], residual=x)

@@ -15,3 +15,20 @@ def kernels_digest(files=CONV_SOURCES) -> str:
         h.update(f.encode())
         h.update(open(os.path.join(here, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def library_sources():
+    """every file `libmt4hip.so` is built from: csrc/*.hip, csrc/*.h and the C-ABI header (names relative to csrc/)"""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    return tuple(sorted(f for f in os.listdir(here) if f.endswith((".hip", ".h")))) + ("../../include/mt4hip.h",)
+
+
+def library_digest() -> str:
+    """digest of ALL library sources.  The Makefile bakes it into `libmt4hip.so` (`mt4_source_digest()`); `_lib.py` refuses a library whose
+    baked digest is not the digest of the sources beside it (a stale `.so` / `.o` would silently detach every committed PMC figure and every
+    test from the code in the tree) unless MT4_ALLOW_STALE=1."""
+    return kernels_digest(library_sources())
+
+
+if __name__ == "__main__":
+    print(library_digest())

@@ -30,11 +30,15 @@ extern "C" {
 #define MT4_F32 0
 #define MT4_BF16 1
 
-/* 9 in this revision (5 -> 6: mt4_stem_maxpool_bf16, mt4_bottleneck_fused_next_bf16, mt4_pack_fragments_bf16, the x2 / fuse_expand fields at the
+/* 10 in this revision (5 -> 6: mt4_stem_maxpool_bf16, mt4_bottleneck_fused_next_bf16, mt4_pack_fragments_bf16, the x2 / fuse_expand fields at the
  * end of mt4_conv_desc; 6 -> 7: mt4_copy_spans_u8; 7 -> 8: mt4_chain_gemm_bf16; 8 -> 9: stat_sums at the end of
- * mt4_conv_desc, mt4_bn_apply_sums_t / _f32, mt4_avgpool1d_rows, mt4_interp_linear_rows, `beta` / relu code 2 of mt4_bn_backward_f32, `bias_grad` of mt4_wgrad_conv1d_f32, MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup in mt4_refresh_weights).  A binding checks it once at load
+ * mt4_conv_desc, mt4_bn_apply_sums_t / _f32, mt4_avgpool1d_rows, mt4_interp_linear_rows, `beta` / relu code 2 of mt4_bn_backward_f32, `bias_grad` of mt4_wgrad_conv1d_f32, MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup in mt4_refresh_weights; 9 -> 10: mt4_source_digest, mt4_attention takes head dims up to 512).  A binding checks it once at load
  * (computervision_codes_amd/_lib.py: ABI_VERSION). */
 int mt4_abi_version(void);
+/* 16 hex digits: sha256 over every source file the library was built from (csrc/*.hip, csrc/*.h, this header), baked in at build time.  No
+ * reference counterpart (the reference has no native code): it ties a loaded binary to the sources in the tree -- `_lib.py` compares it with
+ * `srcdigest.library_digest()` at load and refuses a stale library. */
+const char* mt4_source_digest(void);
 const char* mt4_strerror(int code);
 /* last hipError_t (as int) seen by this thread inside the library, 0 if none */
 int mt4_last_hip_error(void);
@@ -312,10 +316,11 @@ int mt4_kd_mix(const float* s, const float* tea_i, const float* tea_v, const flo
 /* Conv1d weight gradient in the packed layout of mt4_conv_nhwc: dw[co][tap*CPT4 + ci] (+)= sum_{b,t} dy[b,t][co] *
  * x[b, t + tap*dil - pad][ci] (zero outside the sequence).  dy [B*T][Cout], x [B*T][Cin]; Cin, Cout % 4 == 0.
  * bias_grad (optional, [Cout]): bias_grad[co] += sum_{b,t} dy[b,t][co] in the same launch (always ADDED, with fp32 atomics: the caller
- * zeroes it) -- what mt4_colsum_f32 would compute in a launch of its own. */
+ * zeroes it, `accumulate` governs dw_packed only) -- what mt4_colsum_f32 would compute in a launch of its own.  Alignment: dy and x 16 bytes
+ * (MT4_EALIGN otherwise); dw_packed and bias_grad need float alignment only. */
 int mt4_wgrad_conv1d_f32(const float* dy, const float* x, float* dw_packed, int32_t B, int32_t T, int32_t Cout, int32_t Cin,
                          int32_t taps, int32_t dil, int32_t pad, int32_t accumulate, float* bias_grad, void* stream);
-/* out[c] (+)= sum_m x[m*ld + c]   (bias gradients) */
+/* out[c] (+)= sum_m x[m*ld + c]   (bias gradients).  `out` needs float alignment only (a bias slice of a flat gradient buffer). */
 int mt4_colsum_f32(const float* x, float* out, int64_t M, int32_t C, int32_t ld, int32_t accumulate, void* stream);
 /* nn.BCEWithLogitsLoss pieces (run.py:196-212, 331): col_loss[n] += sum_m bce(y[m][n], z[m][n]);
  * dy[m*ld_dy + n] = (sigmoid(y) - z) * col_scale[n].  z [M][N] dense. */

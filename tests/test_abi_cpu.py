@@ -26,7 +26,7 @@ def test_header_symbols_all_exported_and_bound():
 
 def test_abi_version_and_error_strings():
     from computervision_codes_amd import _lib
-    assert _lib.lib.mt4_abi_version() == _lib.ABI_VERSION == 9
+    assert _lib.lib.mt4_abi_version() == _lib.ABI_VERSION == 10
     assert _lib.lib.mt4_strerror(0) == b"ok"
     assert b"invalid" in _lib.lib.mt4_strerror(-1)
 
@@ -78,3 +78,25 @@ def test_integration_doc_struct_matches_header_mirror():
         if m:
             fields += [n.strip() for n in m.group(1).split(",")]
     assert fields == [f[0] for f in _lib.ConvDesc._fields_], fields
+
+
+def test_loaded_library_is_built_from_the_sources_in_the_tree(tmp_path):
+    """`mt4_source_digest()` (baked by csrc/Makefile) == `srcdigest.library_digest()` of the sources on disk; a library beside CHANGED sources is
+    refused at import (MT4_ALLOW_STALE=1 loads it anyway)"""
+    import shutil
+    import subprocess
+    import sys
+    from computervision_codes_amd import _lib, srcdigest
+    assert _lib.lib.mt4_source_digest().decode() == srcdigest.library_digest() == _lib.SOURCE_DIGEST and len(_lib.SOURCE_DIGEST) == 16
+    assert {"igemm_conv.hip", "mt4_common.h", "../../include/mt4hip.h"} <= set(srcdigest.library_sources())
+    pkg = tmp_path / "computervision_codes_amd"
+    shutil.copytree(os.path.join(ROOT, "computervision_codes_amd"), pkg, ignore=shutil.ignore_patterns("*.o", "__pycache__"))
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "include")
+    with open(pkg / "csrc" / "tcn_kernels.hip", "a") as f:
+        f.write("\n// edited after the build\n")
+    code = "import computervision_codes_amd._lib as l; print('loaded', l.SOURCE_DIGEST)"
+    env = {k: v for k, v in os.environ.items() if k != "MT4_ALLOW_STALE"}
+    r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "rebuild" in r.stderr and "MT4_ALLOW_STALE" in r.stderr, r.stderr[-500:]
+    r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, env=dict(env, MT4_ALLOW_STALE="1"), capture_output=True, text=True)
+    assert r.returncode == 0 and "loaded " + _lib.SOURCE_DIGEST in r.stdout, r.stderr[-500:]

@@ -124,3 +124,108 @@ def test_recognition_ignore_null_drops_the_six_null_triplets():
     assert N_NULL_TRIPLETS == 6 and cut["AP"].shape == (94,) and np.allclose(cut["AP"], full["AP"][:94], equal_nan=True)
     assert abs(cut["mAP"] - np.nanmean(full["AP"][:94])) < 1e-12 and cut["mAP"] != full["mAP"]
     assert np.allclose(m.compute_video_AP("v", ignore_null=True)["AP"], m.compute_video_AP("v")["AP"], equal_nan=True)
+
+
+def _synthetic_scores(nvid=5, seed=3):
+    """{video -> {head -> (labels, scores)}} with ragged lengths; every component label is the disentangled triplet label (as in the dataset)"""
+    from computervision_codes_amd.metrics import disentangle
+    rng = np.random.default_rng(seed)
+    out = {}
+    for v in range(nvid):
+        n = 30 + 7 * v
+        y = (rng.random((n, 100)) < 0.04).astype(np.int64)
+        out[f"VID{v:02d}"] = {"ivt": (y, rng.random((n, 100)))}
+        for h in ("i", "v", "t"):
+            out[f"VID{v:02d}"][h] = (disentangle(y, h), rng.random((n, disentangle(y, h).shape[1])))
+    return out
+
+
+def test_topk_is_the_reference_loop_and_takes_a_component():
+    """`Recognition.topK(k, component)` (`Spatial_cnn/run.py:543-548`) against the loop the reference writes out in
+    `Temporal_mstct/run.py:507-523` (per frame: positives among the k best scores / positives, summed over all frames), on disentangled inputs"""
+    from computervision_codes_amd.metrics import disentangle, recognition_from
+    sc = _synthetic_scores()
+    m = recognition_from(sc, sorted(sc))
+    for comp in ("ivt", "i", "v", "t", "iv", "it"):
+        for k in (5, 10, 20):
+            correct, total = 0.0, 0
+            for v in sorted(sc):
+                t, p = disentangle(sc[v]["ivt"][0].astype(np.float64), comp), disentangle(sc[v]["ivt"][1], comp)
+                for gt, pd in zip(t, p):
+                    gt_pos = np.nonzero(gt)[0]
+                    pd_idx = (-pd).argsort()[:k]
+                    correct += len(set(gt_pos).intersection(set(pd_idx)))
+                    total += len(gt_pos)
+            assert abs(m["ivt"].topK(k, comp) - correct / max(total, 1)) < 1e-12, (comp, k)
+    assert m["i"].topK(5) == m["i"].topK(5, "ivt")
+    with pytest.raises(ValueError):
+        m["i"].topK(5, "v")
+
+
+@pytest.mark.parametrize("style", ["spatial_cnn", "spatial_transformer", "temporal_tenco", "temporal_mstct"])
+def test_final_report_rows_match_sklearn(style):
+    """the closing report (`Spatial_cnn/run.py:517-560`, `Temporal_tenco/run.py:534-570`): the mean-AP row holds I / V / T DISENTANGLED from the
+    triplet head for --loss_type all (head-wise for i | v | t, and in the temporal drivers' 'singletest' row), computed here straight from
+    sklearn; the per-category lines print the numpy vectors; the spatial_cnn style carries the three top-K rows"""
+    from sklearn.metrics import average_precision_score
+    from computervision_codes_amd.metrics import disentangle, final_report, recognition_from
+    sc = _synthetic_scores()
+    order = sorted(sc)
+    m = recognition_from(sc, order)
+
+    def video_map(head, comp):
+        per = []
+        for v in order:
+            t, p = sc[v][head]
+            t, p = disentangle(t.astype(np.float64), comp), disentangle(p, comp)
+            per.append([average_precision_score(t[:, c], p[:, c]) if t[:, c].sum() > 0 else np.nan for c in range(t.shape[1])])
+        return float(np.nanmean(np.nanmean(np.array(per), axis=0)))
+    dis = [video_map("ivt", c) for c in ("i", "v", "t", "iv", "it", "ivt")]
+    single = [video_map(c, "ivt") for c in ("i", "v", "t")] + dis[3:]
+    fmt = lambda a: ":::::: : " + " | ".join(f"{x:.4f}" for x in a) + " "
+    lines, res = final_report(m, "all", False, style)
+    text = "\n".join(lines)
+    assert "Per-category AP" in text and "IVT : [" in text and lines[-1] == "=" * 50
+    assert fmt(dis) in lines                                     # `--loss_type all`: disentangled components
+    assert abs(res["AP_ivt"] - dis[5]) < 1e-12 and abs(res["AP_i"] - dis[0]) < 1e-12
+    if style.startswith("temporal"):
+        assert fmt(single) in lines and lines.index(fmt(dis)) < lines.index(fmt(single)) and "------------singletest-------------" in lines
+    else:
+        lines_i, res_i = final_report(m, "i", False, style)      # a single-task run reports the component heads' own AP (`run.py:518-521`)
+        assert fmt(single) in lines_i and abs(res_i["AP_v"] - single[1]) < 1e-12
+    if style == "spatial_cnn":
+        for k in (5, 10, 20):
+            i = lines.index(f"top {k}:  I  |  V  |  T  |  IV  |  IT  |  IVT ")
+            assert lines[i + 1] == fmt([m["ivt"].topK(k, c) for c in ("i", "v", "t", "iv", "it", "ivt")])
+    if style == "spatial_transformer":
+        assert lines[-2] == "top 5:  I  |  V  |  T  |  IV  |  IT  |  IVT "      # the reference prints this header and no numbers (`run.py:525`)
+
+
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from computervision_codes_amd.extract import shard_videos
+    from computervision_codes_amd.metrics import final_report, gather_recognition
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    sc = _synthetic_scores()
+    order = sorted(sc)
+    mine = shard_videos(order, [sc[v]["ivt"][0].shape[0] for v in order], rank, world)
+    m = gather_recognition({order[i]: sc[order[i]] for i in mine}, order)
+    q.put((rank, final_report(m, "all", False, "spatial_cnn")[0]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_evaluation_reports_the_single_rank_numbers():
+    """videos sharded over 2 ranks (gloo), (labels, scores) gathered on the host: both ranks hold the report of the single-process run, line for line"""
+    import torch.multiprocessing as mp
+    from computervision_codes_amd.metrics import final_report, recognition_from
+    sc = _synthetic_scores()
+    want = final_report(recognition_from(sc, sorted(sc)), "all", False, "spatial_cnn")[0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_gather_worker, args=(r, 2, 29577, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert got[0] == want and got[1] == want

@@ -73,12 +73,24 @@ def test_row_pitch_and_argument_checks(cuda):
         ops.chain_gemm(x5, ops.pack_fragments(w1p5), b15, ops.pack_fragments(w2p5), b25, r1=torch.zeros((64, 1024), dtype=torch.bfloat16, device=cuda))
 
 
-def test_resnet50_trunk_with_chained_launches_is_bit_identical(cuda):
+def test_resnet50_trunk_with_chained_launches_is_bit_identical(cuda, monkeypatch):
     """ResNet-50 bf16 extraction with conv3 + next conv1 chained in layer3 / layers 2 and 3 against one launch per conv there: features and
-    logits equal bit for bit (ragged batch: the last row tile of every map is partial)"""
+    logits equal bit for bit (ragged batch: the last row tile of every map is partial).  The chained launch is gated on the row count
+    (`ops.chain_gemm_pays`: one 128-row workgroup per CU cannot fill the chip at small batches); the gate is opened here and checked below."""
     import types
-    from computervision_codes_amd import shapes
+    from computervision_codes_amd import ops, shapes
     from computervision_codes_amd.spatial_cnn import VideoNas
+    assert not ops.chain_gemm_pays(5 * 28 * 28) and ops.chain_gemm_pays(1336 * 14 * 14) and ops.chain_gemm_pays(128 * 192)
+    with ops.latency_tiles():
+        assert not ops.chain_gemm_pays(1336 * 14 * 14)
+    calls = []
+    orig = ops.chain_gemm
+    monkeypatch.setattr(ops, "chain_gemm", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    gated = VideoNas(args=types.SimpleNamespace(network="resnet50", loss_type="all", student_dim=2048, teacher_dim=1536, train=False),
+                     dtype=torch.bfloat16).eval().load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes("resnet50"), seed=3))
+    out_gated = gated.extract_u8(synth.synthetic_frames(5, 224, 224, seed=9).to(cuda))
+    assert not calls and len(gated.launch_groups(224, 224, batch=5)) == 39 and len(gated.launch_groups(224, 224, batch=1336)) == 35
+    monkeypatch.setattr(ops, "CHAIN_MIN_TILES", 0)
     args = types.SimpleNamespace(network="resnet50", loss_type="all", student_dim=2048, teacher_dim=1536, train=False)
     sd = synth.fill_from_shapes(shapes.spatial_cnn_shapes("resnet50"), seed=3)
     frames = synth.synthetic_frames(5, 224, 224, seed=9).to(cuda)
@@ -88,7 +100,8 @@ def test_resnet50_trunk_with_chained_launches_is_bit_identical(cuda):
         m.chain_layers = chain
         outs.append(m.extract_u8(frames))
         assert len(m.launch_groups(224, 224)) == {(): 39, (3,): 35, (2, 3): 35}[chain]
-    for o in outs[1:]:
+    assert len(calls) == 4 + 7          # layer3: blocks 1-4 -> next conv1; layer2: blocks 1-3 (the last into layer3.0)
+    for o in outs[1:] + [out_gated]:
         assert torch.equal(o[3][0], outs[0][3][0]) and all(torch.equal(a[1], b[1]) for a, b in zip(o, outs[0]))
 
 
@@ -100,9 +113,15 @@ def test_swin_mlp_through_chain_gemm_is_bit_identical(cuda, monkeypatch):
     args = types.SimpleNamespace(backbone="swin_B_384_22k", img_size=384, hidden_dim=1024, loss_type="t")
     sd = synth.fill_from_shapes(shapes.q2l_param_shapes("swin_B_384_22k", 384, 1024, "t"), seed=5)
     frames = synth.synthetic_frames(2, 384, 384, seed=6).to(cuda)
+    from computervision_codes_amd import ops
+    monkeypatch.setattr(ops, "CHAIN_MIN_TILES", 0)           # (2 frames: below the row-count gate of `ops.chain_gemm_pays`)
+    calls = []
+    orig = ops.chain_gemm
+    monkeypatch.setattr(ops, "chain_gemm", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
     m = build_q2l(args, dtype=torch.bfloat16).eval().load_state_dict(sd)
     assert m._stages[0]["blocks"][0]["mlp_frag"] is not None and m._stages[1]["blocks"][1]["mlp_frag"] is not None and m._stages[2]["blocks"][0]["mlp_frag"] is None
     a = m(frames)
+    assert len(calls) == 4
     monkeypatch.setenv("MT4_NO_MLP_CHAIN", "1")
     m2 = build_q2l(args, dtype=torch.bfloat16).eval().load_state_dict(sd)
     assert m2._stages[0]["blocks"][0]["mlp_frag"] is None

@@ -32,6 +32,40 @@ def _make_dataset(d, n_frames=3, h=64, w=96):
     return vids
 
 
+def _report_rows(log, header="Mean AP"):
+    """the ':::::: : a | b | c | d | e | f' rows that follow a '<header>:  I  |  V  |  T  |  IV  |  IT  |  IVT' line of the closing report"""
+    lines = log.splitlines()
+    rows = []
+    for i, ln in enumerate(lines[:-1]):
+        if ln.startswith(header + ":  I  |  V  |  T  |  IV  |  IT  |  IVT") and lines[i + 1].startswith(":::::: :"):
+            rows.append([float(x) for x in lines[i + 1][len(":::::: :"):].split("|")])
+    return rows
+
+
+def _sklearn_rows(maps):
+    """mean-AP rows straight from sklearn on the metric objects' per-video (labels, scores): per video and class AP, NaN without positives,
+    nan-mean over videos then classes; components of the triplet head = max over the triplets that share the component"""
+    from sklearn.metrics import average_precision_score
+    from computervision_codes_amd.metrics import _TRIPLETS
+    trip = np.array(_TRIPLETS)
+    comp_id = {"i": trip[:, 0], "v": trip[:, 1], "t": trip[:, 2], "iv": 10 * trip[:, 0] + trip[:, 1], "it": 15 * trip[:, 0] + trip[:, 2], "ivt": np.arange(100)}
+
+    def vmap(head, comp=None):
+        per = []
+        for t, p in zip(maps[head].global_targets, maps[head].global_predictions):
+            if comp is not None:
+                ids = comp_id[comp]
+                t = np.stack([t[:, ids == c].max(1) for c in np.unique(ids)], 1)
+                p = np.stack([p[:, ids == c].max(1) for c in np.unique(ids)], 1)
+            per.append([average_precision_score(t[:, c], p[:, c]) if t[:, c].sum() > 0 else np.nan for c in range(t.shape[1])])
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return float(np.nanmean(np.nanmean(np.array(per), 0)))
+    dis = [vmap("ivt", c) for c in ("i", "v", "t", "iv", "it", "ivt")]
+    return {"disentangled": dis, "single": [vmap("i"), vmap("v"), vmap("t")] + dis[3:]}
+
+
 def test_student_pipeline_scripts(cuda, tmp_path):
     tree = tmp_path / "MT4MTLKD"
     shutil.copytree(os.path.join(ROOT, "MT4MTLKD"), tree)
@@ -58,11 +92,17 @@ def test_student_pipeline_scripts(cuda, tmp_path):
     with torch.no_grad():
         ref = o_cnn.spatial_cnn_forward(sd_cnn, synth.normalize_frames(fr), "resnet18")[3][0]
     assert np.abs(feats["79"] - ref.numpy()).max() < 1e-3
-    assert os.path.exists(tree / "Temporal_tenco" / "__checkpoint__" / "run_SwinL2Res18_TCN" /
-                          "rendezvous_l8_cholectcholect45-crossval_k1_batchnorm_lowres_test_mAP.pkl")
-    log = open(tree / "Temporal_tenco" / "__checkpoint__" / "run_SwinL2Res18_TCN" /
-               "rendezvous_l8_cholectcholect45-crossval_k1_batchnorm_lowres.log").read()
-    assert "AP_ivt=" in log
+    # `Temporal_tenco/run.py:529-570`: the pickled metric objects and the closing report; its mean-AP rows recomputed here with sklearn from the
+    # pickled (labels, scores)
+    run = tree / "Temporal_tenco" / "__checkpoint__" / "run_SwinL2Res18_TCN"
+    maps = pickle.load(open(run / "mAPs_k1.pckl", "rb"))
+    assert sorted(maps) == ["i", "ivt", "t", "v"] and len(maps["ivt"].global_targets) == 9 and maps["ivt"].global_predictions[0].shape == (3, 100)
+    log = open(run / "rendezvous_l8_cholectcholect45-crossval_k1_batchnorm_lowres.log").read()
+    rows = _report_rows(log)
+    assert len(rows) == 2 and "------------singletest-------------" in log and "Per-category AP" in log
+    want = _sklearn_rows(maps)
+    assert np.allclose(rows[0], np.round(want["disentangled"], 4), atol=1.1e-4, equal_nan=True), (rows[0], want["disentangled"])
+    assert np.allclose(rows[1], np.round(want["single"], 4), atol=1.1e-4, equal_nan=True), (rows[1], want["single"])
 
 
 def test_extraction_script_device_png_decode_writes_the_same_features(cuda, tmp_path):
@@ -108,7 +148,10 @@ def test_tenco_train_driver_runs_and_checkpoints(cuda, tmp_path):
     table = shapes.tenco_shapes(11, 10, 3, 512, 512, 100, fpn=True)
     assert list(sd.keys()) == [k for k, _ in table] and all(tuple(sd[k].shape) == tuple(s) for k, s in table)
     log = open(str(ck).replace("_latest.pth", ".log")).read()
-    assert log.count("Traning | lr:") == 2 and "AP_ivt=" in log
+    assert log.count("Traning | lr:") == 2 and log.count("mAP => ivt:") == 2 and ">>> Saving checkpoint for epoch 1" in log     # validation + `weight_mgt`
+    best = torch.load(str(ck).replace("_latest.pth", ".pth"), map_location="cpu")
+    assert list(best.keys()) == [k for k, _ in table]
+    assert len(_report_rows(log)) == 2 and os.path.exists(ck.parent / "mAPs_k1.pckl")                                           # the -e pass
 
 
 def test_spatial_cnn_train_driver_runs_and_checkpoints(cuda, tmp_path):
@@ -140,6 +183,8 @@ def test_spatial_cnn_train_driver_runs_and_checkpoints(cuda, tmp_path):
     assert int(sd["basemodel.basemodel.bn1.num_batches_tracked"]) > 0 and all(torch.isfinite(v.float()).all() for v in sd.values())
     log = open(run / "rendezvous_lcholect45-crossval_cholect1.log").read()
     assert log.count("Traning | lr:") == 2 and "mAP => ivt:" in log
+    # -e: the test split through the best checkpoint, the closing report of `run.py:517-560`
+    assert len(_report_rows(log)) == 1 and all(len(_report_rows(log, f"top {k}")) == 1 for k in (5, 10, 20)) and "IVT : [" in log
     r = subprocess.run([sys.executable, "test.py", "-e", "--network", "resnet18", "--student_dim", "512", "--loss_type", "all", "--batch", "8", "--version", "S",
                         "--data_dir", data, "--image_height", "32", "--image_width", "32", "--kfold", "1"],
                        cwd=tree / "Spatial_cnn", env=env, capture_output=True, text=True, timeout=600)
@@ -271,15 +316,25 @@ def test_mstct_train_driver_runs_and_feeds_test_py(cuda, tmp_path):
     assert not torch.equal(sd["TemporalEncoder.block2.0.Global_Relational_Block.q.weight"], sd0["TemporalEncoder.block2.0.Global_Relational_Block.q.weight"])
     assert all(torch.isfinite(v).all() for v in sd.values())
     log = open(str(ck).replace("latest.pth", ".log")).read()
-    assert log.count("Traning | lr:") == 2
+    assert log.count("Traning | lr:") == 2 and log.count("mAP => v:") == 2 and os.path.exists(str(ck).replace("latest.pth", ".pth"))   # validation, best `.pth`
+    # -e: `mAPs.pckl` in the working directory (`run.py:546-549`) + the closing report; the 'singletest' row holds the v head's own AP
+    maps = pickle.load(open(tree / "Temporal_mstct" / "mAPs.pckl", "rb"))
+    rows, want = _report_rows(log), _sklearn_rows(maps)
+    assert len(rows) == 2 and np.allclose(rows[1], np.round(want["single"], 4), atol=1.1e-4, equal_nan=True), (rows, want)
+    assert not os.path.exists(tree / "0-5fold" / "data_feats" / "run_X_MSTCT")       # run.py writes no feature files: that is test.py (`test.py:338-366`)
+    flags = ["--loss_type", "v", "--input_dim", str(D), "--version", "X_MSTCT", "--version1", "X", "--data_dir", data, "--kfold", "1"]
+    r = subprocess.run([sys.executable, "test.py", "-e"] + flags, cwd=tree / "Temporal_mstct", env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     mp = pickle.load(open(tree / "0-5fold" / "data_feats" / "run_X_MSTCT" / "k1_v_pred.pkl", "rb"))
     assert len(mp) == len(vids) and mp[vids[0][-2:]].shape == (20, 10)
 
 
 def test_mstct_run_t_e_under_torchrun_two_ranks_writes_each_file_once(cuda, tmp_path):
-    """`Scripts/train_fold1.sh` with NGPU = 2 runs `launch run.py -t -e`: both ranks train (all-reduce), then the -e pass shards the videos over
-    the ranks, gathers on the host and rank 0 ALONE writes the feature / prediction files (every rank writing the same `.tmp` raced).  The
-    files must equal a single-process `test.py -e` on the checkpoint the two ranks left."""
+    """`Scripts/train_fold1.sh` with NGPU = 2 runs `launch run.py -t -e`: both ranks train (all-reduce), rank 0 validates, checkpoints and writes
+    the closing report once; `test.py -e` under torchrun then shards the videos over the ranks, gathers on the host and rank 0 ALONE writes the
+    feature / prediction files (every rank writing the same `.tmp` raced).  The files must equal a single-process `test.py -e` on the checkpoint
+    the two ranks left."""
     from computervision_codes_amd import featfile
     tree = tmp_path / "MT4MTLKD"
     shutil.copytree(os.path.join(ROOT, "MT4MTLKD"), tree)
@@ -294,6 +349,11 @@ def test_mstct_run_t_e_under_torchrun_two_ranks_writes_each_file_once(cuda, tmp_
     env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MT4_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
                         "run.py", "-t", "-e"] + flags, cwd=tree / "Temporal_mstct", env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    log = open(tree / "Temporal_mstct" / "__checkpoint__" / "run_X_MSTCT_v" / "rendezvous_l8_cholectcholect45-crossval_k1_batchnorm_lowres.log").read()
+    assert len(_report_rows(log)) == 2                                                     # ONE report (rank 0), not one per rank
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29542",
+                        "test.py", "-e"] + flags, cwd=tree / "Temporal_mstct", env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     outdir = tree / "0-5fold" / "data_feats" / "run_X_MSTCT"
     assert sorted(os.listdir(outdir)) == ["k1_v_feats.pkl", "k1_v_pred.pkl"]            # no stray .tmp
@@ -313,7 +373,7 @@ def test_mstct_run_t_e_under_torchrun_two_ranks_writes_each_file_once(cuda, tmp_
 def test_q2l_teacher_train_driver_runs_and_feeds_test_py(cuda, tmp_path):
     """`Spatial_transformer/run.py -t -e` (the first line of Scripts/train_fold1.sh's teacher block) with Swin-T at 224: two epochs on the
     synthetic dataset, `_latest.pth` / best `.pth` in run_<version>_<task>/ with the reference's state-dict keys, validation mAP logged, then
-    the -e pass reads that checkpoint and writes the frame features where Temporal_mstct looks for them"""
+    the -e pass evaluates the test split (closing report) and test.py writes the frame features where Temporal_mstct looks for them"""
     tree = tmp_path / "MT4MTLKD"
     shutil.copytree(os.path.join(ROOT, "MT4MTLKD"), tree)
     data = str(tmp_path / "CholecT45")
@@ -339,6 +399,11 @@ def test_q2l_teacher_train_driver_runs_and_feeds_test_py(cuda, tmp_path):
     assert not torch.equal(sd[k], sd0[k])
     log = open(d / "rendezvous_lcholect45-crossval_cholect1.log").read()
     assert log.count("Traning | lr:") == 2 and "mAP => t:" in log and f"backbone: {len(up) - 2} tensors from" in log
+    assert len(_report_rows(log)) == 1 and "IVT : [" in log                               # -e: the closing report (`run.py:500-527`)
+    r = subprocess.run([sys.executable, "test.py", "-e", "--img_size", "224", "--backbone", "swin_T_224_1k", "--hidden_dim", "768", "--loss_type", "t",
+                        "--version", "T", "--data_dir", data, "--kfold", "1"],
+                       cwd=tree / "Spatial_transformer", env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     feats = pickle.load(open(tree / "0-5fold" / "data_feats" / "run_T" / "k1_t_feats.pkl", "rb"))
     assert list(feats) == [v[3:] for v in vids] and feats["79"].shape == (2, 768) and np.isfinite(feats["79"]).all()
 
@@ -374,3 +439,60 @@ def test_q2l_all_train_driver_reads_teacher_files_and_checkpoints(cuda, tmp_path
         assert not torch.equal(sd[k], sd0[k]), k
     log = open(d / "rendezvous_lcholect45-crossval_cholect1.log").read()
     assert log.count("Traning | lr:") == 2 and "mAP => ivt:" in log
+
+
+def test_spatial_cnn_run_e_closing_report_one_rank_equals_two_ranks_and_sklearn(cuda, tmp_path):
+    """`Spatial_cnn/run.py -e` (`run.py:503-560`): the test-split videos through the best checkpoint, the closing report in the log.  The mean-AP
+    and top-K rows equal sklearn / the reference's own top-k loop on scores computed in-process from the same checkpoint; under torchrun with 2
+    ranks (videos sharded, (labels, scores) gathered on the host) the report is the single-rank report, line for line."""
+    import types
+    from computervision_codes_amd.metrics import HEADS, Recognition
+    from computervision_codes_amd.spatial_cnn import VideoNas
+    tree = tmp_path / "MT4MTLKD"
+    shutil.copytree(os.path.join(ROOT, "MT4MTLKD"), tree)
+    data = str(tmp_path / "CholecT45")
+    _make_dataset(data, n_frames=9, h=32, w=48)
+    sd = synth.fill_from_shapes(shapes.spatial_cnn_shapes("resnet18"), seed=21)
+    flags = ["--network", "resnet18", "--student_dim", "512", "--loss_type", "all", "--dataset_variant=cholect45-crossval", "--kfold", "1", "--batch=8",
+             "--data_dir", data, "--image_height", "32", "--image_width", "48", "--device_batch", "4"]
+    logs = {}
+    for tag, launch, env in (("one", [sys.executable], dict(os.environ, PYTHONPATH=ROOT)),
+                             ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                      "--master-port", "29543"], dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MT4_DIST_BACKEND="gloo"))):
+        run = tree / "Spatial_cnn" / "__checkpoint__" / f"run_{tag}"
+        os.makedirs(run)
+        torch.save(sd, run / "rendezvous_lcholect45-crossval_cholect1.pth")
+        r = subprocess.run(launch + ["run.py", "-e", f"--version={tag}"] + flags, cwd=tree / "Spatial_cnn", env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        logs[tag] = open(run / "rendezvous_lcholect45-crossval_cholect1.log").read()
+    assert logs["one"] == logs["two"] and logs["one"].count("Per-category AP") == 1
+    # the same scores in-process -> sklearn
+    args = types.SimpleNamespace(network="resnet18", loss_type="all", student_dim=512, teacher_dim=1536, train=False)
+    m = VideoNas(args=args, dtype=torch.float32).eval().load_state_dict(sd)
+    _, _, test_videos = cholect.split_videos("cholect45-crossval", 1)
+    maps = {h: Recognition(k) for h, k in HEADS}
+    for v in test_videos:
+        lab = cholect.load_labels(data, v)
+        fr = torch.from_numpy(cholect.load_frames_u8(data, v, lab["ivt"][:, 0], 32, 48)).to(cuda)
+        out = m.extract_u8(fr)
+        for gi, h in enumerate(("i", "v", "t", "ivt")):
+            maps[h].update(lab[h][:, 1:], torch.sigmoid(out[gi][1].float()).cpu().numpy())
+            maps[h].video_end()
+    want = _sklearn_rows(maps)
+    rows = _report_rows(logs["one"])
+    assert len(rows) == 1 and np.allclose(rows[0], np.round(want["disentangled"], 4), atol=1.1e-4, equal_nan=True), (rows, want)
+    from computervision_codes_amd.metrics import _TRIPLETS
+    trip = np.array(_TRIPLETS)
+    ids = {"i": trip[:, 0], "v": trip[:, 1], "t": trip[:, 2], "iv": 10 * trip[:, 0] + trip[:, 1], "it": 15 * trip[:, 0] + trip[:, 2], "ivt": np.arange(100)}
+    for k in (5, 10, 20):
+        got = _report_rows(logs["one"], f"top {k}")[0]
+        for ci, comp in enumerate(("i", "v", "t", "iv", "it", "ivt")):
+            correct, total = 0.0, 0                                  # `Temporal_mstct/run.py:507-523`
+            for t, p in zip(maps["ivt"].global_targets, maps["ivt"].global_predictions):
+                t = np.stack([t[:, ids[comp] == c].max(1) for c in np.unique(ids[comp])], 1)
+                p = np.stack([p[:, ids[comp] == c].max(1) for c in np.unique(ids[comp])], 1)
+                for gt, pd in zip(t, p):
+                    gt_pos = np.nonzero(gt)[0]
+                    correct += len(set(gt_pos).intersection(set((-pd).argsort()[:k])))
+                    total += len(gt_pos)
+            assert abs(got[ci] - correct / max(total, 1)) < 1.1e-4, (k, comp)
