@@ -375,7 +375,8 @@ def _tenco_scores(model, feats, vids, data_dir):
         lab = cholect.load_labels(data_dir, v)
         x = torch.from_numpy(feats[featfile.video_key(v)]).unsqueeze(0).cuda()
         out, out_i, out_v, out_t, _, _ = model(x, False)
-        out_scores[v] = {key: (lab[key][:, 1:], _sigmoid(lg[0][0].transpose(0, 1))) for key, lg in (("ivt", out), ("i", out_i), ("v", out_v), ("t", out_t))}
+        n = x.shape[1]
+        out_scores[v] = {key: (lab[key][:n, 1:], _sigmoid(lg[0][0].transpose(0, 1))) for key, lg in (("ivt", out), ("i", out_i), ("v", out_v), ("t", out_t))}
     return out_scores
 
 
@@ -619,7 +620,8 @@ def _mstct_scores(model, feats, vids, data_dir, loss_type):
             o = model.forward_btd(torch.from_numpy(f[s:s + 256]).unsqueeze(0).cuda())
             ps.append(_sigmoid(o[gi][0][0]))
         p_own = np.concatenate(ps)
-        out_scores[v] = {h: (lab[h][:, 1:], p_own if h == loss_type else np.full(lab[h][:, 1:].shape, 0.5)) for h in ("i", "v", "t", "ivt")}
+        n = p_own.shape[0]                                          # (a feature file may hold fewer frames than the label file lists: the first n)
+        out_scores[v] = {h: (lab[h][:n, 1:], p_own if h == loss_type else np.full(lab[h][:n, 1:].shape, 0.5)) for h in ("i", "v", "t", "ivt")}
     return out_scores
 
 

@@ -185,7 +185,7 @@ def chain_gemm_supported(k1: int, n1: int, n2: int, conv: bool) -> bool:
     return (k1, n1, n2) in ((256, 1024, 256), (128, 512, 128)) or (conv and (k1, n1, n2) == (128, 512, 256))
 
 
-CHAIN_MIN_TILES = 192   # 128-row tiles below which the chained launch is not used (see chain_gemm_pays)
+CHAIN_MIN_TILES = 48    # 128-row tiles below which the chained launch is not used (chain_gemm_pays; profiles/r04_chain_small_batch_ab.txt)
 
 
 def chain_gemm_pays(rows: int) -> bool:
