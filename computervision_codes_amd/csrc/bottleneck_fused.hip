@@ -482,7 +482,7 @@ extern "C" int mt4_bottleneck_fused_bf16(const void* x, void* y, const void* w_f
     a.b1 = b1; a.b2 = b2; a.b3 = b3; a.bds = bds;
     a.B = B; a.H = H; a.W = W;
     a.tiles_h = cdiv(H, TH); a.tiles_w = cdiv(W, TW);
-    a.nt = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
+    a.nt = 1;
     if ((long long)B * a.tiles_h * a.tiles_w > 0x7fffffffLL) return MT4_EUNSUPPORTED;
     return ds ? launch<64, true>(a, (hipStream_t)stream) : launch<256, false>(a, (hipStream_t)stream);
 }
@@ -522,7 +522,7 @@ extern "C" int mt4_bottleneck_fused_next_bf16(const void* x, void* y_even, void*
     a.wn = (const char*)w_next; a.bn = b_next;
     a.B = B; a.H = H; a.W = W; a.H2 = (H + 1) / 2; a.W2 = (W + 1) / 2;
     a.tiles_h = cdiv(H, TH); a.tiles_w = cdiv(W, TW);
-    a.nt = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
+    a.nt = 1;
     if ((long long)B * a.tiles_h * a.tiles_w > 0x7fffffffLL) return MT4_EUNSUPPORTED;
     return launch<256, false, true>(a, (hipStream_t)stream);
 }

@@ -1417,9 +1417,9 @@ int launch_tile(const ConvK& k, bool fast, hipStream_t s) {
     if (k.stat_sums && (!CAN_STATS || (k.Cout % (OUT_F32 ? 4 : 8)) != 0)) return MT4_EUNSUPPORTED;
     kk.n_tiles = cdiv(k.Cout, BN);
     kk.total_tiles = m_tiles * kk.n_tiles;
-    kk.nt_epi = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
+    kk.nt_epi = 1;
     {   // outputs that fit the 256 MB Infinity Cache stay cacheable for the next layer (+0.8 % over always-nt; MT4_NT_MIN_MB overrides)
-        const long long min_mb = MT4_ENV_INT("MT4_NT_MIN_MB", 200);
+        const long long min_mb = MT4_NT_MIN_MB;
         if ((long long)k.M * k.Cout * 2 < min_mb * 1000000LL) kk.nt_epi = 0;
     }
     // LDS: two operand stages, or ONE when the whole K fits a single step (then only the epilogue staging may need
@@ -1484,8 +1484,8 @@ int launch_dual(const ConvK& k, hipStream_t s) {
     ConvK kk = k;
     kk.n_tiles = cdiv(k.Cout, BN);
     kk.total_tiles = cdiv(k.M, BM) * kk.n_tiles;
-    kk.nt_epi = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
-    if ((long long)k.M * k.Cout * 2 < (long long)MT4_ENV_INT("MT4_NT_MIN_MB", 200) * 1000000LL) kk.nt_epi = 0;
+    kk.nt_epi = 1;
+    if ((long long)k.M * k.Cout * 2 < (long long)MT4_NT_MIN_MB * 1000000LL) kk.nt_epi = 0;
     auto fn = igemm_conv_kernel<u16, BM, BN, 4, 4, 2, true, false, 1, true>;
     MT4_RAISE_LDS(fn);
     hipLaunchKernelGGL(fn, dim3(kk.total_tiles), dim3(1024), 2 * stage, s, kk);
@@ -1541,9 +1541,9 @@ int launch_patch3x3(const ConvK& k, hipStream_t s) {
     ConvK kk = k;
     kk.n_tiles = cdiv(k.Cout, BN);
     kk.total_tiles = cdiv(k.M, BM) * kk.n_tiles;
-    kk.nt_epi = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
+    kk.nt_epi = 1;
     {
-        const long long min_mb = MT4_ENV_INT("MT4_NT_MIN_MB", 200);
+        const long long min_mb = MT4_NT_MIN_MB;
         if ((long long)k.M * (EXPAND ? k.f_cout : k.Cout) * 2 < min_mb * 1000000LL) kk.nt_epi = 0;
     }
     constexpr int threads = WM_ * WN_ * 64;
@@ -1600,9 +1600,9 @@ int launch_stem_patch(const ConvK& k, hipStream_t s) {
     ConvK kk = k;
     kk.n_tiles = 1;
     kk.total_tiles = cdiv(k.M, BM);
-    kk.nt_epi = MT4_ENV_SET("MT4_NO_NT") ? 0 : 1;
+    kk.nt_epi = 1;
     {
-        const long long min_mb = MT4_ENV_INT("MT4_NT_MIN_MB", 200);
+        const long long min_mb = MT4_NT_MIN_MB;
         if ((long long)k.M * k.Cout * 2 < min_mb * 1000000LL) kk.nt_epi = 0;
     }
     // frame pixels a tile of 256 consecutive output pixels of ONE image can span: its own run, 3 extra pixels per output row it crosses,
@@ -1633,29 +1633,24 @@ int auto_tile(int M, int N, int nsteps, int es) {
     // 8-wave 256-row tiles (bf16, profiles/r01_tile_tuning_8wave.txt): one workgroup per CU with the same 2 waves per SIMD, but
     // 0.5-0.75x the operand bytes per FLOP through L2 -> LDS-DMA, whose issue cost is what the K-loop waits on
     if (es == 2 && N >= 256) {   // (fp32 launches are bound by the fp32 MFMA rate: the same tiles change nothing there, same-box A/B)
-        if (nsteps == 1 && tiles(13) >= fill) return MT4_ENV_INT("MT4_TILE1STEP", 13);
-        if (nsteps >= 2 && tiles(15) >= 190) return MT4_ENV_INT("MT4_TILE256", 17);
+        if (nsteps == 1 && tiles(13) >= fill) return 13;
+        if (nsteps >= 2 && tiles(15) >= 190) return 17;
     }
     if (es == 2 && N > 64 && N <= 128 && nsteps < 4 && tiles(20) >= 8 * fill) {   // short K: 256x64 (Swin stage-1 proj)
-        const int t = MT4_ENV_INT("MT4_TILE128S", 20);
-        if (t) return t;
+        return 20;
     }
     if (es == 2 && N > 64 && N <= 128 && nsteps >= 4 && tiles(19) >= 8 * fill) {   // 16-wave 256x128, 3 stages; many rounds: small tail
-        const int t = MT4_ENV_INT("MT4_TILE128", 19);
-        if (t) return t;
+        return 19;
     }
     // single K-step: smallest footprint, most workgroups per CU
-    if (nsteps == 1 && tiles(3) >= 4 * fill) return MT4_ENV_INT("MT4_TILE1STEP_SMALL", 3);
+    if (nsteps == 1 && tiles(3) >= 4 * fill) return 3;
     if (N > 64) {
         if (nsteps >= 4 && tiles(1) >= fill) return 1;
         if (tiles(4) >= fill) return 4;
         if (tiles(1) >= fill) return 1;
     } else if (N > 32) {
-        // 64-channel layers at many rounds: 256 pixels x 64 channels, 8 waves (+2.8 % frames/s, same-box A/B; MT4_TILE64=0 disables)
-        {
-            const int t64 = MT4_ENV_INT("MT4_TILE64", 20);
-            if (t64 && es == 2 && tiles(20) >= 8 * fill) return t64;
-        }
+        // 64-channel layers at many rounds: 256 pixels x 64 channels, 8 waves (+2.8 % frames/s, same-box A/B)
+        if (es == 2 && tiles(20) >= 8 * fill) return 20;
         if (tiles(2) >= fill) return 2;
         if (tiles(3) >= fill) return 3;
     }
@@ -1672,7 +1667,7 @@ int auto_tile(int M, int N, int nsteps, int es) {
     }
     // few workgroups, long K (a TCN layer over one short video): nothing else hides the per-step DMA latency, so take
     // the 4-stage ring of the same tile (slower than 2 stages whenever the chip is full: it halves workgroups per CU)
-    if (!MT4_ENV_SET("MT4_NO_DEEP_RING") && nsteps >= 8) {
+    if (nsteps >= 8) {
         if (best == 5) return 10;
         if (best == 6) return 11;
         if (best == 3) return 9;
@@ -1768,7 +1763,7 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
         if (!d->fuse_y || !d->fuse_bias || d->fuse_cout <= 0 || (d->fuse_cout % 128) != 0) return MT4_EINVAL;
         if (((uintptr_t)d->fuse_w | (uintptr_t)d->fuse_y | (uintptr_t)d->fuse_bias) & 15) return MT4_EALIGN;
         if (!(patch3x3_ok(d, k, fast) && d->Cin == 128 && d->Cout == 128 && d->tile == 0 && !d->x2 &&
-              (long long)cdiv(k.M, 256) * cdiv(d->fuse_cout, 256) >= 256 && !MT4_ENV_SET("MT4_NO_EXPAND_FUSE")))
+              (long long)cdiv(k.M, 256) * cdiv(d->fuse_cout, 256) >= 256))
             return MT4_EUNSUPPORTED;
         k.f_w = (const char*)d->fuse_w; k.f_bias = d->fuse_bias; k.f_y = (char*)d->fuse_y; k.f_cout = d->fuse_cout; k.f_relu = d->fuse_relu ? 1 : 0;
         return d->W <= 31 ? launch_patch3x3<128, 128, 2, 2, 2, true>(k, (hipStream_t)stream) : launch_patch3x3<256, 128, 4, 2, 2, true>(k, (hipStream_t)stream);
@@ -1803,7 +1798,7 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
     if (latency) tile = 0;
     hipStream_t s = (hipStream_t)stream;
     if (tile == 34) return MT4_EUNSUPPORTED;   // (retired id: the persistent form of the stem patch kernel, measured no faster in the bench)
-    if (tile == 33 || (tile == 0 && stem_patch_ok(d, k, fast) && !MT4_ENV_SET("MT4_NO_STEM_PATCH"))) {   // the space-to-depth stem
+    if (tile == 33 || (tile == 0 && stem_patch_ok(d, k, fast))) {   // the space-to-depth stem
         if (!stem_patch_ok(d, k, fast)) return MT4_EUNSUPPORTED;
         const int rc = launch_stem_patch(k, s);
         if (rc != MT4_EUNSUPPORTED || tile != 0) return rc;
@@ -1816,31 +1811,21 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
         // 3x3 stride-1 layers at many rounds of the chip: the patch kernel (same-box sweep at 1336 frames,
         // profiles/r01_tile_tuning_patch3x3.txt: layer1 conv2 0.462 -> 0.375 ms (256x64), layer2 0.343 -> 0.300 (128x128, 4 waves with 64x64
         // wave tiles), layer3 0.242 -> 0.244 and layer4 0.232 -> 0.230 (256x256: even); ResNet-50 bench, alternating runs on one box:
-        // 67.8 k frames/s generic, 68.5 k mode 2, 69.0 k mode 3).  MT4_PATCH3X3: 0 = generic tiles only, 1 = patch kernel for Cout <= 64 and the
-        // two-stage generic 256x128 tile for Cout <= 128, 2 = patch tiles 24 / 26 / 23, 3 = default: 24 / 30 (32 for rows wider than 31) / 23
-        const int mode = MT4_ENV_INT("MT4_PATCH3X3", 3);
-        int pt = 0;
-        if (mode == 1) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? 18 : 0;
-        else if (mode == 2) pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? 26 : 23;
-        else if (mode >= 3)   // (128-row tiles only while the 2W+2 halo stays small: W = 56 at 256x448 frames: t30 0.475 ms, t32 0.310, generic 0.325)
-            pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? (d->W <= 31 ? 30 : 32) : 23;
-        if (pt >= 21) {
-            const int rc = launch_patch_tile(k, pt, s);
-            if (rc != MT4_EUNSUPPORTED) return rc;   // (patch too large for LDS: generic tiles)
-        } else if (pt) {
-            tile = pt;
-        }
+        // 67.8 k frames/s generic, 69.0 k with the tiles below): 256x64 for Cout <= 64, 128x128 for Cout <= 128 (only while the 2W+2 halo stays
+        // small -- W = 56 at 256x448 frames: tile 30 0.475 ms, tile 32 0.310, generic 0.325), 256x256 above
+        const int pt = d->Cout <= 64 ? 24 : d->Cout <= 128 ? (d->W <= 31 ? 30 : 32) : 23;
+        const int rc = launch_patch_tile(k, pt, s);
+        if (rc != MT4_EUNSUPPORTED) return rc;   // (patch too large for LDS: generic tiles)
     }
     if (tile == 0) {
         tile = auto_tile(k.M, k.Cout, k.nsteps, d->dtype == MT4_F32 ? 4 : 2);
         // few tiles and a long K: the 4-stage ring of the small tiles (10 / 11), or -- when the caller asked for latency (tile -1) and the
-        // geometry is on the LDS-DMA path -- four K-split groups per workgroup (36 / 35); MT4_KSPLIT=0 keeps the rings
+        // geometry is on the LDS-DMA path -- eight K-split groups of two waves per workgroup (36 / 37)
         // (measured, 4-stage TCN, fp32, T = 256: 1.23 ms with the rings, 1.07 with four groups, 0.96 with eight; config 1 0.357 -> 0.277;
         //  with more than one workgroup per CU -- T = 2000 -- the 16-wave workgroups lose 27 %, and bf16 (half the K-steps; 0.640 -> 0.630 ms with eight groups: the 84 dependent launches are the floor) gains nothing:
         //  fp32 launches of at most 256 tiles only)
-        if (latency && fast && d->dtype == MT4_F32 && (tile == 10 || tile == 11) && MT4_ENV_INT("MT4_KSPLIT", 1)) {
-            const int ksm = MT4_ENV_INT("MT4_KSPLIT", 1);   // 1: eight groups of two waves (tile 37), 2: four groups of four (35), 3: 35's 3-stage form (38)
-            const int kt = tile == 11 ? (ksm == 2 ? 35 : ksm == 3 ? 38 : 37) : 36;
+        if (latency && fast && d->dtype == MT4_F32 && (tile == 10 || tile == 11)) {
+            const int kt = tile == 11 ? 37 : 36;
             if ((long long)cdiv(k.M, kTiles[kt - 1].bm) * cdiv(k.Cout, kTiles[kt - 1].bn) <= 256) tile = kt;
         }
         // a whole video (T ~ 2000 frames x 512 channels: `Temporal_tenco/run.py:369-379` runs batch 1 on full videos): 64 x 64 tiles are one
@@ -1849,7 +1834,7 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
         // (tools/tcn_long_sweep.py): fp32 2.35 ms (32 x 32, 4-stage ring) -> 2.13 (two groups) -> 2.04 (four groups, tile 40);
         // bf16 1.00 -> 0.83 (tile 40) -> 0.74 (two groups with 3-stage rings, tile 41).  At T = 1000 (128 such tiles: half the chip) the
         // small tiles stay, bf16 on the 4-stage 32 x 64 ring (0.74 -> 0.69 ms)
-        if (latency && fast && k.nsteps >= 8 && MT4_ENV_INT("MT4_KSPLIT", 1) && (tile == 5 || tile == 6 || tile == 10 || tile == 11 || tile == 3 || tile == 9)) {
+        if (latency && fast && k.nsteps >= 8 && (tile == 5 || tile == 6 || tile == 10 || tile == 11 || tile == 3 || tile == 9)) {
             const long long t64 = (long long)cdiv(k.M, 64) * cdiv(k.Cout, 64);
             if (t64 >= 192 && t64 <= 512) tile = d->dtype == MT4_F32 ? 40 : 41;
             else if (d->dtype == MT4_BF16 && tile == 11 && (long long)cdiv(k.M, 32) * cdiv(k.Cout, 64) >= 256) tile = 10;

@@ -149,7 +149,7 @@ extern "C" int mt4_preprocess_u8_s2d(const uint8_t* frames, void* out, int32_t B
     const int Hs = (H + 6) / 2, Ws = (W + 6) / 2;
     const long long total = (long long)B * Hs * Ws;
     hipLaunchKernelGGL(stem_input_s2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frames, (u16*)out, B, H,
-                       W, Hs, Ws, mean[0], mean[1], mean[2], std[0], std[1], std[2], MT4_ENV_SET("MT4_S2D_NO_NT") ? 0 : 1);
+                       W, Hs, Ws, mean[0], mean[1], mean[2], std[0], std[1], std[2], 1);
     return mt4_check_launch();
 }
 

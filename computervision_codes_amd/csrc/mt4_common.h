@@ -72,6 +72,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
         }                                                                                                                   \
     } while (0)
 
-// integer value of an environment variable, read ONCE per process and call site (tuning switches must not cost a getenv per launch)
-#define MT4_ENV_INT(name, dflt) ([]() { static const int v = getenv(name) ? atoi(getenv(name)) : (dflt); return v; }())
-#define MT4_ENV_SET(name) ([]() { static const bool v = getenv(name) != nullptr; return v; }())
+// output / residual rows are stored / loaded with the non-temporal bit when the launch's output exceeds this many MB (below it the map fits the
+// Infinity Cache and stays cacheable for the next layer; each byte is touched once per launch: +2.6 % frames/s on ResNet-50, +4.5 % on Swin-B,
+// same-box A/Bs of round 1)
+#define MT4_NT_MIN_MB 200

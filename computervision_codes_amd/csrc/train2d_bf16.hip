@@ -473,7 +473,7 @@ int launch_wgrad(WgK a, hipStream_t stream) {
     a.cin_tiles = cdiv(a.Cin, 64 * BNT);
     const int pairs = cdiv(a.Cout, 64 * BMT) * a.cin_tiles * K;
     // workgroups per launch: every one ends with (64 BMT)(64 BNT) K fp32 atomics, so as few as keep the CUs busy (two per CU)
-    const int target = MT4_ENV_INT("MT4_WGRAD_WGS", 256 * OCC);
+    const int target = 256 * OCC;      // (256 / 512 / 1024 / 2048 workgroups measured: more closing atomics cost more than they hide)
     int nsplit = (target + pairs - 1) / pairs;
     if (nsplit > a.ntiles) nsplit = a.ntiles;
     if (nsplit < 1) nsplit = 1;

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void wgrad_conv2d_f32_wide_kernel(const float*
 template <int BMT, int BNT>
 static int launch_wgrad32_wide(const float* dy, const float* x, float* dw, Wg2 a, int Cout, hipStream_t s) {
     const int tiles = cdiv(a.Kpad, 64 * BNT) * cdiv(Cout, 64 * BMT);
-    long long splits = (MT4_ENV_INT("MT4_WGRAD32_WGS", 768) + tiles - 1) / tiles;
+    long long splits = (768 + tiles - 1) / tiles;
     const long long max_splits = (a.M + 255) / 256;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -522,7 +522,7 @@ extern "C" int mt4_wgrad_conv2d_f32(const float* dy, const float* x, float* dw_p
     // wider tiles where the channel counts allow AND the launch still has >= 2 workgroups per CU (each pixel split covers >= 256 pixels: a small
     // batch has few of them -- ResNet-50 at batch 8: 9.6 ms with the 64 x 64 kernel everywhere, 10.2 with the wide tiles);
     // the 64 x 64 kernel below: the narrowest layers, small batches
-    if (!MT4_ENV_SET("MT4_NO_WGRAD32_WIDE")) {
+    {
         hipStream_t s = (hipStream_t)stream;
         const long long max_splits = (a.M + 255) / 256;
         auto fills = [&](int bm, int bn) { return (long long)cdiv(a.Kpad, bn) * cdiv(Cout, bm) * max_splits >= 512; };

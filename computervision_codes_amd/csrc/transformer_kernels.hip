@@ -736,12 +736,11 @@ extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* 
     const int vec_ok = (hd % 4 == 0) && (k_stride * es) % (4 * es) == 0 && (v_stride * es) % (4 * es) == 0 &&
                        (((uintptr_t)k | (uintptr_t)v) & (4 * es - 1)) == 0;
     hipStream_t s = (hipStream_t)stream;
-    // large head dim, bf16, no bias / mask, keys fit one workgroup's score registers: matrix-unit kernel (MT4_NO_MHA_MFMA=1: VALU kernel)
+    // large head dim, bf16, no bias / mask, keys fit one workgroup's score registers: matrix-unit kernel 
     // (head dim 256: Q2L over Swin-B, d = 1024 / 4 heads; 384: over Swin-L, d = 1536 -- the shipped teacher, Scripts/train_fold1.sh:5-12)
     if (dtype == MT4_BF16 && (hd == 256 || hd == 384) && !bias && !mask && Nk <= 160 && (q_stride % 8) == 0 && (k_stride % 8) == 0 && (v_stride % 8) == 0 &&
         (o_stride % 4) == 0 && ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0) && (((uintptr_t)out & 7) == 0) && cdiv(Nq, 64) <= 65535) {
-        static const bool off = getenv("MT4_NO_MHA_MFMA") != nullptr;
-        if (!off) {
+        {
             const int nkt = cdiv(Nk, 16);
             const dim3 grid(H, B, cdiv(Nq, 64)), block(256);
 #define MHA_LAUNCH_HD(NKTV, HDV) { constexpr int nkp = NKTV * 16, nkp2 = ((NKTV + 1) / 2) * 32; const size_t lds = (size_t)nkp * 144 + 64 * ((nkp2 + 8) * 2); \
@@ -761,11 +760,10 @@ extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* 
     // fp32 (parity mode), no bias / mask, <= 256 keys, head dim <= 128: exact-fp32 matrix-unit kernel (MS-TCT's global block)
     if (dtype == MT4_F32 && hd <= 128 && (hd % 4) == 0 && !bias && !mask && Nk <= 256 && (q_stride % 4) == 0 && (k_stride % 4) == 0 &&
         (v_stride % 4) == 0 && (o_stride % 4) == 0 && ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0) &&
-        cdiv(Nq, 64) <= 65535 && !MT4_ENV_SET("MT4_NO_MHA_MFMA")) {
+        cdiv(Nq, 64) <= 65535) {
         const dim3 block(256);
         // too few 64-query workgroups for the chip (one MS-TCT window: 32): four waves per 16 queries, keys split between them
-        static const bool no_ksplit = MT4_ENV_SET("MT4_NO_MHA_KSPLIT");
-        if ((long long)H * B * cdiv(Nq, 64) < 128 && cdiv(Nq, 16) <= 65535 && !no_ksplit) {
+        if ((long long)H * B * cdiv(Nq, 64) < 128 && cdiv(Nq, 16) <= 65535) {
             const dim3 grid(H, B, cdiv(Nq, 16));
             if (Nk <= 128) {
                 const size_t lds = sizeof(float) * (size_t)((128 * 36 > 32 * 132 ? 128 * 36 : 32 * 132) + 128 + 4 * 16 * 32);
@@ -807,7 +805,7 @@ extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* 
     // query instead: 8x less serial work per lane, 8x more workgroups (workgroup size: 64/128/256 threads within 2 %, A/B)
     if (hd <= 64 && (long long)cdiv(Nq, threads / cfgs[ci][1]) * H * B < 128) {   // (measured: 103 -> 72 us at hd 32, 94 -> 88 at hd 48; slower for hd >= 72)
         for (int i = 7; i < 12; ++i)
-            if (cfgs[i][0] * 8 >= hd) { static const int thr = getenv("MT4_ATT_THREADS") ? atoi(getenv("MT4_ATT_THREADS")) : 256; ci = i; threads = thr; break; }
+            if (cfgs[i][0] * 8 >= hd) { ci = i; threads = 256; break; }
     }
     const int DPL = cfgs[ci][0], LPQ = cfgs[ci][1];
     const int row = LPQ * (DPL + 4);

@@ -585,7 +585,7 @@ def mstct_test(argv=None):
         fs, ps = [], []
         for s in range(0, f.shape[0], 256):                                                # non-overlapping 256-frame chunks
             x = torch.from_numpy(f[s:s + 256]).unsqueeze(0).cuda()
-            if x.shape[1] == 256 and not os.environ.get("MT4_NO_GRAPH"):
+            if x.shape[1] == 256:
                 if graphed is None:
                     from .graph import GraphedForward
                     graphed = GraphedForward(lambda xx: model.forward_btd(xx), [x])

@@ -65,7 +65,7 @@ def conv_out_size(h: int, k: int, stride: int, pad: int, dil: int) -> int:
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-_TCN_LINEAR = not os.environ.get("MT4_NO_TCN_LINEAR")     # latency contexts: nn.Linear on few rows through the TCN latency kernel
+_TCN_LINEAR = True     # latency contexts: nn.Linear on few rows through the TCN latency kernel
 _TCN_LINEAR_MAX_ROWS = 512
 _LATENCY_TILES = contextvars.ContextVar("mt4_latency_tiles", default=False)   # per thread / task: forwards may run from several threads
 

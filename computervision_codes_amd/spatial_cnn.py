@@ -39,15 +39,16 @@ class VideoNas:
         self._sd: Dict[str, torch.Tensor] = {}
         self._p: Dict[str, object] = {}
         self._streams = []
-        import os
-        self.fuse_stem_pool = not os.environ.get("MT4_NO_STEM_POOL_FUSE")   # stem conv + max-pool in one launch (bf16 uint8-frame path)
-        self.fuse_expand = not os.environ.get("MT4_NO_EXPAND_FUSE")   # layer2's stride-1 blocks: conv2 + conv3 in one launch (large batches)
-        self.fuse_next_block = not os.environ.get("MT4_NO_NEXT_FUSE")   # layer2.0's conv1 behind the last layer1 block, in its launch
-        self.fuse_downsample = not os.environ.get("MT4_NO_DS_FUSE")   # strided Bottlenecks: conv3 + downsample branch as one GEMM (bf16)
-        self.fuse_bottleneck = not os.environ.get("MT4_NO_BNECK_FUSE")   # layer1 Bottlenecks in one launch each (bf16 ResNet-50)
+        # fused launches of the bf16 ResNet-50 trunk (every one bit-identical to the launches it replaces except fuse_downsample, which keeps one
+        # fp32 accumulator chain where the two-launch form rounds the branch to bf16; attributes so that tests and A/B tools can switch them):
+        self.fuse_stem_pool = True      # stem conv + max-pool in one launch (uint8-frame path)
+        self.fuse_expand = True         # layer2's stride-1 blocks: conv2 + conv3 in one launch (large batches; used when a block is not chained)
+        self.fuse_next_block = True     # layer2.0's conv1 behind the last layer1 block, in its launch
+        self.fuse_downsample = True     # strided Bottlenecks: conv3 + downsample branch as one GEMM
+        self.fuse_bottleneck = True     # layer1 Bottlenecks in one launch each
         # conv3 (+ bn3 + add + ReLU) of an identity Bottleneck and conv1 (+ bn1 + ReLU) of the block behind it in ONE launch (`ops.chain_gemm`,
-        # K-chunk accumulation: the 4 x planes map is written once and not read back; bit-identical): the layers it is used in (bf16 ResNet-50)
-        self.chain_layers = tuple(int(c) for c in os.environ.get("MT4_CHAIN", "23") if c in "23")
+        # K-chunk accumulation: the 4 x planes map is written once and not read back): the layers it is used in, gated on the row count
+        self.chain_layers = (2, 3)
 
     def train(self, mode: bool = True):
         self.training = bool(mode)
@@ -106,8 +107,7 @@ class VideoNas:
         pre = "basemodel.basemodel."
         p: Dict[str, object] = {}
         p["stem"] = self._fold(pre + "conv1", pre + "bn1", stem=True)
-        import os
-        if self.dtype == torch.bfloat16 and not os.environ.get("MT4_NO_S2D"):   # space-to-depth stem (even frame sizes): one 128-byte run per kernel row, LDS-DMA path
+        if self.dtype == torch.bfloat16:   # space-to-depth stem (even frame sizes): one 128-byte run per kernel row, LDS-DMA path
             sd, dev = self._sd, self.device
             scale = (sd[pre + "bn1.weight"].double() / torch.sqrt(sd[pre + "bn1.running_var"].double() + 1e-5)).float().to(dev)
             p["stem_s2d"] = ops.stem_s2d_weight(sd[pre + "conv1.weight"].float().to(dev), scale)

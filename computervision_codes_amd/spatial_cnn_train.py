@@ -43,7 +43,7 @@ class SpatialCnnTrainer:
     _refresh_table = None
     def __init__(self, network: str = "resnet50", lr: float = 0.01, weight_decay: float = 1e-5, rates: Sequence[float] = (1.0, 1.0, 1.0),
                  temp: float = 4.0, device: str = "cuda", process_group=None, overlap: bool = True, teacher_dim: int = 1536,
-                 loss_type: str = "all", operand_dtype: torch.dtype = torch.float32):
+                 loss_type: str = "all", operand_dtype: torch.dtype = torch.float32, epilogue_stats: bool = True):
         """loss_type 'all': the distillation recipe (four heads, KD branch, hard + soft + feature losses: `run.py:180-192`);
         'i' | 'v' | 't': a single-task student -- only that classifier exists (`network.py:34-41`) and the loss is its BCE alone
         (`run.py:165-179`)"""
@@ -52,8 +52,8 @@ class SpatialCnnTrainer:
         # bfloat16: the convolutions' GEMM operands (activations, activation gradients, weight copies) are bf16, sums fp32 / fp64, master
         # weights + gradients + SGD fp32 (csrc/train2d_bf16.hip); the stem's 7x7x3 convolution and the heads / KD branch stay fp32
         self.op16 = operand_dtype == torch.bfloat16
-        # BatchNorm statistics from the producing convolution's epilogue (MT4_NO_EPILOGUE_STATS=1: the separate pass over the map)
-        self.epilogue_stats = not os.environ.get("MT4_NO_EPILOGUE_STATS")
+        # BatchNorm statistics from the producing convolution's epilogue (False: the separate pass over the map -- same bits, tested)
+        self.epilogue_stats = bool(epilogue_stats)
         self.loss_type = loss_type
         self.heads = _ALL_HEADS if loss_type == "all" else tuple(h for h in _ALL_HEADS if h[0] == loss_type)
         self.NH = sum(k for _, k in self.heads)

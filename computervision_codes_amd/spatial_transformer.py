@@ -22,6 +22,7 @@ from .shapes import SWIN_BUFFER_SUFFIXES, SWIN_CFG, q2l_param_shapes, swin_windo
 from .synth import IMAGENET_MEAN, IMAGENET_STD
 
 _K = {"i": 6, "v": 10, "t": 15, "ivt": 100}
+MLP_CHAIN = True        # Swin blocks of width 128 / 256: Mlp + shortcut as ONE launch (`ops.chain_gemm`, bit-identical to fc1 -> fc2; tests switch it off)
 
 
 def _window_row_map(res: int, ws: int, shift: int) -> torch.Tensor:
@@ -217,8 +218,7 @@ class Qeruy2Label:
         self._p = p
 
     def _mlp_frag(self, q: str, c: int):
-        import os
-        if self.dtype != torch.bfloat16 or os.environ.get("MT4_NO_MLP_CHAIN") or not ops.chain_gemm_supported(c, 4 * c, c, False):
+        if self.dtype != torch.bfloat16 or not MLP_CHAIN or not ops.chain_gemm_supported(c, 4 * c, c, False):
             return None
         return ops.pack_fragments(self._lin(q + "mlp.fc1.weight", None)[0]), ops.pack_fragments(self._lin(q + "mlp.fc2.weight", None)[0])
 

@@ -226,7 +226,7 @@ def test_bf16_operand_step_vs_reference_fixture(cuda, name):
 
 def test_epilogue_statistics_step_equals_separate_pass(cuda, monkeypatch):
     """the forward of a bf16 step with BatchNorm statistics taken in the convolution epilogue (default) and with the separate statistics pass
-    (MT4_NO_EPILOGUE_STATS=1) agree bit for bit: every unit's activations, the advanced running statistics, the BCE term (the KL / MSE terms are
+    (`epilogue_stats=False`) agree bit for bit: every unit's activations, the advanced running statistics, the BCE term (the KL / MSE terms are
     summed with fp32 atomics and agree to their run-to-run noise)"""
     from computervision_codes_amd.spatial_cnn_train import SpatialCnnTrainer
     from oracle.spatial_cnn_train import damp_residual_gamma
@@ -236,9 +236,8 @@ def test_epilogue_statistics_step_equals_separate_pass(cuda, monkeypatch):
     img, labels, tpred, tfeat = _inputs(cfg)
     res = []
     for off in (False, True):
-        if off:
-            monkeypatch.setenv("MT4_NO_EPILOGUE_STATS", "1")
-        tr = SpatialCnnTrainer(cfg["network"], lr=cfg["lr"], weight_decay=1e-5, rates=cfg["rates"], temp=4.0, operand_dtype=BF).load_state_dict(sd)
+        tr = SpatialCnnTrainer(cfg["network"], lr=cfg["lr"], weight_decay=1e-5, rates=cfg["rates"], temp=4.0, operand_dtype=BF,
+                               epilogue_stats=not off).load_state_dict(sd)
         assert tr.epilogue_stats == (not off)
         terms = tr.train_step(img.to(cuda), labels, tpred, tfeat, apply_update=False)
         res.append((terms, [rec[5].clone() for rec in tr.last_saved], {n: (u.rmean.clone(), u.rvar.clone()) for n, u in tr.units.items()}))
