@@ -76,6 +76,8 @@ SIGNATURES = {
     "mt4_png_inflate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_int64, C.c_int64, _vp, _vp]),
     "mt4_png_unfilter_rgb8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.c_int64, _vp, _vp]),
     "mt4_copy_spans_u8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "mt4_png_stat_files": (C.c_int, [C.POINTER(C.c_char_p), _i32, _vp, _i32]),
+    "mt4_png_read_files": (C.c_int, [C.POINTER(C.c_char_p), _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32]),
     "mt4_resize_pass_u8": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mt4_maxpool3x3s2_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mt4_stem_maxpool_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

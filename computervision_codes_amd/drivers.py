@@ -92,16 +92,19 @@ def _spatial_cnn_videos(F, model, vids, labels):
     {video -> {head -> (labels [N,K], sigmoid scores [N,K])}})"""
     feats_local: Dict[str, np.ndarray] = {}
     scores_local = {}
-    for v in vids:
+    dev_dec = F.png_decode == "device"
+
+    def loader(v):
+        ids_all = labels[v]["ivt"][:, 0]                       # file order, no shuffle, drop_last False (`test.py:227-242`)
+        return lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.image_height, F.image_width,   # decode on the host (or
+                                                       workers=F.decode_workers, decode=F.png_decode)          # device), Resize on the GPU
+    # ONE loader pipeline over all videos (`extract.extract_videos_device`): the first loads of the next video are read and decoded while this
+    # one's last passes run.  The device PNG decoder runs one wave per frame and takes ~75 ms per call however many frames ride along: it is
+    # handed loads of 512 frames, three of them in flight on streams of their own, so that reading one load's files overlaps the inflate of the
+    # loads before it and the extractor's passes.
+    plan = [(v, len(labels[v]["ivt"]), loader(v)) for v in vids]
+    for v, feat, lgs in extract.extract_videos_device(model, plan, F.device_batch, prefetch=3 if dev_dec else 1, load_batch=512 if dev_dec else None):
         lab = labels[v]
-        ids_all = lab["ivt"][:, 0]                             # file order, no shuffle, drop_last False (`test.py:227-242`)
-        load = lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.image_height, F.image_width,   # decode on the
-                                                       workers=F.decode_workers, decode=F.png_decode)          # host (or device), Resize on the GPU
-        # (the device PNG decoder runs one wave per frame and needs >= 1024 frames to fill the chip: it is handed several passes' worth at once,
-        # and two loads run ahead, so that gathering one load's compressed bytes on the host overlaps the inflate of the load before it)
-        dev_dec = F.png_decode == "device"
-        feat, lgs = extract.extract_video_device(model, len(ids_all), load, F.device_batch, prefetch=2 if dev_dec else 1,
-                                                 load_batch=1024 if dev_dec else None)
         scores_local[v] = {key: (lab[key][:, 1:], torch.sigmoid(torch.from_numpy(lg)).numpy())       # `test.py:162-169`
                            for key, lg in zip(("i", "v", "t", "ivt"), lgs)}
         feats_local[featfile.video_key(v)] = np.array(feat)    # (own copy: the pinned staging buffer is released)

@@ -56,39 +56,41 @@ def iter_chunks(spans: Sequence[tuple], load_chunk: Callable[[int, int], torch.T
     """Yield `load_chunk(s, e)` for every span in order.  With `prefetch` = k > 0 the next k spans are read and decoded on helper threads
     while the caller works on this one (the reference's DataLoader workers run ahead of the model the same way, `Spatial_cnn/test.py:240-241`);
     k = 2 lets the host part of one load (file reads, gathering the compressed bytes) overlap the device part of the load before it.
-    The helpers launch on ONE side stream per generator (a loader that ends in a blocking status read -- the device PNG decoder -- then waits
-    for its own kernels only, not for every model pass the caller has queued): the device parts of k loads in flight serialise on it, what
-    overlaps is one load's host part with another's device part.  A chunk is handed over with an event the CALLER'S CURRENT stream waits on
-    (and `record_stream` for that stream): a consumer that fans out over streams of its own (`extract_u8(streams > 1)`) must order them
-    behind the current stream, as `VideoNas.extract_u8` does (`st.wait_stream(main)`)."""
+    Every load in flight launches on a SIDE stream of its own (a loader that ends in a blocking status read -- the device PNG decoder -- then
+    waits for its own kernels only, not for every model pass the caller has queued, and the device parts of the k loads -- upload, inflate,
+    unfilter, resize -- co-run: the inflate is latency-bound per frame, 75 ms per call however many frames ride along).  A chunk is handed over
+    with an event the CALLER'S CURRENT stream waits on (and `record_stream` for that stream): a consumer that fans out over streams of its own
+    (`extract_u8(streams > 1)`) must order them behind the current stream, as `VideoNas.extract_u8` does (`st.wait_stream(main)`).
+    `spans` are argument tuples of `load_chunk`."""
     depth = int(prefetch)
     if depth <= 0 or len(spans) < 2 or not torch.cuda.is_available():
-        for s, e in spans:
-            yield load_chunk(s, e)
+        for sp in spans:
+            yield load_chunk(*sp)
         return
     dev, cur = torch.cuda.current_device(), torch.cuda.current_stream()
-    side = torch.cuda.Stream()
-
-    def ahead(s, e):
-        torch.cuda.set_device(dev)
-        with torch.cuda.stream(side):
-            fr = load_chunk(s, e)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        return fr, ev
     depth = min(depth, len(spans))
+    sides = [torch.cuda.Stream() for _ in range(depth)]      # one per load in flight: their device parts (upload, inflate, resize) co-run
+
+    def ahead(i):
+        torch.cuda.set_device(dev)
+        st = sides[i % depth]
+        with torch.cuda.stream(st):
+            fr = load_chunk(*spans[i])
+            ev = torch.cuda.Event()
+            ev.record(st)
+        return fr, ev
     pool = _POOLS.get((dev, depth))
     if pool is None:
         pool = _POOLS[(dev, depth)] = ThreadPoolExecutor(depth, thread_name_prefix=f"mt4-load-{dev}")
-    pending = [pool.submit(ahead, *spans[i]) for i in range(depth)]
+    pending = [pool.submit(ahead, i) for i in range(depth)]
     try:
         for i in range(len(spans)):
             fr, ev = pending.pop(0).result()
             if i + depth < len(spans):
-                pending.append(pool.submit(ahead, *spans[i + depth]))
+                pending.append(pool.submit(ahead, i + depth))
             cur.wait_event(ev)
             if torch.is_tensor(fr) and fr.is_cuda:
-                fr.record_stream(cur)           # allocated on the side stream, consumed on the caller's
+                fr.record_stream(cur)           # allocated on a side stream, consumed on the caller's
             yield fr
     finally:
         for f in pending:                       # (the consumer stopped early: let the loads in flight finish before their buffers go)
@@ -101,6 +103,46 @@ def iter_chunks(spans: Sequence[tuple], load_chunk: Callable[[int, int], torch.T
                     pass
 
 
+def extract_videos_device(model, videos, device_batch: int = 512, streams: int = 1, prefetch=1, load_batch: int = None):
+    """Several videos through the spatial extractor with ONE loader pipeline across them (`Spatial_cnn/test.py:266-268` loops over the videos;
+    its DataLoader workers start each video cold): `videos` = sequence of (key, n_frames, load_chunk); the spans of all videos form one
+    sequence for `iter_chunks`, so while video k's last passes run the first loads of video k + 1 are already being read and decoded -- the
+    pipeline fills once per run, not once per video.  Yields (key, feat [N,D] float32 ndarray, logits (i, v, t, ivt) float32 ndarrays) per
+    video, in order; features and logits of a video stay on the device until it ends, then cross to the host ONCE through pinned memory."""
+    load_batch = max(device_batch, load_batch or device_batch) // device_batch * device_batch      # whole passes per load
+    spans = [(vi, s, min(n, s + load_batch)) for vi, (_, n, _) in enumerate(videos) for s in range(0, n, load_batch)]
+    last = {vi: e for vi, _, e in spans}
+
+    def finish(feats, logits):
+        if not feats:
+            return np.zeros((0, 0), np.float32), tuple(np.zeros((0, 0), np.float32) for _ in range(4))
+        dev_out = [torch.cat(feats).float()] + [torch.cat(l).float() for l in logits]
+        host = [torch.empty(t.shape, dtype=torch.float32, pin_memory=True) for t in dev_out]
+        for h, d in zip(host, dev_out):
+            h.copy_(d, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return host[0].numpy(), tuple(h.numpy() for h in host[1:])
+    done = 0
+    feats, logits = [], [[], [], [], []]
+    chunks = iter_chunks(spans, lambda vi, s, e: videos[vi][2](s, e), prefetch)
+    for (vi, s, e), span in zip(spans, chunks):
+        while done < vi:                                   # (videos without frames in front of this one)
+            yield (videos[done][0],) + finish([], None)
+            done += 1
+        for p0 in range(0, span.shape[0], device_batch):
+            (_, li), (_, lv), (_, lt), (feat, livt) = model.extract_u8(span[p0:p0 + device_batch], streams=streams)
+            feats.append(feat)
+            for acc, lg in zip(logits, (li, lv, lt, livt)):
+                acc.append(lg)
+        if e == last[vi]:
+            yield (videos[vi][0],) + finish(feats, logits)
+            feats, logits = [], [[], [], [], []]
+            done = vi + 1
+    while done < len(videos):
+        yield (videos[done][0],) + finish([], None)
+        done += 1
+
+
 def extract_video_device(model, n_frames: int, load_chunk: Callable[[int, int], torch.Tensor], device_batch: int = 512, streams: int = 1,
                          prefetch=1, load_batch: int = None):
     """One video through the spatial extractor the MI355X way (`Spatial_cnn/test.py:143-177` restated): frames [s, e) arrive as uint8
@@ -110,23 +152,8 @@ def extract_video_device(model, n_frames: int, load_chunk: Callable[[int, int], 
     (a multiple of `device_batch`): frames per `load_chunk` call when the loader wants more than one pass at a time (the device PNG decoder
     runs one wave per frame and fills the GPU from ~2500 frames on).
     Returns (feat [N,D] float32 ndarray, logits (i, v, t, ivt) float32 ndarrays)."""
-    feats, logits = [], [[], [], [], []]
-    load_batch = max(device_batch, load_batch or device_batch) // device_batch * device_batch      # whole passes per load
-    spans = [(s, min(n_frames, s + load_batch)) for s in range(0, n_frames, load_batch)]
-    for span in iter_chunks(spans, load_chunk, prefetch):
-        for s in range(0, span.shape[0], device_batch):
-            (_, li), (_, lv), (_, lt), (feat, livt) = model.extract_u8(span[s:s + device_batch], streams=streams)
-            feats.append(feat)
-            for acc, lg in zip(logits, (li, lv, lt, livt)):
-                acc.append(lg)
-    if not feats:
-        return np.zeros((0, 0), np.float32), tuple(np.zeros((0, 0), np.float32) for _ in range(4))
-    dev_out = [torch.cat(feats).float()] + [torch.cat(l).float() for l in logits]
-    host = [torch.empty(t.shape, dtype=torch.float32, pin_memory=True) for t in dev_out]
-    for h, d in zip(host, dev_out):
-        h.copy_(d, non_blocking=True)
-    torch.cuda.current_stream().synchronize()
-    return host[0].numpy(), tuple(h.numpy() for h in host[1:])
+    for _, feat, lgs in extract_videos_device(model, [(None, n_frames, load_chunk)], device_batch, streams, prefetch, load_batch):
+        return feat, lgs
 
 
 def gather_feats(local: Mapping[str, np.ndarray], group=None) -> Dict[str, np.ndarray]:

@@ -185,69 +185,77 @@ def _decode_streams(streams, offs, lens, n, h, w, dev, timings=None) -> torch.Te
     return out
 
 
-def decode_files(paths: Sequence[str], device="cuda", timings: dict = None, workers: int = 8) -> torch.Tensor:
-    """PNG files on disk (ONE frame size) -> uint8 [N,H,W,3] on the device, as `decode_batch`, without a host copy of the compressed bytes:
-    the files are read straight into one pinned buffer (`readinto`, `workers` threads), uploaded as they lie on disk, and their IDAT
-    payloads are packed into contiguous zlib streams on the device (`mt4_copy_spans_u8`).  The host only walks the chunk lists."""
+_READ_STATUS = {1: "cannot open / short read", 2: "not a PNG file / truncated chunk", 3: "only 8-bit RGB, non-interlaced", 4: "no IHDR / IDAT",
+                5: "too many IDAT chunks", 6: "bad zlib header"}
+
+
+def read_files(paths: Sequence[str], workers: int = 8):
+    """The host part of `decode_files`, on `workers` NATIVE threads outside the interpreter lock (`mt4_png_stat_files` / `mt4_png_read_files`,
+    csrc/png_host.hip): the files are read into this thread's pinned staging buffer as they lie on disk and their chunk lists walked.
+    -> (blob pinned uint8 [total], w, h, src, dst, ln, offsets, lengths): span i of the upload goes from blob[src[i] .. + ln[i]) to
+    streams[dst[i] ..); zlib stream f = streams[offsets[f] .. + lengths[f]) (2-byte zlib header stripped).  Raises `UnsupportedPng` /
+    `MixedSizes` before anything is launched."""
+    import ctypes as C
     import os
     n = len(paths)
     if n == 0:
         raise UnsupportedPng("empty batch")
-    sizes = np.array([os.path.getsize(p) for p in paths], dtype=np.int64)
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    sizes = np.empty(n, dtype=np.int64)
+    check(lib.mt4_png_stat_files(arr, n, sizes.ctypes.data, workers), "mt4_png_stat_files")
+    if int(sizes.min()) < 0:
+        raise FileNotFoundError(paths[int(np.argmin(sizes))])
     foff = np.zeros(n, dtype=np.int64)
     foff[1:] = np.cumsum((sizes[:-1] + 15) // 16 * 16)
     total = int(foff[-1] + sizes[-1])
     blob = _staging(total)
-    host = blob.numpy()
-    metas: List = [None] * n
-
-    def read_one(i):
-        view = memoryview(host)[int(foff[i]):int(foff[i] + sizes[i])]
-        with open(paths[i], "rb", buffering=0) as fh:
-            got = 0
-            while got < len(view):
-                k = fh.readinto(view[got:])
-                if not k:
-                    raise UnsupportedPng(f"{paths[i]}: short read")
-                got += k
-        m = _idat_spans(view)
-        so, sl = m[2][0]
-        if sl < 2 or (view[so] & 0x0F) != 8 or ((view[so] << 8) | view[so + 1]) % 31 != 0 or (view[so + 1] & 0x20):
-            raise UnsupportedPng("bad zlib header")
-        metas[i] = m
-
-    if workers > 1 and n >= 2 * workers:        # (reads release the GIL)
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=workers) as ex:
-            list(ex.map(read_one, range(n)))
-    else:
-        for i in range(n):
-            read_one(i)
-    w, h = metas[0][0], metas[0][1]
-    if any((m[0], m[1]) != (w, h) for m in metas):
+    max_spans = int(min(4096, int(sizes.max()) // 4096 + 8))          # (libpng's default IDAT size is 8 KB, Pillow's 64 KB)
+    width, height, nspans, status = (np.empty(n, dtype=np.int32) for _ in range(4))
+    span_off = np.empty((n, max_spans), dtype=np.int64)
+    span_len = np.empty((n, max_spans), dtype=np.int32)
+    check(lib.mt4_png_read_files(arr, sizes.ctypes.data, foff.ctypes.data, n, blob.data_ptr(), width.ctypes.data, height.ctypes.data,
+                                 span_off.ctypes.data, span_len.ctypes.data, nspans.ctypes.data, max_spans, status.ctypes.data, workers),
+          "mt4_png_read_files")
+    if int(status.max()) != 0:
+        bad = int(np.flatnonzero(status)[0])
+        raise UnsupportedPng(f"{paths[bad]}: {_READ_STATUS.get(int(status[bad]), status[bad])}")
+    w, h = int(width[0]), int(height[0])
+    if bool((width != w).any()) or bool((height != h).any()):
         raise MixedSizes("frames of different sizes in one batch")
-    lengths = np.array([sum(l for _, l in m[2]) - 2 for m in metas], dtype=np.int32)      # without the 2-byte zlib header
-    if int(lengths.min()) < 4:
+    if not (0 < w <= MAX_WIDTH) or h * (1 + 3 * w) > MAX_RAW_BYTES:
+        raise UnsupportedPng(f"frame {w} x {h}: the device decoder takes widths up to {MAX_WIDTH} and < 2 GiB of scanlines")
+    live = np.arange(max_spans)[None, :] < nspans[:, None]
+    sl = np.where(live, span_len, 0).astype(np.int64)
+    so = span_off + foff[:, None]
+    so[:, 0] += 2                                                       # the zlib header (checked by the reader)
+    sl[:, 0] -= 2
+    lengths64 = sl.sum(axis=1)
+    if int(lengths64.min()) < 4:
         raise UnsupportedPng("empty zlib stream")
+    if int(lengths64.max()) >= MAX_STREAM_BYTES:
+        raise UnsupportedPng("zlib stream of 256 MB or more")
     offsets = np.zeros(n, dtype=np.int64)
-    offsets[1:] = np.cumsum(lengths[:-1].astype(np.int64))
-    src, dst, ln = [], [], []
-    for i, m in enumerate(metas):
-        o, skip = int(offsets[i]), 2
-        for so, sl in m[2]:
-            if skip:
-                so, sl, skip = so + skip, sl - skip, 0
-            if sl:
-                src.append(int(foff[i]) + so); dst.append(o); ln.append(sl)
-            o += sl
+    offsets[1:] = np.cumsum(lengths64[:-1])
+    do = offsets[:, None] + np.cumsum(sl, axis=1) - sl                  # destination of every span inside its stream
+    keep = live & (sl > 0)
+    return blob, w, h, so[keep], do[keep], sl[keep].astype(np.int32), offsets, lengths64.astype(np.int32)
+
+
+def decode_files(paths: Sequence[str], device="cuda", timings: dict = None, workers: int = 8) -> torch.Tensor:
+    """PNG files on disk (ONE frame size) -> uint8 [N,H,W,3] on the device, as `decode_batch`, without a host copy of the compressed bytes:
+    the files are read straight into one pinned buffer (`read_files`: native threads), uploaded as they lie on disk, and their IDAT
+    payloads are packed into contiguous zlib streams on the device (`mt4_copy_spans_u8`).  Everything is enqueued on the CURRENT stream; the
+    call ends with one blocking read of the decoder's status words (so the staging buffer is free again when it returns)."""
+    blob, w, h, src, dst, ln, offsets, lengths = read_files(paths, workers)
+    n = len(paths)
     dev = torch.device(device)
     files_dev = blob.to(dev, non_blocking=True)
-    spans = torch.from_numpy(np.array([src, dst], dtype=np.int64)).to(dev)
-    span_len = torch.from_numpy(np.array(ln, dtype=np.int32)).to(dev)
-    streams = torch.empty(int(offsets[-1] + lengths[-1]) + 1024, dtype=torch.uint8, device=dev)     # (+ 1 KB: the decoder prefetches 512-byte pieces)
+    meta = np.concatenate([src, dst, offsets]).astype(np.int64)        # one upload for the three int64 arrays, one for the two int32 ones
+    meta_dev = torch.from_numpy(meta).to(dev, non_blocking=True)
+    m32_dev = torch.from_numpy(np.concatenate([ln, lengths])).to(dev, non_blocking=True)
+    ns = len(ln)
+    streams = torch.empty(int(offsets[-1]) + int(lengths[-1]) + 1024, dtype=torch.uint8, device=dev)     # (+ 1 KB: the decoder prefetches 512-byte pieces)
     streams[-1024:].zero_()
-    check(lib.mt4_copy_spans_u8(files_dev.data_ptr(), streams.data_ptr(), spans[0].data_ptr(), spans[1].data_ptr(), span_len.data_ptr(), len(ln),
+    check(lib.mt4_copy_spans_u8(files_dev.data_ptr(), streams.data_ptr(), meta_dev[:ns].data_ptr(), meta_dev[ns:2 * ns].data_ptr(), m32_dev[:ns].data_ptr(), ns,
                                 ops._stream()), "mt4_copy_spans_u8")
-    offs = torch.from_numpy(offsets).to(dev)
-    lens = torch.from_numpy(lengths).to(dev)
-    return _decode_streams(streams, offs, lens, n, h, w, dev, timings)
+    return _decode_streams(streams, meta_dev[2 * ns:], m32_dev[ns:], n, h, w, dev, timings)

@@ -215,6 +215,16 @@ int mt4_png_unfilter_rgb8(const uint8_t* raw, uint8_t* out, int32_t B, int32_t H
  * of PNG files uploaded whole into the contiguous streams mt4_png_inflate reads (pngdec.decode_files; the reference's PIL reads the chunks on
  * the host, Spatial_cnn/dataloader.py:257-261). */
 int mt4_copy_spans_u8(const uint8_t* src, uint8_t* dst, const int64_t* src_off, const int64_t* dst_off, const int32_t* len, int32_t n, void* stream);
+/* HOST side of the same path, no device work (csrc/png_host.hip): what the reference's three DataLoader worker processes do around PIL's decoder
+ * (open / read / chunk walk, Spatial_cnn/dataloader.py:257-261, Spatial_cnn/test.py:240-241) on `threads` native threads, outside the interpreter
+ * lock.  mt4_png_stat_files: sizes[i] = bytes of paths[i] (-1: cannot stat).  mt4_png_read_files: file i is read to dst + file_off[i] (sizes[i]
+ * bytes; dst is normally page-locked staging memory that is then uploaded whole) and its chunk list walked: status[i] = 0 ok, 1 cannot open /
+ * short read, 2 not a PNG / truncated chunk, 3 not 8-bit RGB non-interlaced, 4 no IHDR / IDAT, 5 more than max_spans IDAT chunks, 6 bad zlib
+ * header; width / height [n]; nspans[i] and span_off / span_len [n][max_spans] = offset INSIDE the file and length of every non-empty IDAT payload
+ * (the 2-byte zlib header is still part of the first one).  Both return MT4_OK when the call ran (per-file results in sizes / status). */
+int mt4_png_stat_files(const char* const* paths, int32_t n, int64_t* sizes, int32_t threads);
+int mt4_png_read_files(const char* const* paths, const int64_t* sizes, const int64_t* file_off, int32_t n, uint8_t* dst, int32_t* width,
+                       int32_t* height, int64_t* span_off, int32_t* span_len, int32_t* nspans, int32_t max_spans, int32_t* status, int32_t threads);
 
 /* One separable pass of Pillow's 8-bit resize (`Image.resize(size, BILINEAR)` = `transforms.Resize((256,448))`,
  * Spatial_cnn/dataloader.py:155-159, Spatial_transformer likewise): out = clip8((2^21 + sum_i in[lo+i] * coeffs[o][i]) >> 22).

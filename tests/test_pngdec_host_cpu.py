@@ -72,3 +72,44 @@ def test_sizes_beyond_the_kernels_limits_and_malformed_headers_are_unsupported_n
         pngdec.decode_batch([], "cpu")
     with pytest.raises(pngdec.UnsupportedPng):
         pngdec.decode_files([], "cpu")
+
+
+def test_native_reader_matches_the_python_chunk_walk(tmp_path, monkeypatch):
+    """`pngdec.read_files` (`mt4_png_stat_files` / `mt4_png_read_files`: native threads, no interpreter lock) against `parse_png`: the spans it reports
+    reassemble every file's zlib stream byte for byte (multi-IDAT files included); unsupported / broken / missing files are refused per file"""
+    import os
+    import torch
+    from PIL import Image
+    from computervision_codes_amd import pngdec
+    monkeypatch.setattr(pngdec, "_staging", lambda nbytes: torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8)[:nbytes])   # (no page-locking without a GPU)
+    rng = np.random.default_rng(0)
+    paths = []
+    for i in range(37):
+        p = str(tmp_path / f"{i:06d}.png")
+        Image.fromarray(rng.integers(0, 255, (130, 171, 3), dtype=np.uint8)).save(p, optimize=bool(i % 2))      # 66 KB raw: two or more IDAT chunks
+        paths.append(p)
+    for workers in (1, 5):
+        blob, w, h, src, dst, ln, offs, lens = pngdec.read_files(paths, workers)
+        assert (w, h) == (171, 130) and len(ln) >= 2 * len(paths) and offs[0] == 0
+        host = blob.numpy()
+        for i, p in enumerate(paths):
+            _, _, z = pngdec.parse_png(open(p, "rb").read())
+            out = np.zeros(int(lens[i]), np.uint8)
+            sel = (dst >= offs[i]) & (dst < offs[i] + lens[i])
+            for s_, d_, l_ in zip(src[sel], dst[sel], ln[sel]):
+                out[d_ - offs[i]:d_ - offs[i] + l_] = host[s_:s_ + l_]
+            assert out.tobytes() == z, i
+    grey = str(tmp_path / "grey.png")
+    Image.fromarray(rng.integers(0, 255, (130, 171), dtype=np.uint8)).save(grey)
+    with pytest.raises(pngdec.UnsupportedPng, match="8-bit RGB"):
+        pngdec.read_files(paths[:3] + [grey], 2)
+    small = str(tmp_path / "small.png")
+    Image.fromarray(rng.integers(0, 255, (20, 30, 3), dtype=np.uint8)).save(small)
+    with pytest.raises(pngdec.MixedSizes):
+        pngdec.read_files(paths[:3] + [small], 2)
+    with open(paths[1], "r+b") as f:
+        f.truncate(os.path.getsize(paths[1]) - 40)
+    with pytest.raises(pngdec.UnsupportedPng, match="truncated"):
+        pngdec.read_files(paths[:4], 2)
+    with pytest.raises(FileNotFoundError):
+        pngdec.read_files([str(tmp_path / "missing.png")], 1)
