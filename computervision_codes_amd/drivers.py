@@ -99,11 +99,11 @@ def _spatial_cnn_videos(F, model, vids, labels):
         return lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.image_height, F.image_width,   # decode on the host (or
                                                        workers=F.decode_workers, decode=F.png_decode)          # device), Resize on the GPU
     # ONE loader pipeline over all videos (`extract.extract_videos_device`): the first loads of the next video are read and decoded while this
-    # one's last passes run.  The device PNG decoder runs one wave per frame and takes ~75 ms per call however many frames ride along: it is
-    # handed loads of 512 frames, three of them in flight on streams of their own, so that reading one load's files overlaps the inflate of the
-    # loads before it and the extractor's passes.
+    # one's last passes run.  The device PNG decoder runs one wave per frame and takes 75-105 ms per call for 512-2048 frames: it is handed loads
+    # of 1024 frames, two in flight on streams of their own (sweep: profiles/r04_png_pipeline_sweep.txt -- 9.7-10.2 k frames/s from 480 x 854 files
+    # through ResNet-50; the host reader alone delivers > 100 k files/s, what bounds the loop is inflate time + extractor time, which share the CUs).
     plan = [(v, len(labels[v]["ivt"]), loader(v)) for v in vids]
-    for v, feat, lgs in extract.extract_videos_device(model, plan, F.device_batch, prefetch=3 if dev_dec else 1, load_batch=512 if dev_dec else None):
+    for v, feat, lgs in extract.extract_videos_device(model, plan, F.device_batch, prefetch=2 if dev_dec else 1, load_batch=1024 if dev_dec else None):
         lab = labels[v]
         scores_local[v] = {key: (lab[key][:, 1:], torch.sigmoid(torch.from_numpy(lg)).numpy())       # `test.py:162-169`
                            for key, lg in zip(("i", "v", "t", "ivt"), lgs)}

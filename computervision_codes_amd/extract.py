@@ -41,6 +41,9 @@ _POOLS: Dict[tuple, ThreadPoolExecutor] = {}        # helper threads by (device,
                                                      # staging buffer (`pngdec._staging`, >= 64 MB per thread) is page-locked once, not once per video
 
 
+_SIDE_STREAMS: Dict[tuple, list] = {}
+
+
 def _shutdown_pools():
     for pool in _POOLS.values():
         pool.shutdown(wait=False, cancel_futures=True)
@@ -69,7 +72,11 @@ def iter_chunks(spans: Sequence[tuple], load_chunk: Callable[[int, int], torch.T
         return
     dev, cur = torch.cuda.current_device(), torch.cuda.current_stream()
     depth = min(depth, len(spans))
-    sides = [torch.cuda.Stream() for _ in range(depth)]      # one per load in flight: their device parts (upload, inflate, resize) co-run
+    # one side stream per load in flight: their device parts (upload, inflate, resize) co-run.  Kept for the life of the process like the helper
+    # threads: torch's caching allocator pools memory per stream, so fresh streams per call meant a hipMalloc for every buffer of every load
+    sides = _SIDE_STREAMS.get((dev, depth))
+    if sides is None:
+        sides = _SIDE_STREAMS[(dev, depth)] = [torch.cuda.Stream() for _ in range(depth)]
 
     def ahead(i):
         torch.cuda.set_device(dev)

@@ -65,15 +65,17 @@ def main():
         ids = np.arange(n)
         ref = None
         print("load_batch  in_flight  workers   frames/s (3 videos, one pipeline)   frames/s (ONE video)   same features")
-        for lb, depth, workers in ((1024, 2, 16), (1024, 3, 16), (512, 3, 16), (512, 4, 16), (512, 6, 16), (256, 6, 16), (256, 8, 16), (512, 4, 8), (512, 4, 32)):
+        for lb, depth, workers in ((1024, 2, 16), (1024, 3, 16), (512, 3, 16), (512, 4, 16), (256, 6, 16), (512, 4, 32)):
             mk = lambda v: (lambda s, e: cholect.load_frames_device(root, v, ids[s:e], 256, 448, device=dev, workers=workers, decode="device"))
             plan = [(v, n, mk(v)) for v in vids]
             run = lambda pl: list(extract.extract_videos_device(m, pl, 512, prefetch=depth, load_batch=lb))
-            run(plan[:1])
+            run(plan[:2])                                   # (warm: helper threads, their pinned staging, the side streams' allocator pools)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            out = run(plan)
-            dt = time.perf_counter() - t0
+            dt = 1e9
+            for _ in range(2):
+                t0 = time.perf_counter()
+                out = run(plan)
+                dt = min(dt, time.perf_counter() - t0)
             t0 = time.perf_counter()
             one = run(plan[:1])
             dt1 = time.perf_counter() - t0
