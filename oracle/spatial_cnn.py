@@ -51,10 +51,61 @@ def resnet_trunk(sd: SD, x: torch.Tensor, arch: str = "resnet50", prefix: str = 
     return F.adaptive_avg_pool2d(x, (1, 1))
 
 
-def spatial_cnn_forward(sd: SD, img: torch.Tensor, network: str = "resnet50", loss_type: str = "all"):
+def _r16(t: torch.Tensor) -> torch.Tensor:
+    """round to bfloat16 and back (round-to-nearest-even: what `v_cvt_pk_bf16_f32` does)"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def resnet_trunk_bf16_emulation(sd: SD, x: torch.Tensor, arch: str = "resnet50", prefix: str = "", fuse_downsample: bool = True) -> torch.Tensor:
+    """The SAME graph with the roundings of the bf16 throughput mode of the MI355X path put where its kernels put them (and nowhere else), all
+    arithmetic in fp32: the normalised frame is rounded to bf16; every convolution's weights are the eval-mode BatchNorm scale folded in fp32 and
+    THEN rounded to bf16, its bias (beta - mu * scale) stays fp32; a unit's output -- conv + bias [+ residual], ReLU -- is rounded to bf16 once,
+    when it is stored; in the strided Bottlenecks conv3 and the downsample branch are ONE fp32 sum (`fuse_downsample`, the mode's default), so the
+    branch is not rounded on its own; max-pool on bf16 values is exact; the pooled feature and the heads are fp32.  What is left between this and
+    the kernels is the fp32 summation order inside a convolution (and the rare bf16 rounding tie it flips), so the bf16 mode can be held to ~1e-2
+    of the logit range against it instead of the 5e-2 it needs against the fp32 reference -- tight enough to see a wrong tap or a missing
+    rounding.  Test infrastructure only."""
+    def fold(conv: str, bn: str):
+        g, b = sd[bn + ".weight"].double(), sd[bn + ".bias"].double()
+        mu, var = sd[bn + ".running_mean"].double(), sd[bn + ".running_var"].double()
+        scale = g / torch.sqrt(var + 1e-5)
+        w = _r16(sd[conv + ".weight"].float() * scale.float()[:, None, None, None])
+        return w, (b - mu * scale).float()
+
+    def unit(xx, conv, bn, stride=1, padding=0, relu=True, add=None, store=True):
+        w, b = fold(conv, bn)
+        y = F.conv2d(xx, w, stride=stride, padding=padding) + b[None, :, None, None]
+        if add is not None:
+            y = y + add
+        if relu:
+            y = F.relu(y)
+        return _r16(y) if store else y
+    x = unit(_r16(x), prefix + "conv1", prefix + "bn1", stride=2, padding=3)
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    for li, n in enumerate(_DEPTHS[arch], start=1):
+        for bi in range(n):
+            s = 2 if (bi == 0 and li > 1) else 1
+            q = f"{prefix}layer{li}.{bi}."
+            has_ds = (q + "downsample.0.weight") in sd
+            if arch == "resnet50":
+                o = unit(x, q + "conv1", q + "bn1")
+                o = unit(o, q + "conv2", q + "bn2", stride=s, padding=1)
+                if has_ds and fuse_downsample and li > 1:      # one accumulator chain over K = planes + Cin (layer1.0's branch is rounded: fused kernel)
+                    idt = unit(x, q + "downsample.0", q + "downsample.1", stride=s, relu=False, store=False)
+                else:
+                    idt = unit(x, q + "downsample.0", q + "downsample.1", stride=s, relu=False) if has_ds else x
+                x = unit(o, q + "conv3", q + "bn3", add=idt)
+            else:
+                idt = unit(x, q + "downsample.0", q + "downsample.1", stride=s, relu=False) if has_ds else x
+                o = unit(x, q + "conv1", q + "bn1", stride=s, padding=1)
+                x = unit(o, q + "conv2", q + "bn2", padding=1, add=idt)
+    return F.adaptive_avg_pool2d(x, (1, 1))
+
+
+def spatial_cnn_forward(sd: SD, img: torch.Tensor, network: str = "resnet50", loss_type: str = "all", emulate_bf16: bool = False):
     """`VideoNas.forward` (`Spatial_cnn/network.py:45-92`) in eval (`args.train` False): the KD branch is
-    skipped and its three slots are the integer 0."""
-    high = resnet_trunk(sd, img, network, prefix="basemodel.basemodel.")
+    skipped and its three slots are the integer 0.  `emulate_bf16`: the trunk with the bf16 mode's roundings (`resnet_trunk_bf16_emulation`)."""
+    high = (resnet_trunk_bf16_emulation if emulate_bf16 else resnet_trunk)(sd, img, network, prefix="basemodel.basemodel.")
     feat = high.squeeze(-1).squeeze(-1)
     b = feat.shape[0]
     flat = torch.flatten(high, 1)

@@ -164,6 +164,32 @@ def test_spatial_cnn_bf16_mode(cuda, name):
     assert _maxerr(feat, z["feat"]) < 5e-2 * float(np.abs(z["feat"]).max())
 
 
+@pytest.mark.parametrize("name", ["cnn_resnet50_small", "cnn_resnet50_224", "cnn_resnet18_224", "cnn_resnet50_256x448"])
+def test_spatial_cnn_bf16_mode_vs_rounding_emulating_oracle(cuda, name):
+    """The bf16 throughput mode against an oracle run that rounds to bf16 exactly where the kernels do (`oracle.spatial_cnn.
+    resnet_trunk_bf16_emulation`: folded weights, the normalised frame, every stored activation; conv3 + downsample of the strided Bottlenecks as
+    one fp32 sum) and is fp32 otherwise.  What remains is the summation order inside a convolution and the bf16 rounding ties it flips: DECLARED
+    3e-3 of the logit / feature range (measured 3e-4 - 1.5e-3, profiles/r04_bf16_emulation_probe.txt) -- 15 x tighter than the 5e-2 the mode is
+    given against the fp32 reference, and well inside the 5e-3 - 1e-2 by which the emulation itself differs from fp32: a wrong tap, a missing
+    rounding or a branch rounded where the kernels keep fp32 shows up here.  The emulation explains the mode's deviation from the reference:
+    hip-vs-emulation is less than half of hip-vs-fp32 on every output."""
+    from oracle import spatial_cnn as o_cnn
+    z, cfg = load_golden(name)
+    m = _cnn_model(cfg, torch.bfloat16)
+    frames = synth.synthetic_frames(cfg["B"], cfg["H"], cfg["W"], seed=cfg["seed"])
+    sd = synth.fill_from_shapes(shapes.spatial_cnn_shapes(cfg["network"]), seed=cfg["seed"])
+    with torch.no_grad():
+        emu = o_cnn.spatial_cnn_forward(sd, synth.normalize_frames(frames), cfg["network"], emulate_bf16=True)
+    out = m.extract_u8(frames.to(cuda))
+    for got, want, key in ((out[0][1], emu[0][1], "logit_i"), (out[1][1], emu[1][1], "logit_v"), (out[2][1], emu[2][1], "logit_t"),
+                           (out[3][1], emu[3][1], "logit_ivt"), (out[3][0], emu[3][0], "feat")):
+        rng = float(np.abs(z[key]).max())
+        d_emu = (got.float().cpu() - want).abs().max().item()
+        d_ref = _maxerr(got, z[key])
+        assert d_emu <= 3e-3 * rng, (key, d_emu / rng)
+        assert d_emu < 0.5 * d_ref, (key, d_emu / rng, d_ref / rng)
+
+
 def _agreement(a, ref):
     a, ref = a.float().cpu(), torch.as_tensor(np.asarray(ref)).float()
     k = min(5, a.shape[1])
