@@ -19,7 +19,7 @@ for r in csv.DictReader(open(f)):
     name = r["Kernel_Name"]
     for s in subs:
         if s in name:
-            short = name.split("(")[0][-70:]
+            short = name.replace("(anonymous namespace)::", "").split("(")[0][-70:]
             acc[short][r["Counter_Name"]] += float(r["Counter_Value"])
             seen[short].add(r["Dispatch_Id"])
 print(f"# {f}")
