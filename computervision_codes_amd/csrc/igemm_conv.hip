@@ -1838,6 +1838,13 @@ extern "C" int mt4_conv_nhwc(const mt4_conv_desc* d, void* stream) {
         // (tools/tcn_long_sweep.py): fp32 2.35 ms (32 x 32, 4-stage ring) -> 2.13 (two groups) -> 2.04 (four groups, tile 40);
         // bf16 1.00 -> 0.83 (tile 40) -> 0.74 (two groups with 3-stage rings, tile 41).  At T = 1000 (128 such tiles: half the chip) the
         // small tiles stay, bf16 on the 4-stage 32 x 64 ring (0.74 -> 0.69 ms)
+        // several short videos per forward (the temporal head's throughput mode: 8192 rows x 512 channels at 32 videos): 128 x 128 tiles are a
+        // single round of 256 four-wave workgroups; 64 x 128 gives two per CU -- 36.1 -> 30.4 us (dilated conv), 24.4 -> 21.0 (1 x 1) in bf16,
+        // 135 -> 123 / 56.5 -> 51.8 in fp32 (profiles/r04_tcn_batched_tile_sweep.txt).  Latency callers only: the spatial paths keep their tuned table.
+        if (latency && tile == 1) {
+            const long long t128 = (long long)cdiv(k.M, 128) * cdiv(k.Cout, 128), t64 = (long long)cdiv(k.M, 64) * cdiv(k.Cout, 128);
+            if (t128 < 512 && t64 >= 256) tile = 4;
+        }
         if (latency && fast && k.nsteps >= 8 && (tile == 5 || tile == 6 || tile == 10 || tile == 11 || tile == 3 || tile == 9)) {
             const long long t64 = (long long)cdiv(k.M, 64) * cdiv(k.Cout, 64);
             if (t64 >= 192 && t64 <= 512) tile = d->dtype == MT4_F32 ? 40 : 41;
