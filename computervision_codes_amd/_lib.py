@@ -111,6 +111,8 @@ SIGNATURES = {
     "mt4_bn_stats_t": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, C.c_float, C.c_float, _vp]),
     "mt4_avgpool1d_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mt4_interp_linear_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_avgpool1d_rows_bwd_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_interp_linear_rows_bwd_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mt4_bn_apply_sums_f32": (C.c_int, [_vp] * 10 + [C.c_int64, _i32, C.c_float, C.c_float, _i32, _vp]),
     "mt4_bn_apply_sums_t": (C.c_int, [_vp, _i32] + [_vp] * 9 + [C.c_int64, _i32, C.c_float, C.c_float, _i32, _vp]),
     "mt4_bn_apply_t": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _vp]),

@@ -411,7 +411,77 @@ __global__ void interp_linear_rows_kernel(const T* __restrict__ x, T* __restrict
     const float4 a = ldrow4<T>(x + (b * Tin + i0) * C + c), v = ldrow4<T>(x + (b * Tin + i1) * C + c);
     strow4<T>(y + r * C + c, make_float4(l0 * a.x + l1 * v.x, l0 * a.y + l1 * v.y, l0 * a.z + l1 * v.z, l0 * a.w + l1 * v.w));
 }
+// adjoints of the two (fp32: the TCN trainer's dtype), both as deterministic gathers over the OUTPUT rows that touch an input row
+__global__ void avgpool1d_rows_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Tin, int Tout, int C, int k, int stride, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = C >> 2;
+    const int c = (int)(i % c4) * 4;
+    const long long r = i / c4;
+    const int t = (int)(r % Tin);
+    const long long b = r / Tin;
+    int w0 = t - (k - 1);
+    w0 = w0 <= 0 ? 0 : (w0 + stride - 1) / stride;          // first window that reaches t
+    int w1 = t / stride;                                    // last window that starts at or before t
+    if (w1 > Tout - 1) w1 = Tout - 1;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = w0; w <= w1; ++w) {
+        const float4 v = *(const float4*)(dy + (b * Tout + w) * C + c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float d = (float)k;
+    *(float4*)(dx + r * C + c) = make_float4(s.x / d, s.y / d, s.z / d, s.w / d);
+}
+
+__global__ void interp_linear_rows_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Tin, int Tout, int C, float scale, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = C >> 2;
+    const int c = (int)(i % c4) * 4;
+    const long long r = i / c4;
+    const int t = (int)(r % Tin);
+    const long long b = r / Tin;
+    // output rows w whose source index max(0, scale (w + 0.5) - 0.5) lies in [t - 1, t + 1): a bracket a row wide on either side, then the
+    // forward's own arithmetic decides
+    int lo = (int)floorf(((float)t - 0.5f) / scale - 0.5f) - 1, hi = (int)ceilf(((float)t + 1.5f) / scale - 0.5f) + 1;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > Tout - 1 ? Tout - 1 : hi;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = lo; w <= hi; ++w) {
+        float src = scale * ((float)w + 0.5f) - 0.5f;
+        src = src < 0.f ? 0.f : src;
+        const int i0 = (int)src;
+        const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+        const float l1 = src - (float)i0, l0 = 1.f - l1;
+        const float wt = (i0 == t ? l0 : 0.f) + (i1 == t ? l1 : 0.f);
+        if (wt != 0.f) {
+            const float4 v = *(const float4*)(dy + (b * Tout + w) * C + c);
+            s.x += wt * v.x; s.y += wt * v.y; s.z += wt * v.z; s.w += wt * v.w;
+        }
+    }
+    *(float4*)(dx + r * C + c) = s;
+}
 }  // namespace
+
+extern "C" int mt4_avgpool1d_rows_bwd_f32(const float* dy, float* dx, int32_t B, int32_t Tin, int32_t C, int32_t k, int32_t stride, void* stream) {
+    mt4_clear_error();
+    if (!dy || !dx || B <= 0 || Tin <= 0 || C <= 0 || k <= 0 || stride <= 0 || Tin < k) return MT4_EINVAL;
+    if ((C & 3) || (((uintptr_t)dy | (uintptr_t)dx) & 15)) return MT4_EALIGN;
+    const int Tout = (Tin - k) / stride + 1;
+    const long long n4 = (long long)B * Tin * (C >> 2);
+    hipLaunchKernelGGL(avgpool1d_rows_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, Tin, Tout, C, k, stride, n4);
+    return mt4_check_launch();
+}
+
+extern "C" int mt4_interp_linear_rows_bwd_f32(const float* dy, float* dx, int32_t B, int32_t Tin, int32_t Tout, int32_t C, void* stream) {
+    mt4_clear_error();
+    if (!dy || !dx || B <= 0 || Tin <= 0 || Tout <= 0 || C <= 0) return MT4_EINVAL;
+    if ((C & 3) || (((uintptr_t)dy | (uintptr_t)dx) & 15)) return MT4_EALIGN;
+    const long long n4 = (long long)B * Tin * (C >> 2);
+    hipLaunchKernelGGL(interp_linear_rows_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, Tin, Tout, C,
+                       (float)Tin / (float)Tout, n4);
+    return mt4_check_launch();
+}
 
 extern "C" int mt4_avgpool1d_rows(const void* x, void* y, int32_t B, int32_t Tin, int32_t C, int32_t k, int32_t stride, int32_t dtype, void* stream) {
     mt4_clear_error();

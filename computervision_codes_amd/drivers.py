@@ -394,15 +394,13 @@ def _tenco_train(F):
     modelname = f"{F.model}_l8_cholect{F.dataset_variant}_k{F.kfold}_batchnorm_lowres"
     model_dir = f"./__checkpoint__/run_{F.version}"
     logfile = os.path.join(model_dir, modelname + ".log")
-    if getattr(F, "hier", False):
-        raise NotImplementedError("--hier True (pooled refinement levels, Temporal_tenco/network.py:154-155) is built for inference (temporal_tenco.VideoNas); "
-                                  "the HIP training step covers the shipped recipe (Scripts/train_fold1.sh: no --hier)")
     if not F.fpn:
         # the reference's own train loop cannot run a model without --fpn: `out_list_i / _v / _t` stay empty (`network.py:56-66`), so `loss_i`,
         # `loss_v`, `loss_t` stay the int 0 they start as (`run.py:190`) and `loss_i.item()` raises AttributeError at `run.py:214` in the first step
         raise NotImplementedError("Temporal_tenco training needs --fpn (Scripts/train_fold1.sh:28): without it the reference's train loop itself fails "
                                   "in its first step (run.py:190,214: .item() on the int 0 that loss_i stays when the model returns no per-component logits)")
-    tr = TencoTrainer(F.num_layers_PG, F.num_layers_R, F.num_R, 512, F.input_dim, lr=F.initial_learning_rates[2], weight_decay=F.weight_decay)
+    tr = TencoTrainer(F.num_layers_PG, F.num_layers_R, F.num_R, 512, F.input_dim, lr=F.initial_learning_rates[2], weight_decay=F.weight_decay,
+                      hier=bool(getattr(F, "hier", False)))      # --hier True: pooled refinement levels (`network.py:147,154-155`, `run.py:159-179`)
     from . import shapes, synth
     init = os.path.join(model_dir, modelname + "_latest.pth")
     if os.path.exists(init):

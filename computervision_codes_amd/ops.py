@@ -880,6 +880,26 @@ def avgpool1d_rows(x: torch.Tensor, k: int = 7, stride: int = 3) -> torch.Tensor
     return y
 
 
+def avgpool1d_rows_bwd(dy: torch.Tensor, t_in: int, k: int = 7, stride: int = 3) -> torch.Tensor:
+    """adjoint of `avgpool1d_rows`: dy [B, (t_in - k) // stride + 1, C] fp32 -> dx [B, t_in, C]"""
+    _need_cuda(dy)
+    assert dy.dim() == 3 and dy.is_contiguous() and dy.dtype == torch.float32 and dy.shape[1] == (t_in - k) // stride + 1
+    b, _, c = dy.shape
+    dx = torch.empty((b, t_in, c), dtype=torch.float32, device=dy.device)
+    check(lib.mt4_avgpool1d_rows_bwd_f32(dy.data_ptr(), dx.data_ptr(), b, t_in, c, k, stride, _stream()), "mt4_avgpool1d_rows_bwd_f32")
+    return dx
+
+
+def interp_linear_rows_bwd(dy: torch.Tensor, t_in: int) -> torch.Tensor:
+    """adjoint of `interp_linear_rows(x [B, t_in, C], t_out)`: dy [B, t_out, C] fp32 -> dx [B, t_in, C]"""
+    _need_cuda(dy)
+    assert dy.dim() == 3 and dy.is_contiguous() and dy.dtype == torch.float32
+    b, t_out, c = dy.shape
+    dx = torch.empty((b, t_in, c), dtype=torch.float32, device=dy.device)
+    check(lib.mt4_interp_linear_rows_bwd_f32(dy.data_ptr(), dx.data_ptr(), b, t_in, t_out, c, _stream()), "mt4_interp_linear_rows_bwd_f32")
+    return dx
+
+
 def interp_linear_rows(x: torch.Tensor, t_out: int) -> torch.Tensor:
     """F.interpolate(x, size=t_out, mode='linear') over the time axis of frame-major rows x [B, T, C] (`Temporal_tenco/network.py:96`)"""
     _need_cuda(x)

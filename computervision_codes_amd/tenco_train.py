@@ -33,7 +33,10 @@ class _Conv:
 
 class TencoTrainer:
     def __init__(self, num_layers_PG=11, num_layers_R=10, num_R=3, num_f_maps=512, dim=512, num_classes=100, lr=0.1, weight_decay=1e-5,
-                 device: str = "cuda", process_group=None, overlap: bool = True):
+                 device: str = "cuda", process_group=None, overlap: bool = True, hier: bool = False):
+        # hier = `args.hier` (`network.py:147,154-155`): AvgPool1d(7, 3) behind every refinement stage, so level l has its own length T_l, the FPN
+        # resamples (`:96`) and `fusion` scores every level against the labels resized to it (`run.py:159-179,196-212`)
+        self.hier = bool(hier)
         self.overlap = overlap            # DDP: all-reduce a stage's gradients as soon as its backward has written them (eager steps)
         self._pending: list = []
         self._capturing = False
@@ -47,6 +50,7 @@ class TencoTrainer:
         self.convs: Dict[str, _Conv] = {}
         self._graphs: Dict[int, object] = {}
         self._scales: Dict[int, torch.Tensor] = {}
+        self._label_idx: Dict[tuple, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ parameters
     def _stages(self):
@@ -135,18 +139,32 @@ class TencoTrainer:
                 out[name + ".weight"], out[name + ".bias"] = g, gb
         return out
 
+    def level_lengths(self, t: int) -> List[int]:
+        """frames of the four FPN levels for a video of t frames: all t, or t -> (t - 7) // 3 + 1 per refinement stage with --hier"""
+        out = [t]
+        for _ in range(self.R):
+            if self.hier:
+                if t < 7:
+                    raise ValueError(f"--hier: a level of {t} < 7 frames cannot be pooled (AvgPool1d(7, 3))")
+                t = (t - 7) // 3 + 1
+            out.append(t)
+        return out
+
     # ------------------------------------------------------------------ randomness
     def draw_masks(self, t: int, generator: Optional[torch.Generator] = None) -> dict:
-        """the train-time random pieces as reference-shaped tensors ([1,D,T] / [1,D,1] / {prefix: [1,C,T]})"""
+        """the train-time random pieces as reference-shaped tensors ([1,D,T] / [1,D,1] / {prefix: [1,C,T_stage]}: a refinement stage runs at the
+        length of the level it reads)"""
         g = generator
         n = self.D * t
         perm = torch.randperm(n, generator=g)
         flat = torch.cat((torch.zeros(n - int(n * 0.75)), torch.ones(int(n * 0.75))))[perm]   # `network.py:44-47`
         masks = {"input_mask": flat.view(1, self.D, t), "channel_mask": (torch.rand(1, self.D, 1, generator=g) >= 0.5).float() * 2.0,
                  "layer_masks": {}}
-        for prefix, nl in self._stages():
+        lens = self.level_lengths(t)
+        for si, (prefix, nl) in enumerate(self._stages()):
+            ts = lens[max(si - 1, 0)]
             for i in range(nl):
-                masks["layer_masks"][f"{prefix}.layers.{i}"] = (torch.rand(1, self.C, t, generator=g) >= 0.5).float() * 2.0
+                masks["layer_masks"][f"{prefix}.layers.{i}"] = (torch.rand(1, self.C, ts, generator=g) >= 0.5).float() * 2.0
         return masks
 
     # ------------------------------------------------------------------ one step
@@ -195,10 +213,11 @@ class TencoTrainer:
                 col_loss = g(x, z)
         else:
             col_loss = self._fwd_bwd(x, z, masks)
-        cl = col_loss.cpu()
+        cl = col_loss.cpu()                                  # [levels, 131]: BCE sums per level and column
+        lens = self.level_lengths(T)
         terms, o = {}, 0
         for s, k, _ in HEADS:
-            terms[s] = float(cl[o:o + k].sum() / (T * k))
+            terms[s] = float(sum(cl[l, o:o + k].sum() / (lens[l] * k) for l in range(len(lens))))   # BCEWithLogitsLoss(mean) per level (`run.py:196-210`)
             o += k
         loss = sum(w * terms[s] for s, _, w in HEADS)
         if apply_update:
@@ -222,13 +241,15 @@ class TencoTrainer:
             h0 = ops.mul_add(h0, to_rows(masks["input_mask"]).view_as(h0))
         if masks and masks.get("channel_mask") is not None:
             h0 = ops.mul_add(h0, masks["channel_mask"][0].transpose(0, 1).expand(T, self.D).contiguous().to(dev).view_as(h0))
-        lm = {k: to_rows(v).view(1, 1, T, C) for k, v in ((masks or {}).get("layer_masks") or {}).items()}
+        lm = {k: to_rows(v).view(1, 1, v.shape[-1], C) for k, v in ((masks or {}).get("layer_masks") or {}).items()}
 
         # ---- forward, saving layer inputs z and ReLU outputs u
+        lens = self.level_lengths(T)                       # frames per FPN level (all T without --hier)
         saved: List[tuple] = []
         f = self._conv(h0, cv["PG.conv_1x1"])
         stage_out = []
-        for prefix, n in self._stages():
+        for si, (prefix, n) in enumerate(self._stages()):
+            ts = lens[max(si - 1, 0)]                      # a refinement stage runs at the length of the level it reads
             for i in range(n):
                 p = f"{prefix}.layers.{i}"
                 d = 2 ** i
@@ -238,55 +259,65 @@ class TencoTrainer:
                     fn = ops.mul_add(o, lm[p], f)
                 else:
                     fn = self._conv(u, cv[p + ".conv_1x1"], residual=f)
-                saved.append((p, d, f, u))
+                saved.append((p, d, f, u, ts))
                 f = fn
+            if self.hier and si > 0:                       # `Refinement.forward` (:154-155): the stage's feature is the pooled map
+                f = ops.avgpool1d_rows(f.view(1, ts, C), 7, 3).view(1, 1, lens[si], C)
             stage_out.append(f)
         c1, c2, c3, p4 = stage_out
         lat = cv["fpn.latlayer1"]
-        p3 = self._conv(c3, lat, residual=p4)
-        p2 = self._conv(c2, lat, residual=p3)
-        p1 = self._conv(c1, lat, residual=p2)
+        # `FPN._upsample_add` (:93-96): linear interpolation to the lateral's length (the identity at equal lengths) + lateral
+        up = (lambda xx, li: ops.interp_linear_rows(xx.view(1, lens[li + 1], C), lens[li]).view(1, 1, lens[li], C)) if self.hier else (lambda xx, li: xx)
+        p3 = self._conv(c3, lat, residual=up(p4, 2))
+        p2 = self._conv(c2, lat, residual=up(p3, 1))
+        p1 = self._conv(c1, lat, residual=up(p2, 0))
         levels = [p1, p2, p3, p4]
         hd = cv["heads"]
-        logits = [self._conv(l, hd) for l in levels]                          # [1,1,T,132], column 131 is padding (= 0)
+        logits = [self._conv(l, hd) for l in levels]                          # [1,1,T_l,132], column 131 is padding (= 0)
 
         # ---- loss + dL/dlogits
         # every weight / bias gradient below ADDS into the flat buffer, zeroed here once: zeroing per tensor in front of its (atomic) sums was
         # ~150 launches = 0.8 ms of an 8 ms whole-video step
         self.G.zero_()
-        col_scale = self._col_scale(T)
-        col_loss = torch.zeros(NH, device=dev)
+        col_loss = torch.zeros((len(levels), NH), device=dev)
         dys = []
-        for lg in logits:
-            dy = torch.zeros((1, 1, T, NHP), device=dev)
-            ops.bce_logits(lg.view(T, NHP)[:, :NH], z, col_scale, dy.view(T, NHP), col_loss)
+        for li, lg in enumerate(logits):
+            tl = lens[li]
+            dy = torch.zeros((1, 1, tl, NHP), device=dev)
+            ops.bce_logits(lg.view(tl, NHP)[:, :NH], self._level_labels(z, T, tl), self._col_scale(tl), dy.view(tl, NHP), col_loss[li])
             dys.append(dy)
         # ---- backward: heads and FPN (top-down adds fan the level gradients into each other)
         g = None
         dstage = [None, None, None, None]
         for li, (lv, dy) in enumerate(zip(levels, dys)):
-            ops.wgrad_conv1d(dy.view(T, NHP), lv.view(T, C), hd.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True, bias_grad=hd.gb)
+            tl = lens[li]
+            ops.wgrad_conv1d(dy.view(tl, NHP), lv.view(tl, C), hd.gw, batch=1, t=tl, taps=1, dil=1, pad=0, accumulate=True, bias_grad=hd.gb)
+            if g is not None and self.hier:                                    # p_{li} = interp(p_{li+1}) + lateral: the adjoint of the resampling
+                g = ops.interp_linear_rows_bwd(g.view(1, lens[li - 1], C), tl).view(1, 1, tl, C)
             g = self._conv(dy, hd, transposed=True, residual=g)               # gradient w.r.t. p_{li+1}
             if li < 3:
                 cl_ = stage_out[li]                                            # lateral input c_{li+1}
-                ops.wgrad_conv1d(g.view(T, C), cl_.view(T, C), lat.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True, bias_grad=lat.gb)
+                ops.wgrad_conv1d(g.view(tl, C), cl_.view(tl, C), lat.gw, batch=1, t=tl, taps=1, dil=1, pad=0, accumulate=True, bias_grad=lat.gb)
                 dstage[li] = self._conv(g, lat, transposed=True)
             else:
-                dstage[3] = g                                                  # p4 is the last stage's output itself
+                dstage[3] = g                                                  # p4 is the last stage's (pooled) output itself
         self._reduce_bucket("heads")
         # ---- backward through the stages, last to first
         df = dstage[3]
         idx = len(saved)
         for si in range(len(self._stages()) - 1, -1, -1):
             prefix, n = self._stages()[si]
+            ts = lens[max(si - 1, 0)]
+            if self.hier and si > 0:                                           # through the stage's AvgPool1d(7, 3)
+                df = ops.avgpool1d_rows_bwd(df.view(1, lens[si], C), ts, 7, 3).view(1, 1, ts, C)
             for i in range(n - 1, -1, -1):
                 idx -= 1
-                p, d, zin, u = saved[idx]
+                p, d, zin, u, _ = saved[idx]
                 w1, wd = cv[p + ".conv_1x1"], cv[p + ".conv_dilated"]
                 do = ops.mul_add(df, lm[p]) if p in lm else df
-                ops.wgrad_conv1d(do.view(T, C), u.view(T, C), w1.gw, batch=1, t=T, taps=1, dil=1, pad=0, accumulate=True, bias_grad=w1.gb)
+                ops.wgrad_conv1d(do.view(ts, C), u.view(ts, C), w1.gw, batch=1, t=ts, taps=1, dil=1, pad=0, accumulate=True, bias_grad=w1.gb)
                 du = self._conv(do, w1, transposed=True, residual=u, act="relu_gate")
-                ops.wgrad_conv1d(du.view(T, C), zin.view(T, C), wd.gw, batch=1, t=T, taps=3, dil=d, pad=d, accumulate=True, bias_grad=wd.gb)
+                ops.wgrad_conv1d(du.view(ts, C), zin.view(ts, C), wd.gw, batch=1, t=ts, taps=3, dil=d, pad=d, accumulate=True, bias_grad=wd.gb)
                 df = self._conv(du, wd, dil=d, transposed=True, residual=df)
             if si > 0:
                 df = ops.mul_add(df, torch.ones_like(df), dstage[si - 1])      # + gradient of this stage's input as lateral c
@@ -318,6 +349,19 @@ class TencoTrainer:
         self.bucket_order = getattr(self, "bucket_order", []) + [name]
         if b > a:
             self._pending.append(dist.all_reduce(self.G[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _level_labels(self, z: torch.Tensor, T: int, tl: int) -> torch.Tensor:
+        """`fusion` (`run.py:169-175`): the labels of a level of tl != T frames are `F.interpolate(labels, size=tl, mode='nearest')` of the [T, K] rows:
+        row j <- row min(floor(j * float32(T / tl)), T - 1) (torch's nearest index arithmetic, in float32)"""
+        if tl == T:
+            return z
+        idx = self._label_idx.get((T, tl))
+        if idx is None:
+            import numpy as np
+            scale = np.float32(T) / np.float32(tl)
+            src = np.minimum(np.floor(np.arange(tl, dtype=np.float32) * scale).astype(np.int64), T - 1)
+            idx = self._label_idx[(T, tl)] = torch.from_numpy(src).to(self.dev)
+        return z.index_select(0, idx)
 
     def _col_scale(self, T: int) -> torch.Tensor:
         cs = self._scales.get(T)

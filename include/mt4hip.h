@@ -32,7 +32,7 @@ extern "C" {
 
 /* 10 in this revision (5 -> 6: mt4_stem_maxpool_bf16, mt4_bottleneck_fused_next_bf16, mt4_pack_fragments_bf16, the x2 / fuse_expand fields at the
  * end of mt4_conv_desc; 6 -> 7: mt4_copy_spans_u8; 7 -> 8: mt4_chain_gemm_bf16; 8 -> 9: stat_sums at the end of
- * mt4_conv_desc, mt4_bn_apply_sums_t / _f32, mt4_avgpool1d_rows, mt4_interp_linear_rows, `beta` / relu code 2 of mt4_bn_backward_f32, `bias_grad` of mt4_wgrad_conv1d_f32, MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup in mt4_refresh_weights; 9 -> 10: mt4_source_digest, mt4_attention takes head dims up to 512).  A binding checks it once at load
+ * mt4_conv_desc, mt4_bn_apply_sums_t / _f32, mt4_avgpool1d_rows, mt4_interp_linear_rows, `beta` / relu code 2 of mt4_bn_backward_f32, `bias_grad` of mt4_wgrad_conv1d_f32, MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup in mt4_refresh_weights; 9 -> 10: mt4_source_digest, mt4_attention takes head dims up to 512, mt4_png_stat_files / mt4_png_read_files, mt4_avgpool1d_rows_bwd_f32 / mt4_interp_linear_rows_bwd_f32).  A binding checks it once at load
  * (computervision_codes_amd/_lib.py: ABI_VERSION). */
 int mt4_abi_version(void);
 /* 16 hex digits: sha256 over every source file the library was built from (csrc/*.hip, csrc/*.h, this header), baked in at build time.  No
@@ -487,6 +487,11 @@ int mt4_fpn_topdown(const void* lat, void* levels, int32_t nlev, int64_t n, int3
  *   y [B][Tout][C]: source index max(0, (Tin / Tout)(w + 0.5) - 0.5), the two neighbours weighted by its fraction. */
 int mt4_avgpool1d_rows(const void* x, void* y, int32_t B, int32_t Tin, int32_t C, int32_t k, int32_t stride, int32_t dtype, void* stream);
 int mt4_interp_linear_rows(const void* x, void* y, int32_t B, int32_t Tin, int32_t Tout, int32_t C, int32_t dtype, void* stream);
+/* their adjoints for `--hier True` TRAINING (`loss.backward()` through `Refinement.max_pool_1x1` and `FPN._upsample_add`, Temporal_tenco/run.py:213),
+ * fp32, deterministic gathers: dx [B][Tin][C] from dy [B][Tout][C] (Tout = (Tin - k) / stride + 1 for the pool; for the interpolation Tin is the
+ * length of the FORWARD's input, Tout of its output). */
+int mt4_avgpool1d_rows_bwd_f32(const float* dy, float* dx, int32_t B, int32_t Tin, int32_t C, int32_t k, int32_t stride, void* stream);
+int mt4_interp_linear_rows_bwd_f32(const float* dy, float* dx, int32_t B, int32_t Tin, int32_t Tout, int32_t C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward pieces of the transformer-shaped temporal teacher MS-TCT (what torch autograd derives inside

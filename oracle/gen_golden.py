@@ -352,6 +352,9 @@ def gen_mstct(name):
 TRAIN_CASES = {
     "tenco_train_small": dict(num_layers_PG=4, num_layers_R=3, num_R=3, num_f_maps=64, dim=32, T=50, seed=501, lr=0.1),
     "tenco_train_full": dict(num_layers_PG=11, num_layers_R=10, num_R=3, num_f_maps=512, dim=512, T=120, seed=502, lr=0.1),
+    # `--hier True` (`network.py:147,154-155`, `run.py:159-179,196-212`): AvgPool1d(7, 3) behind every refinement stage, levels of 301 / 99 / 31 / 9
+    # frames, labels resized per level by `fusion`'s nearest interpolation
+    "tenco_train_hier": dict(num_layers_PG=4, num_layers_R=3, num_R=3, num_f_maps=64, dim=32, T=301, seed=503, lr=0.1, hier=True),
 }
 
 
@@ -362,8 +365,9 @@ def gen_tenco_train(name):
     cfg = TRAIN_CASES[name]
     torch.set_grad_enabled(True)
     try:
+        hier = bool(cfg.get("hier", False))
         mc = dict(num_layers_PG=cfg["num_layers_PG"], num_layers_R=cfg["num_layers_R"], num_R=cfg["num_R"], num_f_maps=cfg["num_f_maps"],
-                  dim=cfg["dim"], fpn=True)
+                  dim=cfg["dim"], fpn=True, hier=hier)
         m = _ref_tenco(mc)
         table = shapes.tenco_shapes(cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["num_f_maps"], cfg["dim"], 100, fpn=True)
         sd = synth.fill_from_shapes(table, seed=cfg["seed"])
@@ -375,8 +379,12 @@ def gen_tenco_train(name):
         out = m(x, False)
         bce = torch.nn.BCEWithLogitsLoss()
         terms = {}
+        def level_labels(y, t):          # `fusion` (`run.py:169-175`): identity at equal length, else nearest interpolation of the label rows
+            if y.shape[0] == t:
+                return y.float()
+            return torch.nn.functional.interpolate(y.float().transpose(0, 1).unsqueeze(0), size=t, mode="nearest").squeeze().transpose(0, 1).long().float()
         for gi, (s, _, _) in enumerate(o_tt.HEADS):
-            terms[s] = sum(bce(lv[0].transpose(0, 1), labels[s].float()) for lv in out[gi])
+            terms[s] = sum(bce(lv[0].transpose(0, 1), level_labels(labels[s], lv.shape[-1])) for lv in out[gi])
         loss = 0.1 * (terms["_i"] + terms["_v"] + terms["_t"]) + terms[""]
         for p_ in m.parameters():
             p_.grad = None
@@ -385,6 +393,10 @@ def gen_tenco_train(name):
         opt.step()
         new_ref = {k: v.detach().clone() for k, v in m.state_dict().items()}
         cfgk = dict(num_layers_PG=cfg["num_layers_PG"], num_layers_R=cfg["num_layers_R"], num_R=cfg["num_R"])
+        if hier:
+            cfgk["hier"] = True
+            outd_lengths = [int(lv.shape[-1]) for lv in out[0]]
+            assert outd_lengths == [301, 99, 31, 9], outd_lengths
         new_o, loss_o, terms_o, g_o = o_tt.train_step(sd, x, labels, cfg["lr"], 1e-5, **cfgk)
         assert abs(loss_o - float(loss)) < 1e-5 * max(1, abs(float(loss))), (loss_o, float(loss))
         outd = {"loss": np.array(float(loss)), "cfg": np.array(repr(cfg))}

@@ -19,11 +19,12 @@ def _trainer(cfg):
     from computervision_codes_amd.tenco_train import TencoTrainer
     table = shapes.tenco_shapes(cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["num_f_maps"], cfg["dim"], 100, fpn=True)
     sd = synth.fill_from_shapes(table, seed=cfg["seed"])
-    tr = TencoTrainer(cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["num_f_maps"], cfg["dim"], lr=cfg["lr"], weight_decay=1e-5)
+    tr = TencoTrainer(cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["num_f_maps"], cfg["dim"], lr=cfg["lr"], weight_decay=1e-5,
+                      hier=bool(cfg.get("hier", False)))
     return tr.load_state_dict(sd), sd, table
 
 
-@pytest.mark.parametrize("name", ["tenco_train_small", "tenco_train_full"])
+@pytest.mark.parametrize("name", ["tenco_train_small", "tenco_train_full", "tenco_train_hier"])   # (hier: `--hier True`, levels of 301 / 99 / 31 / 9 frames)
 def test_train_step_vs_reference_autograd(cuda, name):
     z, cfg = load_golden(name)
     tr, sd, table = _trainer(cfg)
@@ -128,3 +129,52 @@ def test_colsum_and_wgrad_take_float_aligned_outputs(cuda, off):
     ref = ops.pack_conv_weight(w.grad.to(cuda)[:, :, None, :], None, torch.float32).cpu()       # Conv1d weight [co][ci][tap] as a 1 x taps Conv2d
     assert (dw.cpu() - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
     assert bool((flat[:off] == 7.0).all()) and bool((flat[off + cout * kp:] == 7.0).all()) and torch.isfinite(dw).all()
+
+
+def test_hier_train_step_with_masks_vs_oracle_and_pool_interp_adjoints(cuda):
+    """`--hier True` training (`Temporal_tenco/network.py:147,154-155`, `run.py:159-179,196-212`): (i) the adjoints of AvgPool1d(7, 3) and of the
+    FPN's linear interpolation against torch autograd; (ii) a step with every random piece drawn (per-layer masks at their stage's length) against
+    the CPU oracle, every gradient tensor; (iii) hipGraph replay == eager"""
+    from computervision_codes_amd import ops
+    from computervision_codes_amd.tenco_train import TencoTrainer
+    from oracle import tenco_train as o_tt
+    g = torch.Generator().manual_seed(3)
+    for t_in in (301, 99, 31, 10, 7):
+        x = torch.randn((2, t_in, 8), generator=g, requires_grad=True)
+        y = torch.nn.functional.avg_pool1d(x.permute(0, 2, 1), 7, 3).permute(0, 2, 1)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        got = ops.avgpool1d_rows_bwd(dy.contiguous().to(cuda), t_in)
+        assert (got.cpu() - x.grad).abs().max().item() < 1e-6
+    for t_in, t_out in ((9, 31), (31, 99), (99, 301), (5, 5), (1, 4), (20, 7)):
+        x = torch.randn((2, t_in, 12), generator=g, requires_grad=True)
+        y = torch.nn.functional.interpolate(x.permute(0, 2, 1), size=t_out, mode="linear").permute(0, 2, 1)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        got = ops.interp_linear_rows_bwd(dy.contiguous().to(cuda), t_in)
+        assert (got.cpu() - x.grad).abs().max().item() < 2e-6, (t_in, t_out)
+    cfg = dict(num_layers_PG=4, num_layers_R=3, num_R=3, num_f_maps=64, dim=32, T=157, seed=511, lr=0.05)
+    table = shapes.tenco_shapes(4, 3, 3, 64, 32, 100, fpn=True)
+    sd = synth.fill_from_shapes(table, seed=cfg["seed"])
+    tr = TencoTrainer(4, 3, 3, 64, 32, lr=cfg["lr"], weight_decay=1e-5, hier=True).load_state_dict(sd)
+    assert tr.level_lengths(157) == [157, 51, 15, 3]
+    x = synth.synthetic_features(cfg["T"], cfg["dim"], seed=cfg["seed"])
+    labels = _labels(cfg["seed"], cfg["T"])
+    masks = tr.draw_masks(cfg["T"], torch.Generator().manual_seed(9))
+    assert masks["layer_masks"]["Rs.1.layers.0"].shape[-1] == 51 and masks["layer_masks"]["Rs.0.layers.2"].shape[-1] == 157
+    new_o, loss_o, terms_o, g_o = o_tt.train_step(sd, x, labels, cfg["lr"], 1e-5, masks=masks, num_layers_PG=4, num_layers_R=3, num_R=3, hier=True)
+    loss, terms = tr.train_step(x.to(cuda), labels, masks=masks, apply_update=False)
+    assert abs(loss - loss_o) < 1e-4 * max(1.0, abs(loss_o)), (loss, loss_o)
+    grads = tr.grads()
+    gmax = max(float(v.abs().max()) for v in g_o.values())
+    for k, gg in grads.items():
+        assert (gg - g_o[k]).abs().max().item() <= 2e-4 * max(g_o[k].abs().max().item(), 1e-4 * gmax), k
+    tr.apply_update()
+    new = tr.state_dict()
+    for k, _ in table:
+        assert (new[k] - new_o[k]).abs().max().item() <= 2e-5 * max(1.0, new_o[k].abs().max().item()), k
+    tr_e = TencoTrainer(4, 3, 3, 64, 32, lr=cfg["lr"], weight_decay=1e-5, hier=True).load_state_dict(sd)
+    tr_g = TencoTrainer(4, 3, 3, 64, 32, lr=cfg["lr"], weight_decay=1e-5, hier=True).load_state_dict(sd)
+    le = [tr_e.train_step(x.to(cuda), labels)[0] for _ in range(2)]
+    lg = [tr_g.train_step(x.to(cuda), labels, use_graph=True)[0] for _ in range(2)]
+    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(le, lg)) and le[1] < le[0]

@@ -114,10 +114,12 @@ def test_mstct_oracle_matches_reference_outputs(name):
     _close(flat[:: max(1, flat.numel() // 8192)], z["concat_sample"], tol=1e-4)
 
 
-def test_tenco_train_oracle_matches_reference_step():
-    """one Temporal_tenco step (`run.py:128-213`): the oracle's loss, gradients and SGD update vs the reference-captured fixture"""
+@pytest.mark.parametrize("name", ["tenco_train_small", "tenco_train_hier"])
+def test_tenco_train_oracle_matches_reference_step(name):
+    """one Temporal_tenco step (`run.py:128-213`): the oracle's loss, gradients and SGD update vs the reference-captured fixture
+    (tenco_train_hier: `--hier True`, pooled levels of 301 / 99 / 31 / 9 frames, labels resized per level by `fusion`)"""
     from oracle import tenco_train as o_tt
-    z, cfg = load_golden("tenco_train_small")
+    z, cfg = load_golden(name)
     table = shapes.tenco_shapes(cfg["num_layers_PG"], cfg["num_layers_R"], cfg["num_R"], cfg["num_f_maps"], cfg["dim"], 100, fpn=True)
     sd = synth.fill_from_shapes(table, seed=cfg["seed"])
     x = synth.synthetic_features(cfg["T"], cfg["dim"], seed=cfg["seed"])
@@ -125,7 +127,7 @@ def test_tenco_train_oracle_matches_reference_step():
     labels = {s: torch.from_numpy((synth.uniform01(cfg["seed"], 900 + i, cfg["T"] * k) < 0.1).reshape(cfg["T"], k).astype(np.int64))
               for i, (s, k) in enumerate(heads)}
     new, loss, terms, g = o_tt.train_step(sd, x, labels, cfg["lr"], 1e-5, num_layers_PG=cfg["num_layers_PG"], num_layers_R=cfg["num_layers_R"],
-                                          num_R=cfg["num_R"])
+                                          num_R=cfg["num_R"], **({"hier": True} if cfg.get("hier") else {}))
     assert abs(loss - float(z["loss"])) < 1e-5 * max(1.0, abs(float(z["loss"])))
     unused = set(str(z["unused"]).split(";"))          # parameters the reference's autograd leaves without gradient
     for k, ref in zip([k for k, _ in table], z["grad_norms"]):
