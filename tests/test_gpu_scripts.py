@@ -496,3 +496,24 @@ def test_spatial_cnn_run_e_closing_report_one_rank_equals_two_ranks_and_sklearn(
                     correct += len(set(gt_pos).intersection(set((-pd).argsort()[:k])))
                     total += len(gt_pos)
             assert abs(got[ci] - correct / max(total, 1)) < 1.1e-4, (k, comp)
+
+
+def test_tenco_hier_train_driver_runs_and_evaluates(cuda, tmp_path):
+    """`Temporal_tenco/run.py -t -e --fpn --hier True` (`network.py:147,154-155`, `run.py:159-179`): one epoch on 80-frame videos (levels of 80 / 25 /
+    7 / 1 frames), validation + best checkpoint, then the closing report of the -e pass (the finest level scores the frames)"""
+    from computervision_codes_amd import featfile
+    tree = tmp_path / "MT4MTLKD"
+    shutil.copytree(os.path.join(ROOT, "MT4MTLKD"), tree)
+    data = str(tmp_path / "CholecT45")
+    vids = _make_dataset(data, n_frames=80, h=8, w=8)
+    rng = np.random.default_rng(1)
+    featfile.write_feats(str(tree / "0-5fold" / "data_feats" / "run_S" / "k1_feats.pkl"), {v[-2:]: rng.standard_normal((80, 512)).astype(np.float32) for v in vids})
+    r = subprocess.run([sys.executable, "run.py", "-t", "-e", "--fpn", "--hier", "True", "--input_dim", "512", "--loss_type", "all", "--epochs", "1", "-l", "1e-2",
+                        "5e-3", "1e-2", "-w", "9", "18", "200", "--version", "S_H", "--version1", "S", "--data_dir", data, "--kfold", "1"],
+                       cwd=tree / "Temporal_tenco", env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    run = tree / "Temporal_tenco" / "__checkpoint__" / "run_S_H"
+    log = open(run / "rendezvous_l8_cholectcholect45-crossval_k1_batchnorm_lowres.log").read()
+    assert log.count("Traning | lr:") == 1 and "mAP => ivt:" in log and len(_report_rows(log)) == 2
+    maps = pickle.load(open(run / "mAPs_k1.pckl", "rb"))
+    assert maps["ivt"].global_predictions[0].shape == (80, 100)
