@@ -880,6 +880,21 @@ def avgpool1d_rows(x: torch.Tensor, k: int = 7, stride: int = 3) -> torch.Tensor
     return y
 
 
+def tcn_layer_fused(x: torch.Tensor, w1_frag: torch.Tensor, b1: torch.Tensor, w2_frag: torch.Tensor, b2: torch.Tensor, dilation: int,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One DilatedResidualLayer in one launch (`mt4_tcn_layer_fused_bf16`; `Temporal_tenco/network.py:186-198`): x [B, T, 512] bf16 -> same shape,
+    the hidden map stays in LDS; w*_frag = `pack_fragments` of the packed conv weights.  Bit-identical to the two `conv_nhwc` launches."""
+    _need_cuda(x, w1_frag, b1, w2_frag, b2, out)
+    assert x.dim() == 3 and x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[2] == 512
+    assert tuple(w1_frag.shape) == (512, 1536) and tuple(w2_frag.shape) == (512, 512) and w1_frag.dtype == w2_frag.dtype == torch.bfloat16
+    assert b1.dtype == b2.dtype == torch.float32 and b1.numel() == b2.numel() == 512
+    y = torch.empty_like(x) if out is None else out
+    assert y.data_ptr() != x.data_ptr() and y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
+    check(lib.mt4_tcn_layer_fused_bf16(x.data_ptr(), w1_frag.data_ptr(), b1.data_ptr(), w2_frag.data_ptr(), b2.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1],
+                                       512, int(dilation), _stream()), "mt4_tcn_layer_fused_bf16")
+    return y
+
+
 def avgpool1d_rows_bwd(dy: torch.Tensor, t_in: int, k: int = 7, stride: int = 3) -> torch.Tensor:
     """adjoint of `avgpool1d_rows`: dy [B, (t_in - k) // stride + 1, C] fp32 -> dx [B, t_in, C]"""
     _need_cuda(dy)

@@ -59,6 +59,7 @@ class VideoNas:
         self._sd: Dict[str, torch.Tensor] = {}
         self._p: Dict[str, torch.Tensor] = {}
         self.tile = 0            # implicit-GEMM path: 0 = the library's choice per launch; a tile id forces it (tools/tcn_long_sweep.py)
+        self.fused_layer_min_tiles = 96    # bf16, 512 channels: 64-frame tiles (B x ceil(T / 64)) from which a layer runs as ONE launch (tools/tcn_fused_layer_ab.py)
 
     # ------------------------------------------------------------------ nn.Module-like surface
     def eval(self):
@@ -98,6 +99,9 @@ class VideoNas:
             for i in range(n):
                 pk(f"{prefix}.layers.{i}.conv_dilated")
                 pk(f"{prefix}.layers.{i}.conv_1x1")
+                if self.dtype == torch.bfloat16 and self.C == 512:      # fragment-ordered copies for the one-launch layer of the throughput mode
+                    for c in ("conv_dilated", "conv_1x1"):
+                        p[f"{prefix}.layers.{i}.{c}.wf"] = ops.pack_fragments(p[f"{prefix}.layers.{i}.{c}.w"])
         if not self.use_fpn:
             pk("PG.conv_out")
         else:
@@ -118,6 +122,12 @@ class VideoNas:
 
     def _layer(self, x, prefix, d):
         p = self._p
+        b, _, t, _ = x.shape
+        if (prefix + ".conv_dilated.wf") in p and not self.hier and b * ((t + 63) // 64) >= self.fused_layer_min_tiles:
+            # throughput mode (several videos per forward): the whole DilatedResidualLayer in ONE launch, the 512-channel hidden map stays in LDS
+            # (`ops.tcn_layer_fused`, bit-identical to the two launches below; gated on the tile count: one 64-frame tile per CU)
+            return ops.tcn_layer_fused(x.view(b, t, self.C), p[prefix + ".conv_dilated.wf"], p[prefix + ".conv_dilated.b"], p[prefix + ".conv_1x1.wf"],
+                                       p[prefix + ".conv_1x1.b"], d).view(b, 1, t, self.C)
         h = ops.conv_nhwc(x, p[prefix + ".conv_dilated.w"], p[prefix + ".conv_dilated.b"], kh=1, kw=3, pad=(0, d), dil=(1, d),
                           relu=True, tile=self.tile)
         return ops.conv_nhwc(h, p[prefix + ".conv_1x1.w"], p[prefix + ".conv_1x1.b"], kh=1, kw=1, residual=x, tile=self.tile)

@@ -32,7 +32,7 @@ extern "C" {
 
 /* 10 in this revision (5 -> 6: mt4_stem_maxpool_bf16, mt4_bottleneck_fused_next_bf16, mt4_pack_fragments_bf16, the x2 / fuse_expand fields at the
  * end of mt4_conv_desc; 6 -> 7: mt4_copy_spans_u8; 7 -> 8: mt4_chain_gemm_bf16; 8 -> 9: stat_sums at the end of
- * mt4_conv_desc, mt4_bn_apply_sums_t / _f32, mt4_avgpool1d_rows, mt4_interp_linear_rows, `beta` / relu code 2 of mt4_bn_backward_f32, `bias_grad` of mt4_wgrad_conv1d_f32, MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup in mt4_refresh_weights; 9 -> 10: mt4_source_digest, mt4_attention takes head dims up to 512, mt4_png_stat_files / mt4_png_read_files, mt4_avgpool1d_rows_bwd_f32 / mt4_interp_linear_rows_bwd_f32).  A binding checks it once at load
+ * mt4_conv_desc, mt4_bn_apply_sums_t / _f32, mt4_avgpool1d_rows, mt4_interp_linear_rows, `beta` / relu code 2 of mt4_bn_backward_f32, `bias_grad` of mt4_wgrad_conv1d_f32, MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup in mt4_refresh_weights; 9 -> 10: mt4_source_digest, mt4_attention takes head dims up to 512, mt4_png_stat_files / mt4_png_read_files, mt4_avgpool1d_rows_bwd_f32 / mt4_interp_linear_rows_bwd_f32, mt4_tcn_layer_fused_bf16).  A binding checks it once at load
  * (computervision_codes_amd/_lib.py: ABI_VERSION). */
 int mt4_abi_version(void);
 /* 16 hex digits: sha256 over every source file the library was built from (csrc/*.hip, csrc/*.h, this header), baked in at build time.  No
@@ -477,6 +477,12 @@ int mt4_tcn_dilated_residual_layer(const void* x, const void* w_dilated, const f
 int mt4_tcn_stage(const void* x, void* buf_a, void* buf_b, void* h, void* y, const void* const* w_dilated, const float* const* b_dilated,
                   const void* const* w_1x1, const float* const* b_1x1, int32_t n_layers, int32_t B, int32_t T, int32_t C,
                   int32_t dtype, void* stream);
+/* One DilatedResidualLayer in ONE launch, bf16, the head's THROUGHPUT mode (several videos per forward; Temporal_tenco/network.py:186-198):
+ * y[b][t] = x[b][t] + W2 . relu(W1 * x + b1) + b2, W1 a k = 3 convolution of `dilation` over the frames of video b (frames outside it are zeros),
+ * x, y [B][T][512] bf16 (y != x), w1_frag / w2_frag = mt4_pack_fragments_bf16 of the packed [512][3 * 512] / [512][512] matrices, b1 / b2 fp32.
+ * The 512-channel hidden map stays in LDS.  Bit-identical to the two mt4_conv_nhwc launches; tiles of 64 frames never cross a video.  C must be 512. */
+int mt4_tcn_layer_fused_bf16(const void* x, const void* w1_frag, const float* b1, const void* w2_frag, const float* b2, void* y, int32_t B, int32_t T,
+                             int32_t C, int32_t dilation, void* stream);
 /* FPN top-down pathway at equal lengths (network.py:93-106; `F.interpolate(x, size=W, mode='linear')` to the same length is the
  * identity): levels[l] = lat[l] + levels[l+1] for l = nlev-2 .. 0, in place.  lat [nlev-1][n], levels [nlev][n] of dtype, n % 4 == 0. */
 int mt4_fpn_topdown(const void* lat, void* levels, int32_t nlev, int64_t n, int32_t dtype, void* stream);
