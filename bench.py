@@ -217,7 +217,7 @@ def temporal_bench(dev, do_cpu):
     sd = synth.fill_from_shapes(shapes.tenco_shapes(11, 10, 3, 512, 512, 100, fpn=True), seed=47)
     for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
         m = VideoNas(args, 11, 10, 3, 512, 512, 100, dtype=dt).eval().load_state_dict(sd)
-        for B in (8, 32):
+        for B in (8, 32, 64):          # (bf16, 24 ... 96 videos: every DilatedResidualLayer is ONE launch, `mt4_tcn_layer_fused_bf16`)
             xb = torch.stack([synth.synthetic_features(256, 512, seed=47 + i)[0] for i in range(8)]).repeat(B // 8, 1, 1).to(dev).contiguous()
             g = GraphedForward(lambda xx: m(xx, False), [xb])
             ms = _time_call(lambda: g(xb), iters=10)

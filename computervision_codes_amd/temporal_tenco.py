@@ -59,7 +59,10 @@ class VideoNas:
         self._sd: Dict[str, torch.Tensor] = {}
         self._p: Dict[str, torch.Tensor] = {}
         self.tile = 0            # implicit-GEMM path: 0 = the library's choice per launch; a tile id forces it (tools/tcn_long_sweep.py)
-        self.fused_layer_min_tiles = 96    # bf16, 512 channels: 64-frame tiles (B x ceil(T / 64)) from which a layer runs as ONE launch (tools/tcn_fused_layer_ab.py)
+        # bf16, 512 channels: the window of 64-frame tile counts (B x ceil(T / 64)) in which a layer runs as ONE launch.  Below it the chip is not
+        # filled (one tile per CU), above it the generic 256 x 256 tiles amortise the weights better than 2 MB per 64 rows through L2
+        # (profiles/r04_tcn_fused_layer_ab.txt: 24 ... 64 videos of 256 frames +2 ... +20 %, 8 whole videos of 2000 frames 2.98 -> 1.98 ms; 128 videos: even)
+        self.fused_layer_min_tiles, self.fused_layer_max_tiles = 96, 384
 
     # ------------------------------------------------------------------ nn.Module-like surface
     def eval(self):
@@ -123,7 +126,7 @@ class VideoNas:
     def _layer(self, x, prefix, d):
         p = self._p
         b, _, t, _ = x.shape
-        if (prefix + ".conv_dilated.wf") in p and not self.hier and b * ((t + 63) // 64) >= self.fused_layer_min_tiles:
+        if (prefix + ".conv_dilated.wf") in p and not self.hier and self.fused_layer_min_tiles <= b * ((t + 63) // 64) <= self.fused_layer_max_tiles:
             # throughput mode (several videos per forward): the whole DilatedResidualLayer in ONE launch, the 512-channel hidden map stays in LDS
             # (`ops.tcn_layer_fused`, bit-identical to the two launches below; gated on the tile count: one 64-frame tile per CU)
             return ops.tcn_layer_fused(x.view(b, t, self.C), p[prefix + ".conv_dilated.wf"], p[prefix + ".conv_dilated.b"], p[prefix + ".conv_1x1.wf"],

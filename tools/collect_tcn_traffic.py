@@ -9,7 +9,7 @@ _spec = _ilu.spec_from_file_location("srcdigest", os.path.join(os.path.dirname(o
 _sd = _ilu.module_from_spec(_spec); _spec.loader.exec_module(_sd)
 KSHA = _sd.kernels_digest(_sd.TCN_SOURCES)          # the sources the profiled library was built from (bench.py nulls the figure when they change)
 
-KERNELS = ("tcn_conv_kernel", "fpn_topdown_kernel", "igemm_conv_kernel")
+KERNELS = ("tcn_conv_kernel", "fpn_topdown_kernel", "igemm_conv_kernel", "tcn_layer_fused_kernel")
 
 
 def last_forward(d, counter):

@@ -34,7 +34,7 @@ for B, T in ((8, 256), (16, 256), (24, 256), (32, 256), (48, 256), (64, 256), (1
     x = torch.stack([synth.synthetic_features(T, 512, seed=47 + i)[0] for i in range(min(B, 8))]).repeat((B + 7) // 8, 1, 1)[:B].cuda().contiguous()
     row = []
     for gate in (10 ** 9, 0):
-        m.fused_layer_min_tiles = gate
+        m.fused_layer_min_tiles, m.fused_layer_max_tiles = gate, 10 ** 9
         g = GraphedForward(lambda xx: m(xx, False), [x])
         row.append(timeit(lambda: g(x)))
         del g

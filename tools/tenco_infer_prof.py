@@ -14,6 +14,8 @@ ap.add_argument("--T", type=int, default=256)
 ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
 ap.add_argument("--config", default="tenco4", choices=["tenco4", "config1"])
 ap.add_argument("--replays", type=int, default=50)
+ap.add_argument("--videos", type=int, default=0, help="throughput mode: this many videos per forward ([B, T, dim] input)")
+ap.add_argument("--layer", default="auto", choices=["auto", "fused", "two"], help="throughput mode, bf16: one launch per DilatedResidualLayer / two / the model's window")
 ap.add_argument("--tile", type=int, default=0, help="implicit-GEMM path: force this tile id (0 = the library's choice)")
 a = ap.parse_args()
 num_R, dim = (3, 512) if a.config == "tenco4" else (0, 2048)
@@ -22,7 +24,11 @@ args = types.SimpleNamespace(fpn=fpn, output=False, hier=False, mask=True)
 sd = synth.fill_from_shapes(shapes.tenco_shapes(11, 10, num_R, 512, dim, 100, fpn=fpn), seed=47)
 m = VideoNas(args, 11, 10, num_R, 512, dim, 100, dtype=torch.float32 if a.dtype == "f32" else torch.bfloat16).eval().load_state_dict(sd)
 m.tile = a.tile
+if a.layer != "auto":
+    m.fused_layer_min_tiles, m.fused_layer_max_tiles = (0, 10 ** 9) if a.layer == "fused" else (10 ** 9, 10 ** 9)
 x = synth.synthetic_features(a.T, dim, seed=47).cuda()
+if a.videos:
+    x = x.repeat(a.videos, 1, 1).contiguous()
 g = GraphedForward(lambda xx: m(xx, False), [x])
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,4 +37,5 @@ for _ in range(a.replays):
     g(x)
 e1.record()
 torch.cuda.synchronize()
-print(json.dumps({"config": a.config, "T": a.T, "dtype": a.dtype, "replays": a.replays, "ms_per_video": round(e0.elapsed_time(e1) / a.replays, 4)}))
+print(json.dumps({"config": a.config, "T": a.T, "dtype": a.dtype, "replays": a.replays, "videos": max(a.videos, 1), "layer": a.layer,
+                  "ms_per_forward": round(e0.elapsed_time(e1) / a.replays, 4)}))
