@@ -137,6 +137,8 @@ SIGNATURES = {
     "mt4_bottleneck_fused_next_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mt4_fpn_topdown": (C.c_int, [_vp, _vp, _i32, C.c_int64, _i32, _vp]),
     "mt4_tcn_layer_fused_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mt4_tcn_linear_ln_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _i32, _vp, _vp, _vp]),
+    "mt4_tcn_linear_stats_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mt4_bgemm_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                 C.c_float, _i32, _vp]),
     "mt4_softmax_rows_f32": (C.c_int, [_vp, C.c_int64, _i32, C.c_float, _vp]),

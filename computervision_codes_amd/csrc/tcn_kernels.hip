@@ -41,6 +41,15 @@ struct TcnK {
     unsigned tps_magic, nnx_magic;   // floor(2^32 / v) + 1: q = mulhi(n, magic) is n / v for n, v < 2^16
     int relu;
     unsigned x_bytes;
+    // LN (mt4_tcn_linear_ln_f32): LayerNorm over the Cin channels of every frame folded into the GEMM -- w holds gamma o W, bias W . beta + b,
+    // ln_colsum[n] = sum_k (gamma o W)[n][k]; the frame's statistics arrive as partial sums written by the launch that produced x (its `stat_out`):
+    // stat_in [stat_parts][B * T] x (sum, sum of squares) over 16 channels each, added here in a fixed order.
+    // stat_out (any 1-tap fp32 launch, Cout % 16 == 0): this launch's partials of ITS output
+    const float* ln_colsum;
+    float ln_eps, ln_inv_k;
+    const float2* stat_in;
+    float2* stat_out;
+    int stat_parts;
 };
 
 __device__ __forceinline__ v4u tcn_make_srd(const void* p, unsigned bytes) {
@@ -66,8 +75,12 @@ __device__ __forceinline__ void tcn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0
 
 constexpr int kTcnBM = 32, kTcnBN = 16, kTcnWaves = 8, kTcnRing = 2, kTcnMaxPieces = 8;
 
-template <typename T, int TAPS, bool OUT_F32>
+constexpr int kTcnMaxStatParts = 56;     // channels / 16 of the widest folded LayerNorm (MS-TCT: 864 / 16 = 54)
+
+// LN: LayerNorm of the input rows folded in, their statistics from `stat_in`
+template <typename T, int TAPS, bool OUT_F32, bool LN = false>
 __global__ __launch_bounds__(kTcnWaves * 64) void tcn_conv_kernel(const TcnK a) {
+    static_assert(!LN || (sizeof(T) == 4 && TAPS == 1), "the LayerNorm fold is the fp32 nn.Linear form");
     constexpr int ES = (int)sizeof(T);
     constexpr int NW = kTcnWaves;
     constexpr int HP = (TAPS - 1) / 2;
@@ -79,6 +92,8 @@ __global__ __launch_bounds__(kTcnWaves * 64) void tcn_conv_kernel(const TcnK a) 
                  "s"(a.A), "s"(a.logA), "s"(a.tps));
     asm volatile("" ::"s"(a.S), "s"(a.TT), "s"(a.slots), "s"(a.np), "s"(a.SPT), "s"(a.w_row_bytes), "s"(a.n_tiles), "s"(a.nnx), "s"(a.relu),
                  "s"(a.x_bytes), "s"(a.tps_magic), "s"(a.nnx_magic));
+    if constexpr (LN) asm volatile("" ::"s"(a.ln_colsum), "s"(a.ln_eps), "s"(a.ln_inv_k), "s"(a.stat_in), "s"(a.stat_parts));
+    if constexpr (sizeof(T) == 4 && TAPS == 1) asm volatile("" ::"s"(a.stat_out));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -164,8 +179,28 @@ __global__ __launch_bounds__(kTcnWaves * 64) void tcn_conv_kernel(const TcnK a) 
     const bool eok = wave < 2 && et < a.T && en < a.Cout;
     // (raw loaded values only: nothing consumes them before the epilogue, so no wait lands in front of the K loop)
     float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pcs = make_float4(0.f, 0.f, 0.f, 0.f);        // LN: column sums of the folded weight
     uint4 pr = make_uint4(0u, 0u, 0u, 0u);               // residual: 4 fp32 or (in .x/.y) 4 bf16
+    constexpr int NSP = kTcnMaxStatParts / 4;
+    float2 pst[LN ? NSP : 1];                            // LN: the producer's partials q, q + 4, ... of this lane's frame
+    if constexpr (LN) {
+        const long long nrows = (long long)a.B * a.T;
+#pragma unroll
+        for (int j = 0; j < NSP; ++j) {
+            pst[j] = make_float2(0.f, 0.f);
+            if (wave < 2 && et < a.T && q + 4 * j < a.stat_parts) pst[j] = a.stat_in[(q + 4 * j) * nrows + erow];
+        }
+    }
     if (eok) {
+        if constexpr (LN) {
+            if (evec) pcs = *(const float4*)(a.ln_colsum + en);
+            else {
+                pcs.x = a.ln_colsum[en];
+                if (en + 1 < a.Cout) pcs.y = a.ln_colsum[en + 1];
+                if (en + 2 < a.Cout) pcs.z = a.ln_colsum[en + 2];
+                if (en + 3 < a.Cout) pcs.w = a.ln_colsum[en + 3];
+            }
+        }
         if (a.bias) {
             if (evec) pb = *(const float4*)(a.bias + en);
             else {
@@ -259,6 +294,20 @@ __global__ __launch_bounds__(kTcnWaves * 64) void tcn_conv_kernel(const TcnK a) 
     f32x4 sum = red[wave * 64 + lane];
 #pragma unroll
     for (int v = 1; v < NW; ++v) sum += red[(v * 2 + wave) * 64 + lane];
+    if constexpr (LN) {                                   // y = rstd (x . W' - mean colsum) + (W . beta + b): LayerNorm(x) . W^T + b with the channel scale in W'
+        float s1 = pst[0].x, s2 = pst[0].y;
+#pragma unroll
+        for (int j = 1; j < NSP; ++j) { s1 += pst[j].x; s2 += pst[j].y; }      // (absent parts are zeros)
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);      // parts q, q + 4, ... sit in lanes r16 + 16 q: every lane ends with the same total
+        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+        const float mean = s1 * a.ln_inv_k;
+        const float var = fmaxf(fmaf(-mean, mean, s2 * a.ln_inv_k), 0.f);
+        const float rstd = 1.0f / sqrtf(var + a.ln_eps);
+        sum[0] = rstd * fmaf(-mean, pcs.x, sum[0]);
+        sum[1] = rstd * fmaf(-mean, pcs.y, sum[1]);
+        sum[2] = rstd * fmaf(-mean, pcs.z, sum[2]);
+        sum[3] = rstd * fmaf(-mean, pcs.w, sum[3]);
+    }
     if (!eok) return;
     sum += (f32x4){pb.x, pb.y, pb.z, pb.w};
     if constexpr (sizeof(T) == 4) sum += (f32x4){__uint_as_float(pr.x), __uint_as_float(pr.y), __uint_as_float(pr.z), __uint_as_float(pr.w)};
@@ -269,6 +318,15 @@ __global__ __launch_bounds__(kTcnWaves * 64) void tcn_conv_kernel(const TcnK a) 
     if (a.relu) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) sum[e] = fmaxf(sum[e], 0.f);
+    }
+    if constexpr (sizeof(T) == 4 && TAPS == 1) {
+        if (a.stat_out) {       // LayerNorm partials of the stored row over this tile's 16 channels (Cout % 16 == 0: every lane of the frame is here)
+            float v1 = (sum[0] + sum[1]) + (sum[2] + sum[3]);
+            float v2 = fmaf(sum[3], sum[3], fmaf(sum[2], sum[2], fmaf(sum[1], sum[1], sum[0] * sum[0])));
+            v1 += __shfl_xor(v1, 16); v1 += __shfl_xor(v1, 32);
+            v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
+            if (q == 0) a.stat_out[(long long)n_tile * ((long long)a.B * a.T) + row] = make_float2(v1, v2);
+        }
     }
     if constexpr (OUT_F32) {
         float* yp = (float*)a.y + row * a.Cout + n;
@@ -311,18 +369,22 @@ Comb choose_comb(int T, int d, int taps) {
     return best;
 }
 
-template <typename T, int TAPS, bool OUT_F32>
+template <typename T, int TAPS, bool OUT_F32, bool LN = false>
 int launch_tcn(const TcnK& k, hipStream_t s) {
     const int lds = kTcnWaves * kTcnRing * k.np * 1024 + kTcnWaves * 2 * 64 * 16;
     if (lds > 160 * 1024) return MT4_EUNSUPPORTED;
-    auto fn = tcn_conv_kernel<T, TAPS, OUT_F32>;
+    auto fn = tcn_conv_kernel<T, TAPS, OUT_F32, LN>;
     if (lds > 65536) MT4_RAISE_LDS(fn);
     hipLaunchKernelGGL(fn, dim3(8, k.TT, k.B * k.nnx), dim3(kTcnWaves * 64), lds, s, k);
     return mt4_check_launch();
 }
 
-int tcn_conv_impl(const mt4_tcn_desc* d, hipStream_t s) {
+int tcn_conv_impl(const mt4_tcn_desc* d, hipStream_t s, const float* ln_colsum = nullptr, float ln_eps = 0.f, const float* stat_in = nullptr,
+                  float* stat_out = nullptr) {
     if (!d || !d->x || !d->w || !d->y) return MT4_EINVAL;
+    if (ln_colsum && (d->dtype != MT4_F32 || d->taps != 1 || !d->bias || !(ln_eps > 0.f) || ((uintptr_t)ln_colsum & 15) || !stat_in || d->Cin % 16 ||
+                      d->Cin / 16 > kTcnMaxStatParts || ((uintptr_t)stat_in & 7))) return MT4_EINVAL;
+    if (stat_out && (d->dtype != MT4_F32 || d->taps != 1 || d->Cout % 16 || ((uintptr_t)stat_out & 7))) return MT4_EINVAL;
     if (d->B <= 0 || d->T <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->dilation <= 0 || (d->taps != 1 && d->taps != 3)) return MT4_EINVAL;
     if (d->dtype != MT4_F32 && d->dtype != MT4_BF16) return MT4_EUNSUPPORTED;
     if (d->out_dtype != MT4_F32 && d->out_dtype != MT4_BF16) return MT4_EUNSUPPORTED;
@@ -353,6 +415,12 @@ int tcn_conv_impl(const mt4_tcn_desc* d, hipStream_t s) {
     if (c.TT > 65535 || (long long)d->B * k.nnx > 65535 || c.tps > 65535) return MT4_EUNSUPPORTED;   // grid limits; exact magic division
     k.tps_magic = (unsigned)(0x100000000ULL / (unsigned)c.tps) + 1u;
     k.nnx_magic = (unsigned)(0x100000000ULL / (unsigned)k.nnx) + 1u;
+    k.stat_out = (float2*)stat_out;
+    if (ln_colsum) {
+        k.ln_colsum = ln_colsum; k.ln_eps = ln_eps; k.ln_inv_k = 1.0f / (float)d->Cin;
+        k.stat_in = (const float2*)stat_in; k.stat_parts = d->Cin / 16;
+        return launch_tcn<float, 1, true, true>(k, s);
+    }
     if (d->dtype == MT4_F32) return taps == 3 ? launch_tcn<float, 3, true>(k, s) : launch_tcn<float, 1, true>(k, s);
     if (d->out_dtype == MT4_F32) return taps == 3 ? launch_tcn<u16, 3, true>(k, s) : launch_tcn<u16, 1, true>(k, s);
     return taps == 3 ? launch_tcn<u16, 3, false>(k, s) : launch_tcn<u16, 1, false>(k, s);
@@ -363,6 +431,28 @@ int tcn_conv_impl(const mt4_tcn_desc* d, hipStream_t s) {
 extern "C" int mt4_tcn_conv(const mt4_tcn_desc* d, void* stream) {
     mt4_clear_error();
     return tcn_conv_impl(d, (hipStream_t)stream);
+}
+
+// nn.LayerNorm(Cin) + nn.Linear(Cin, Cout) on the rows of one short window in ONE launch (MS-TCT's norm1 -> q | kv and norm2 -> linear1,
+// `Temporal_mstct/MSTCT/Temporal_Encoder.py`): w = gamma o W packed as for mt4_tcn_conv, colsum[n] = sum_k w[n][k], bias = W . beta + b.
+// stats_in: the partial sums the launch that produced x left (its stats_out).
+extern "C" int mt4_tcn_linear_ln_f32(const void* x, const void* w_folded, const float* colsum, const float* bias_folded, const void* residual, void* y,
+                                     int32_t rows, int32_t Cin, int32_t Cout, float eps, int32_t relu, const float* stats_in, float* stats_out,
+                                     void* stream) {
+    mt4_clear_error();
+    if (!colsum || !stats_in) return MT4_EINVAL;
+    mt4_tcn_desc d{x, w_folded, bias_folded, residual, y, 1, rows, Cin, Cout, 1, 1, relu, MT4_F32, MT4_F32};
+    return tcn_conv_impl(&d, (hipStream_t)stream, colsum, eps, stats_in, stats_out);
+}
+
+// nn.Linear on the rows of one short window (mt4_tcn_conv with one tap, fp32) that also leaves the LayerNorm partials of its OUTPUT rows for the
+// mt4_tcn_linear_ln_f32 launch behind it: stats_out [Cout / 16][rows] x (sum, sum of squares over 16 channels), Cout % 16 == 0.
+extern "C" int mt4_tcn_linear_stats_f32(const void* x, const void* w, const float* bias, const void* residual, void* y, int32_t rows, int32_t Cin,
+                                        int32_t Cout, int32_t relu, float* stats_out, void* stream) {
+    mt4_clear_error();
+    if (!stats_out) return MT4_EINVAL;
+    mt4_tcn_desc d{x, w, bias, residual, y, 1, rows, Cin, Cout, 1, 1, relu, MT4_F32, MT4_F32};
+    return tcn_conv_impl(&d, (hipStream_t)stream, nullptr, 0.f, nullptr, stats_out);
 }
 
 // One DilatedResidualLayer (Temporal_tenco/network.py:186-198, eval): y = x + conv_1x1(relu(conv_dilated(x))), two dependent launches;

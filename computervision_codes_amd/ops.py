@@ -271,6 +271,58 @@ def tcn_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tenso
     return out
 
 
+def fold_layernorm(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """host side of `linear_ln`: nn.Linear (w [N,K], b [N]) behind nn.LayerNorm (gamma, beta [K]) -> (gamma o W, its row sums, W . beta + b), float32
+    (sums in float64)"""
+    w64, g64 = w.double(), gamma.double()
+    wf = w64 * g64[None, :]
+    return wf.float(), wf.float().double().sum(1).float().contiguous(), (w64 @ beta.double() + b.double()).float().contiguous()
+
+
+def linear_ln(x2d: torch.Tensor, w_folded_packed: torch.Tensor, colsum: torch.Tensor, bias_folded: torch.Tensor, *, eps: float = 1e-5,
+              stats_in: torch.Tensor, residual: Optional[torch.Tensor] = None, relu: bool = False,
+              stats_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Linear(LayerNorm(x)) on the rows of one short window in one launch of the latency kernel (`mt4_tcn_linear_ln_f32`); operands from
+    `fold_layernorm` + `pack_linear_weight`.  fp32; rows within `latency_linear_ok`.  stats_in [K / 16, M, 2]: the partial sums the launch that
+    produced x left (`linear_stats` / `stats_out` of this op)."""
+    _need_cuda(x2d, w_folded_packed, colsum, bias_folded, residual, stats_in, stats_out)
+    assert x2d.dtype == torch.float32 and x2d.dim() == 2 and x2d.is_contiguous() and w_folded_packed.dtype == torch.float32
+    m, k = x2d.shape
+    n = w_folded_packed.shape[0]
+    assert w_folded_packed.shape[1] == packed_k(k, 1, 1, torch.float32) and tcn_supported(k, torch.float32)
+    assert colsum.dtype == torch.float32 and colsum.numel() == n and bias_folded.dtype == torch.float32 and bias_folded.numel() == n
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.is_contiguous() and residual.numel() == m * n
+    assert stats_in.dtype == torch.float32 and stats_in.is_contiguous() and tuple(stats_in.shape) == (k // 16, m, 2) and k % 16 == 0
+    if stats_out is not None:
+        assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and tuple(stats_out.shape) == (n // 16, m, 2) and n % 16 == 0
+    y = torch.empty((m, n), dtype=torch.float32, device=x2d.device)
+    check(lib.mt4_tcn_linear_ln_f32(x2d.data_ptr(), w_folded_packed.data_ptr(), colsum.data_ptr(), bias_folded.data_ptr(),
+                                    residual.data_ptr() if residual is not None else None, y.data_ptr(), m, k, n, eps, 1 if relu else 0,
+                                    stats_in.data_ptr(), stats_out.data_ptr() if stats_out is not None else None,
+                                    _stream()), "mt4_tcn_linear_ln_f32")
+    return y
+
+
+def linear_stats(x2d: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, residual: Optional[torch.Tensor] = None,
+                 relu: bool = False):
+    """nn.Linear on one short window through the latency kernel, leaving the LayerNorm partials of its output rows (`mt4_tcn_linear_stats_f32`):
+    -> (y [M, N], stats [N / 16, M, 2]) for the `linear_ln` launch that normalises y"""
+    _need_cuda(x2d, w_packed, bias, residual)
+    assert x2d.dtype == torch.float32 and x2d.dim() == 2 and x2d.is_contiguous() and w_packed.dtype == torch.float32
+    m, k = x2d.shape
+    n = w_packed.shape[0]
+    assert w_packed.shape[1] == packed_k(k, 1, 1, torch.float32) and tcn_supported(k, torch.float32) and n % 16 == 0
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.is_contiguous() and residual.numel() == m * n
+    y = torch.empty((m, n), dtype=torch.float32, device=x2d.device)
+    st = torch.empty((n // 16, m, 2), dtype=torch.float32, device=x2d.device)
+    check(lib.mt4_tcn_linear_stats_f32(x2d.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                       residual.data_ptr() if residual is not None else None, y.data_ptr(), m, k, n, 1 if relu else 0, st.data_ptr(),
+                                       _stream()), "mt4_tcn_linear_stats_f32")
+    return y, st
+
+
 def latency_linear_ok(rows: int, cin: int, dtype: torch.dtype) -> bool:
     """inside a latency context: does a GEMM / 1-D conv over `rows` frames of `cin` channels take the temporal head's latency kernel?"""
     return bool(_LATENCY_TILES.get()) and _TCN_LINEAR and rows <= _TCN_LINEAR_MAX_ROWS and tcn_supported(cin, dtype)

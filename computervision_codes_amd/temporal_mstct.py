@@ -34,6 +34,8 @@ class VideoNas:
         self.D, self.E = in_feat_dim, final_embedding_dim
         self.dtype, self.device = dtype, torch.device(device)
         self.training = False
+        self.fold_layernorm = True      # fp32, one short window: norm1 / norm2 ride in the launch of the nn.Linear behind them (ops.linear_ln)
+        self.fold_linear1_max_c = 384   # ... norm2 -> linear1 only up to this width (profiles/r04_mstct_ln_fold_ab.txt)
         self._table = mstct_shapes(in_feat_dim, self.inter, num_block, mlp_ratio, final_embedding_dim, self.loss_type)
         self._sd: Dict[str, torch.Tensor] = {}
         self._p: Dict[str, object] = {}
@@ -77,9 +79,19 @@ class VideoNas:
                 # q and kv (`Temporal_Encoder.py:80-84`: two nn.Linear on the same normalised input) as ONE GEMM over the stacked weights
                 qkv = (ops.pack_linear_weight(torch.cat([sd[g + ".q.weight"], sd[g + ".kv.weight"]], 0).to(dev), dt),
                        torch.cat([sd[g + ".q.bias"], sd[g + ".kv.bias"]], 0).to(dev).contiguous())
-                st["blocks"].append(dict(n1=ln(q + ".norm1"), n2=ln(q + ".norm2"), qkv=qkv, proj=lin(g + ".proj"),
-                                         l1=lin(l + ".linear1"), l2=lin(l + ".linear2"),
-                                         tc=(sd[l + ".TC.weight"][:, 0, :].to(dev).contiguous(), sd[l + ".TC.bias"].to(dev).contiguous())))
+                blk = dict(n1=ln(q + ".norm1"), n2=ln(q + ".norm2"), qkv=qkv, proj=lin(g + ".proj"),
+                           l1=lin(l + ".linear1"), l2=lin(l + ".linear2"),
+                           tc=(sd[l + ".TC.weight"][:, 0, :].to(dev).contiguous(), sd[l + ".TC.bias"].to(dev).contiguous()))
+                if dt == torch.float32:
+                    # one short window (latency context): norm1 -> q | kv and norm2 -> linear1 run as ONE launch each, the LayerNorm folded into
+                    # the GEMM (`ops.linear_ln`): gamma into the weight, mean / rstd from the operand fragments, beta into the bias
+                    def folded(w, b, n):
+                        wf, cs, bf = ops.fold_layernorm(w, b, sd[n + ".weight"], sd[n + ".bias"])
+                        return ops.pack_linear_weight(wf.to(dev), dt), cs.to(dev), bf.to(dev)
+                    blk["qkv_ln"] = folded(torch.cat([sd[g + ".q.weight"], sd[g + ".kv.weight"]], 0), torch.cat([sd[g + ".q.bias"], sd[g + ".kv.bias"]], 0),
+                                           q + ".norm1")
+                    blk["l1_ln"] = folded(sd[l + ".linear1.weight"], sd[l + ".linear1.bias"], q + ".norm2")
+                st["blocks"].append(blk)
             p["stages"].append(st)
         mx = "Temporal_Mixer."
         p["f4"] = lin(mx + "linear_f4.proj")
@@ -94,17 +106,32 @@ class VideoNas:
         p["pred"] = lin(c + ".linear_pred")
         self._p = p
 
-    def _block(self, x, blk, b, t, c):
-        y = ops.layernorm(x, *blk["n1"])
-        qkv = ops.linear(y, *blk["qkv"])                                  # [B*T, 3C]: q | k | v column slices
+    def _block(self, x, blk, b, t, c, stats=None):
+        """one encoder block on rows x [B*T, C]; `stats` = the LayerNorm partials of x if the launch that produced x left them.  Returns (x, stats)"""
         hd = c // self.head
+        fold = self.fold_layernorm and "qkv_ln" in blk and ops.latency_linear_ok(b * t, c, self.dtype) and c % 16 == 0
+        if not fold:
+            qkv = ops.linear(ops.layernorm(x, *blk["n1"]), *blk["qkv"])       # [B*T, 3C]: q | k | v column slices
+            a = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch=b, heads=self.head, nq=t, nk=t, hd=hd, q_stride=3 * c, k_stride=3 * c,
+                              v_stride=3 * c, scale=hd ** -0.5)
+            x = ops.linear(a, *blk["proj"], residual=x)
+            h = ops.linear(ops.layernorm(x, *blk["n2"]), *blk["l1"])
+            h = ops.dwconv1d_k3(h.view(b, t, -1), *blk["tc"], act="gelu").view(b * t, -1)
+            return ops.linear(h, *blk["l2"], residual=x), None
+        # one short window: norm1 / norm2 ride in the nn.Linear behind them (gamma in the weight, beta in the bias), their row statistics come as
+        # partial sums from the epilogue of the launch that wrote the row (proj / linear2 of the block before); a block whose input has none
+        # (behind the stage's merge norm) normalises in a launch of its own
+        qkv = ops.linear_ln(x, *blk["qkv_ln"], stats_in=stats) if stats is not None else ops.linear(ops.layernorm(x, *blk["n1"]), *blk["qkv"])
         a = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch=b, heads=self.head, nq=t, nk=t, hd=hd, q_stride=3 * c, k_stride=3 * c,
                           v_stride=3 * c, scale=hd ** -0.5)
-        x = ops.linear(a, *blk["proj"], residual=x)
-        y = ops.layernorm(x, *blk["n2"])
-        h = ops.linear(y, *blk["l1"])
+        if c <= self.fold_linear1_max_c:
+            x, st = ops.linear_stats(a, *blk["proj"], residual=x)
+            h = ops.linear_ln(x, *blk["l1_ln"], stats_in=st)
+        else:      # C -> 8 C at C = 576 / 864: C / 16 partial sums re-read by each of the 8 C / 16 channel tiles cost more than the LayerNorm launch
+            x = ops.linear(a, *blk["proj"], residual=x)
+            h = ops.linear(ops.layernorm(x, *blk["n2"]), *blk["l1"])
         h = ops.dwconv1d_k3(h.view(b, t, -1), *blk["tc"], act="gelu").view(b * t, -1)
-        return ops.linear(h, *blk["l2"], residual=x)
+        return ops.linear_stats(h, *blk["l2"], residual=x)
 
     @ops.with_latency_tiles
     def forward_btd(self, x_btd: torch.Tensor):
@@ -125,8 +152,9 @@ class VideoNas:
             else:
                 y = ops.conv_nhwc(x.view(b, 1, t, cin), st["merge"][0], st["merge"][1], kh=1, kw=3, pad=(0, 1)).view(b * t, c)
             y = ops.layernorm(y, *st["merge_norm"])
-            for blk in st["blocks"]:
-                y = self._block(y, blk, b, t, c)
+            stats = None
+            for i, blk in enumerate(st["blocks"]):
+                y, stats = self._block(y, blk, b, t, c, stats)
             y = ops.layernorm(y, *st["norm"])
             feats.append(y)
             x, cin = y, c

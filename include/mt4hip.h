@@ -32,10 +32,10 @@ extern "C" {
 
 /* 10 in this revision (5 -> 6: mt4_stem_maxpool_bf16, mt4_bottleneck_fused_next_bf16, mt4_pack_fragments_bf16, the x2 / fuse_expand fields at the
  * end of mt4_conv_desc; 6 -> 7: mt4_copy_spans_u8; 7 -> 8: mt4_chain_gemm_bf16; 8 -> 9: stat_sums at the end of
- * mt4_conv_desc, mt4_bn_apply_sums_t / _f32, mt4_avgpool1d_rows, mt4_interp_linear_rows, `beta` / relu code 2 of mt4_bn_backward_f32, `bias_grad` of mt4_wgrad_conv1d_f32, MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup in mt4_refresh_weights; 9 -> 10: mt4_source_digest, mt4_attention takes head dims up to 512, mt4_png_stat_files / mt4_png_read_files, mt4_avgpool1d_rows_bwd_f32 / mt4_interp_linear_rows_bwd_f32, mt4_tcn_layer_fused_bf16).  A binding checks it once at load
+ * mt4_conv_desc, mt4_bn_apply_sums_t / _f32, mt4_avgpool1d_rows, mt4_interp_linear_rows, `beta` / relu code 2 of mt4_bn_backward_f32, `bias_grad` of mt4_wgrad_conv1d_f32, MT4_REFRESH_TILES_PER_BLOCK tiles per workgroup in mt4_refresh_weights; 9 -> 10: mt4_source_digest, mt4_attention takes head dims up to 512, mt4_png_stat_files / mt4_png_read_files, mt4_avgpool1d_rows_bwd_f32 / mt4_interp_linear_rows_bwd_f32, mt4_tcn_layer_fused_bf16, mt4_tcn_linear_ln_f32, mt4_tcn_linear_stats_f32).  A binding checks it once at load
  * (computervision_codes_amd/_lib.py: ABI_VERSION). */
 int mt4_abi_version(void);
-/* 16 hex digits: sha256 over every source file the library was built from (csrc/*.hip, csrc/*.h, this header), baked in at build time.  No
+/* 16 hex digits: sha256 over every source file the library was built from (every .hip / .h file of csrc/ and this header), baked in at build time.  No
  * reference counterpart (the reference has no native code): it ties a loaded binary to the sources in the tree -- `_lib.py` compares it with
  * `srcdigest.library_digest()` at load and refuses a stale library. */
 const char* mt4_source_digest(void);
@@ -483,6 +483,19 @@ int mt4_tcn_stage(const void* x, void* buf_a, void* buf_b, void* h, void* y, con
  * The 512-channel hidden map stays in LDS.  Bit-identical to the two mt4_conv_nhwc launches; tiles of 64 frames never cross a video.  C must be 512. */
 int mt4_tcn_layer_fused_bf16(const void* x, const void* w1_frag, const float* b1, const void* w2_frag, const float* b2, void* y, int32_t B, int32_t T,
                              int32_t C, int32_t dilation, void* stream);
+/* nn.LayerNorm(Cin) followed by nn.Linear(Cin, Cout) on the `rows` frames of one short window in ONE launch of the latency kernel, fp32 -- MS-TCT's
+ * `norm1 -> q | kv` and `norm2 -> linear1` (Temporal_mstct/MSTCT/Temporal_Encoder.py:74-86,35-40 with :112-113): with w_folded = gamma o W (packed like
+ * any 1-tap weight of mt4_tcn_conv), colsum[n] = sum_k w_folded[n][k] and bias_folded = W . beta + b,
+ *     y[t][n] = rstd_t (x_t . w_folded[n] - mean_t colsum[n]) + bias_folded[n]  (+ residual, ReLU)  ==  Linear(LayerNorm(x_t))[n];
+ * mean_t / rstd_t (biased variance, eps inside the root): from stats_in [Cin / 16][rows][2] = per 16 channels (sum, sum of squares) of every row of x, as
+ * the launch that produced x left them (`stats_out` of this function or of mt4_tcn_linear_stats_f32; Cin % 16 == 0, Cin <= 896), added in a fixed
+ * order.  The normalised map is never written.  stats_out (may be NULL; Cout % 16 == 0): the partials of y for the next such launch.  Geometry contract of mt4_tcn_conv. */
+int mt4_tcn_linear_ln_f32(const void* x, const void* w_folded, const float* colsum, const float* bias_folded, const void* residual, void* y,
+                          int32_t rows, int32_t Cin, int32_t Cout, float eps, int32_t relu, const float* stats_in, float* stats_out, void* stream);
+/* nn.Linear on one short window (mt4_tcn_conv, one tap, fp32: the residual-stream producers `proj` / `linear2` of an MS-TCT block,
+ * Temporal_Encoder.py:86,40) that also writes stats_out [Cout / 16][rows][2] for the mt4_tcn_linear_ln_f32 launch that normalises its output. */
+int mt4_tcn_linear_stats_f32(const void* x, const void* w, const float* bias, const void* residual, void* y, int32_t rows, int32_t Cin, int32_t Cout,
+                             int32_t relu, float* stats_out, void* stream);
 /* FPN top-down pathway at equal lengths (network.py:93-106; `F.interpolate(x, size=W, mode='linear')` to the same length is the
  * identity): levels[l] = lat[l] + levels[l+1] for l = nlev-2 .. 0, in place.  lat [nlev-1][n], levels [nlev][n] of dtype, n % 4 == 0. */
 int mt4_fpn_topdown(const void* lat, void* levels, int32_t nlev, int64_t n, int32_t dtype, void* stream);

@@ -172,3 +172,53 @@ def test_tenco_throughput_mode_uses_the_fused_layer_and_matches_the_two_launch_m
         for u, v in zip(la, lb):
             assert torch.equal(u, v)
     assert torch.equal(a[0][0][:6], a[0][0][6:12])          # the same six videos: the same rows whatever rides along
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(256, 256, 768), (256, 384, 1152), (256, 576, 4608), (256, 864, 2592), (200, 864, 6912), (37, 32, 48), (1, 64, 16),
+                                           (70, 896, 50)])
+def test_linear_ln_vs_float64_layernorm_linear(cuda, rows, cin, cout):
+    """`mt4_tcn_linear_stats_f32` -> `mt4_tcn_linear_ln_f32`: x = a . Wp^T + bp + r leaves the LayerNorm partials of its rows, Linear(LayerNorm(x)) is ONE
+    launch behind it (MS-TCT's proj -> norm2 -> linear1, linear2 -> norm1 -> q | kv): against float64 on the CPU, as close as LayerNorm + Linear as two
+    launches; rows with a mean far from zero (where sum x^2 - mean^2 loses digits) stay within the model's 1e-3"""
+    from computervision_codes_amd import ops
+    rng = np.random.default_rng(rows + cin + cout)
+    r = torch.from_numpy(rng.standard_normal((rows, cin)).astype(np.float32)) * 2.0 + torch.from_numpy(rng.standard_normal((rows, 1)).astype(np.float32)) * 1.5
+    a = torch.from_numpy(rng.standard_normal((rows, 64)).astype(np.float32))
+    wpr = torch.from_numpy((rng.standard_normal((cin, 64)) / 8.0).astype(np.float32))
+    bp = torch.from_numpy(rng.standard_normal(cin).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((cout, cin)) / np.sqrt(cin)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    g = torch.from_numpy((1.0 + 0.3 * rng.standard_normal(cin)).astype(np.float32))
+    be = torch.from_numpy((0.2 * rng.standard_normal(cin)).astype(np.float32))
+    res = torch.from_numpy(rng.standard_normal((rows, cout)).astype(np.float32))
+    wpp = ops.pack_linear_weight(wpr.to(cuda), torch.float32)
+    x, st = ops.linear_stats(a.to(cuda), wpp, bp.to(cuda), residual=r.to(cuda))
+    with ops.latency_tiles():
+        assert torch.equal(x, ops.linear(a.to(cuda), wpp, bp.to(cuda), residual=r.to(cuda)))        # the statistics ride along: same rows
+    x64 = x.double().cpu()
+    assert tuple(st.shape) == (cin // 16, rows, 2)
+    assert (st[..., 0].double().cpu().sum(0) - x64.sum(1)).abs().max().item() < 1e-5 * max(1.0, x64.abs().sum(1).max().item())
+    assert (st[..., 1].double().cpu().sum(0) / (x64 * x64).sum(1) - 1).abs().max().item() < 1e-5
+    ref = F.linear(F.layer_norm(x64, (cin,), g.double(), be.double(), 1e-5), w.double(), b.double())
+    wf, cs, bf = ops.fold_layernorm(w, b, g, be)
+    wp = ops.pack_linear_weight(wf.to(cuda), torch.float32)
+    with ops.latency_tiles():
+        two = ops.linear(ops.layernorm(x, g.to(cuda), be.to(cuda)), ops.pack_linear_weight(w.to(cuda), torch.float32), b.to(cuda))
+    st2 = torch.empty((cout // 16, rows, 2), device=cuda) if cout % 16 == 0 else None
+    one = ops.linear_ln(x, wp, cs.to(cuda), bf.to(cuda), stats_in=st, stats_out=st2)
+    scale = max(1.0, ref.abs().max().item())
+    e_two, e_one = (two.double().cpu() - ref).abs().max().item() / scale, (one.double().cpu() - ref).abs().max().item() / scale
+    assert e_one < 2e-5 and e_one < 4 * e_two + 2e-6, (e_one, e_two)
+    if st2 is not None:
+        assert (st2[..., 0].double().cpu().sum(0) - one.double().cpu().sum(1)).abs().max().item() < 1e-5 * max(1.0, one.abs().sum(1).max().item())
+    one_r = ops.linear_ln(x, wp, cs.to(cuda), bf.to(cuda), stats_in=st, residual=res.to(cuda), relu=True)
+    assert (one_r.double().cpu() - F.relu(ref + res.double())).abs().max().item() / scale < 2e-5
+    assert torch.equal(one, ops.linear_ln(x, wp, cs.to(cuda), bf.to(cuda), stats_in=st))                                     # deterministic
+    if rows > 40:   # a frame's row does not depend on what shares its launch
+        assert torch.equal(one[:33], ops.linear_ln(x[:33].contiguous(), wp, cs.to(cuda), bf.to(cuda), stats_in=st[:, :33].contiguous()))
+    xs, sts = ops.linear_stats(a.to(cuda), wpp, bp.to(cuda), residual=(r + 30.0).to(cuda))    # mean 30, sigma 2: the one-pass variance loses ~8 bits
+    far = ops.linear_ln(xs, wp, cs.to(cuda), bf.to(cuda), stats_in=sts)
+    ref_far = F.linear(F.layer_norm(xs.double().cpu(), (cin,), g.double(), be.double(), 1e-5), w.double(), b.double())
+    assert (far.double().cpu() - ref_far).abs().max().item() / scale < 1e-3
+    csd, bfd = cs.to(cuda), bf.to(cuda)      # the partial sums are not optional
+    assert ops.lib.mt4_tcn_linear_ln_f32(x.data_ptr(), wp.data_ptr(), csd.data_ptr(), bfd.data_ptr(), None, one.data_ptr(), rows, cin, cout, 1e-5, 0, None, None, None) != 0
