@@ -616,8 +616,15 @@ def linear(x2d: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tenso
     m, k = x2d.shape
     y_ld = 0 if out is None or out.is_contiguous() else out.stride(0)
     res_ld = 0 if residual is None or residual.is_contiguous() else residual.stride(0)
-    if (_LATENCY_TILES.get() and _TCN_LINEAR and act in (None, "none", "relu") and out_row_map is None and y_ld == 0 and res_ld == 0
-            and m <= _TCN_LINEAR_MAX_ROWS and tcn_supported(k, x2d.dtype) and x2d.is_contiguous() and (residual is None or residual.dtype == x2d.dtype)
+    n = w_packed.shape[0]
+    lat = bool(_LATENCY_TILES.get()) and _TCN_LINEAR and m <= _TCN_LINEAR_MAX_ROWS
+    if lat and x2d.dtype == torch.float32 and n >= 8 * k and n >= 3072 and 128 <= m:
+        # ... except the widest expansions (MS-TCT's linear1, C -> 8 C from C = 384): thousands of 32 x 16 tiles are many rounds of the chip, the generic
+        # kernel's plain 32 x 32 tiles (no K split: same sums whatever rides along) run them 12-20 % faster (384 -> 3072: 13.2 -> 11.6 us, 864 -> 6912: 45.7 -> 36.8)
+        y = conv_nhwc(x2d.view(m, 1, 1, k), w_packed, bias, kh=1, kw=1, residual=residual, act=act, out_row_map=out_row_map,
+                      out_dtype=out_dtype, out=out, y_ld=y_ld, res_ld=res_ld, tile=6)
+        return y if out is not None else y.view(m, -1)
+    if (lat and act in (None, "none", "relu") and out_row_map is None and y_ld == 0 and res_ld == 0 and tcn_supported(k, x2d.dtype) and x2d.is_contiguous() and (residual is None or residual.dtype == x2d.dtype)
             and (out_dtype is None or out_dtype == x2d.dtype or out_dtype == torch.float32)):
         # a short sequence's nn.Linear inside a latency context (MS-TCT on one window): the temporal head's latency kernel as a 1-tap conv
         # (32 x 16 tiles, one workgroup per CU, no barrier in the K loop) instead of the K-split tiles of the generic kernel

@@ -35,7 +35,7 @@ class VideoNas:
         self.dtype, self.device = dtype, torch.device(device)
         self.training = False
         self.fold_layernorm = True      # fp32, one short window: norm1 / norm2 ride in the launch of the nn.Linear behind them (ops.linear_ln)
-        self.fold_linear1_max_c = 384   # ... norm2 -> linear1 only up to this width (profiles/r04_mstct_ln_fold_ab.txt)
+        self.fold_linear1_max_c = 256   # ... norm2 -> linear1 only up to this width (profiles/r04_mstct_ln_fold_ab.txt)
         self._table = mstct_shapes(in_feat_dim, self.inter, num_block, mlp_ratio, final_embedding_dim, self.loss_type)
         self._sd: Dict[str, torch.Tensor] = {}
         self._p: Dict[str, object] = {}
@@ -127,7 +127,8 @@ class VideoNas:
         if c <= self.fold_linear1_max_c:
             x, st = ops.linear_stats(a, *blk["proj"], residual=x)
             h = ops.linear_ln(x, *blk["l1_ln"], stats_in=st)
-        else:      # C -> 8 C at C = 576 / 864: C / 16 partial sums re-read by each of the 8 C / 16 channel tiles cost more than the LayerNorm launch
+        else:      # C -> 8 C from C = 384: C / 16 partial sums re-read by each of the 8 C / 16 channel tiles cost more than the LayerNorm launch, and
+            # the GEMM itself is faster on the generic kernel's 32 x 32 tiles (ops.linear)
             x = ops.linear(a, *blk["proj"], residual=x)
             h = ops.linear(ops.layernorm(x, *blk["n2"]), *blk["l1"])
         h = ops.dwconv1d_k3(h.view(b, t, -1), *blk["tc"], act="gelu").view(b * t, -1)
