@@ -16,6 +16,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 import types
 
@@ -46,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-temporal", action="store_true")
     ap.add_argument("--no-ddp-train", action="store_true", help="N > 1: skip the data-parallel training sub-record")
+    ap.add_argument("--ddp-timeout", type=float, default=300.0, help="N > 1: seconds after which the data-parallel training sub-record is given up and the headline line is printed without it")
     ap.add_argument("--per-layer", default="", help="write a per-conv-layer timing table (json) to this path")
     return ap.parse_args()
 
@@ -855,12 +857,25 @@ def main():
                    "data": "synthetic", "config": {"workload": f"Spatial_cnn {a.network} extractor, {a.height}x{a.width} frames, {a.dtype}, eval (BASELINE configs[1])"},
                    "roofline": None, "error": f"rank-0 sub-records failed: {type(e).__name__}: {e}"}
     if world > 1 and not a.no_ddp_train:
+        # the headline line must survive the sub-record: an exception is caught below; a collective that never returns (the RCCL exchange has
+        # not run on more than one GPU before the driver's scaling run) is cut by a timer -- rank 0 prints the line it has, every rank leaves
+        def give_up():
+            if rank == 0:
+                res["ddp_train"] = {"error": f"no result after {a.ddp_timeout} s (a collective did not return); the headline above was complete before this leg"}
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+        timer = threading.Timer(a.ddp_timeout, give_up)
+        timer.daemon = True
+        timer.start()
         try:
             rec = ddp_train_bench(dev, dist, world, rank)  # every rank takes part (the exchange is collective)
-        except Exception as e:                             # the headline line must survive a failure of the sub-record
+        except Exception as e:
             rec = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             res["ddp_train"] = rec
+        if dist is not None:
+            dist.barrier()
+        timer.cancel()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
