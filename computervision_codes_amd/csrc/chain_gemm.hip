@@ -44,7 +44,14 @@ constexpr int BM = 128;              // rows per workgroup
 constexpr int CH = 128;              // channels of N1 per chunk = 2 K-steps of GEMM2
 constexpr int PLANE = BM * 128;      // one 64-channel plane of a row tile: [row][8 x 16 B], chunk index XOR (row & 7)
 
-__device__ __forceinline__ float act(float v, int a) { return a == 1 ? fmaxf(v, 0.f) : a == 2 ? gelu_erf(v) : v; }
+__device__ __forceinline__ void act4(float (&v)[4], int a) {
+    if (a == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (a == 2) {
+        gelu_erf_n(v);
+    }
+}
 
 // NT2: N2 = 128 * NT2 (16-channel tiles per wave in GEMM2); NKS1 = K1 / 64; CONV: the Bottleneck form (r1 and y1 given, act1 = ReLU), else the MLP
 // form (no r1 / y1, act1 = GELU).  Everything a load is conditional on is a template parameter: a load behind a runtime condition makes hipcc
@@ -193,8 +200,7 @@ __global__ __launch_bounds__(512, 2) void chain_gemm_kernel(const ChainK a) {
                     v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
                     v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act(v[e], ACT1);
+                act4(v, ACT1);
                 *(uint2*)hp = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             }
         }
@@ -260,8 +266,7 @@ __global__ __launch_bounds__(512, 2) void chain_gemm_kernel(const ChainK a) {
                 v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
                 v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act(v[e], ACT2);
+            act4(v, ACT2);
             *(uint2*)(smem + row * pitch + n * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
         }
     }

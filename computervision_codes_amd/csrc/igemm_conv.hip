@@ -609,8 +609,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel
 #pragma unroll
                     for (int e = 0; e < CH; ++e) v[e] = fmaxf(v[e], 0.f);
                 } else if (a.relu == 2) {
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) v[e] = gelu_erf(v[e]);
+                    gelu_erf_n(v);
                 }
                 if constexpr (OUT_F32) {
                     *(float4*)(a.y + o * 4) = make_float4(v[0], v[1], v[2], v[3]);

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ GELU backward (erf form)
-// dx = dy * (Phi(x) + x phi(x)),  Phi by the same Abramowitz-Stegun erf as the forward (gelu_erf), phi(x) = exp(-x^2/2) / sqrt(2 pi)
+// dx = dy * (Phi(x) + x phi(x)),  Phi by the Abramowitz-Stegun 7.1.26 erf (|err| < 1.5e-7; shares its exp with phi), phi(x) = exp(-x^2/2) / sqrt(2 pi)
 __global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long long n) {
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;

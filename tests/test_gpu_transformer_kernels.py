@@ -252,7 +252,10 @@ def test_window_attention_mfma_bf16(cuda, cfg):
 @pytest.mark.parametrize("ws,H,res,shift", [(12, 4, 24, 6), (12, 4, 24, 0), (7, 8, 14, 3), (7, 3, 7, 0), (4, 2, 8, 2)])
 def test_window_attention_from_relative_table_equals_expanded_tables(cuda, ws, H, res, shift):
     """the table / region-id form of the Swin core (`mt4_window_attention_rel_bf16`) against the same kernel fed with the expanded
-    [H,N,N] bias and [nW,N,N] mask the reference materialises (`swin_transformer.py:92-103,129-132,210-229`): bit-identical"""
+    [H,N,N] bias and [nW,N,N] mask the reference materialises (`swin_transformer.py:92-103,129-132,210-229`): bit-identical on unshifted
+    blocks.  On shifted blocks the region form adds +100 where the regions are equal (one more MFMA on one-hot region vectors) instead of -100
+    where they differ -- the same softmax with every score of a row moved by 100: outputs differ by one bf16 ulp in < 0.5 % of the elements, and
+    both forms are equally close to the float64 result"""
     from computervision_codes_amd import ops
     from computervision_codes_amd.spatial_transformer import _rel_pos_index, _shift_mask, _shift_regions
     N, nwin = ws * ws, (res // ws) ** 2
@@ -268,4 +271,14 @@ def test_window_attention_from_relative_table_equals_expanded_tables(cuda, ws, H
                                     mask_padded=ops.pad_attention_bias(mask.to(cuda), 0.0) if shift else None, **kw)
     got = ops.window_attention_rel_bf16(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], ws=ws, rel_table=table.t().contiguous().to(cuda),
                                         region=_shift_regions(res, ws, shift).to(torch.int32).to(cuda) if shift else None, **kw)
-    assert torch.equal(got, ref)
+    if not shift:
+        assert torch.equal(got, ref)
+        return
+    d = (got.float() - ref.float()).abs()
+    assert (d > 0).float().mean().item() < 5e-3 and d.max().item() <= 2.0 ** -5 * max(1.0, ref.float().abs().max().item() / 4.0), (d.max().item(), (d > 0).float().mean().item())
+    q, k, v = [t.double().cpu().view(B, N, H, 32).permute(0, 2, 1, 3) for t in (qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:])]
+    qs = (q.float() * scale).to(torch.bfloat16).double()       # (the kernel rounds the scaled q to bf16)
+    sc = qs @ k.transpose(-1, -2) + bias.double()[None] + mask.double().repeat(B // mask.shape[0], 1, 1)[:, None]
+    o64 = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B * N, c)
+    e_got, e_ref = (got.double().cpu() - o64).abs().max().item(), (ref.double().cpu() - o64).abs().max().item()
+    assert e_got <= 1.05 * e_ref + 1e-6, (e_got, e_ref)
