@@ -1,6 +1,7 @@
 // Kernels around the GEMMs of the transformer-shaped stages (Swin + Query2Label, MS-TCT): LayerNorm with
 // row gather, multi-head attention core, patch extraction, small element-wise pieces.  All HBM-bound or tiny.
 #include "mt4_common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------ vector helpers
 template <typename T> struct Vec;  // one 16-byte global vector <-> floats
@@ -1032,6 +1033,11 @@ extern "C" int mt4_kd_mix(const float* s, const float* tea_i, const float* tea_v
 // for e >= 4; the V^T fragment is read in the same order), so P never touches LDS.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
+__device__ __forceinline__ float wa_max3(float a, float b, float c) {      // (fmaxf chains compile to v_max_f32 + canonicalising copies: 47 instructions for 36 scores)
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 typedef short wa_v4s_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 wa_read_tr(const char* p) {     // ds_read_b64_tr_b16 (EXEC must be all ones: the query-tile loops are wave-uniform)
     return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((wa_v4s_t __attribute__((address_space(3)))*)(uintptr_t)p));
@@ -1125,9 +1131,9 @@ __global__ __launch_bounds__(NW * 64, (NT >= 8 && NT <= 9) ? 3 : 1) void window_
     int* Kidx = (int*)(Tb + 2 * T + 4);
     // shifted blocks: the mask -100 [region(i) != region(j)] (`swin_transformer.py:222-229`) enters as +100 [region(i) == region(j)] -- the same softmax,
     // every score of a row moved by the same 100 -- and that is a dot product of one-hot region vectors scaled by 10: one more MFMA per key tile
-    // on a second operand image Oh [token][16 bf16] instead of a compare, a select and an add per score (12 VALU per key tile: windows holding
-    // more than one region ran 1.3-1.8 x the time of the others)
-    char* Oh = (char*)(((uintptr_t)(Kidx + NP) + 15) & ~(uintptr_t)15);
+    // on a second operand image Oh [token][32 bf16] (dims 16 .. 31 zeros; rows laid out like Q / K) instead of a compare, a select and an add per
+    // score (12 VALU per key tile: windows holding more than one region ran 1.3-1.8 x the time of the others)
+    char* const Oh = smem + ((2 * NP * QK_PITCH + V_BYTES + (2 * T + 4) * 4 + NP * 4 + 15) & ~15);     // (an offset from `smem`: the compiler keeps it an LDS address)
     int mixed = 0;   // shifted block: does this window type hold more than one region?  (only the last row / column of windows do)
     if (rel_table) {
         if (tb_regs) {
@@ -1148,8 +1154,11 @@ __global__ __launch_bounds__(NW * 64, (NT >= 8 && NT <= 9) ? 3 : 1) void window_
             const int hw = rid_own >> 1;
             lo.x = hw == 0 ? hv : 0u; lo.y = hw == 1 ? hv : 0u; lo.z = hw == 2 ? hv : 0u; lo.w = hw == 3 ? hv : 0u;
             hi.x = hw == 4 ? hv : 0u; hi.y = hw == 5 ? hv : 0u; hi.z = hw == 6 ? hv : 0u; hi.w = hw == 7 ? hv : 0u;
-            *(uint4*)(Oh + e * 32) = lo;
-            *(uint4*)(Oh + e * 32 + 16) = hi;
+            const int osw = (e >> 1) & 3;
+            *(uint4*)(Oh + e * QK_PITCH + ((0 ^ osw) << 4)) = lo;
+            *(uint4*)(Oh + e * QK_PITCH + ((1 ^ osw) << 4)) = hi;
+            *(uint4*)(Oh + e * QK_PITCH + ((2 ^ osw) << 4)) = make_uint4(0, 0, 0, 0);
+            *(uint4*)(Oh + e * QK_PITCH + ((3 ^ osw) << 4)) = make_uint4(0, 0, 0, 0);
             if (rid_own != rid_first) mixed = 1;
         }
         mixed = __syncthreads_or(mixed);
@@ -1159,9 +1168,16 @@ __global__ __launch_bounds__(NW * 64, (NT >= 8 && NT <= 9) ? 3 : 1) void window_
     }
     __syncthreads();
 
+    // what a lane needs of the key side does not depend on the query tile: the table index of its 4 keys per key tile (ws % 4 == 0: 4 consecutive
+    // keys share an image row, their table entries are 4 consecutive floats)
+    const int sw = (qd ^ ((r16 >> 1) & 3)) << 4;          // ((16 t + r16) >> 1) & 3 == (r16 >> 1) & 3
+    const bool row4 = rel_table && (ws & 3) == 0;
+    int kidx[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) kidx[kt] = row4 ? Kidx[kt * 16 + qd * 4] : 0;
+
 #pragma unroll 1
     for (int qt = wave; qt < NT; qt += nw) {
-        const int sw = (qd ^ ((r16 >> 1) & 3)) << 4;      // ((16 t + r16) >> 1) & 3 == (r16 >> 1) & 3
         const bf16x8_t qf = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Qs + (qt * 16 + r16) * QK_PITCH + sw));
         const int query = qt * 16 + r16;
         // S^T = K Q^T with the bias (+ mask) as the accumulator's initial value: a lane owns query `query` and keys 16 kt + 4 qd .. + 3 of every key tile.
@@ -1172,38 +1188,52 @@ __global__ __launch_bounds__(NW * 64, (NT >= 8 && NT <= 9) ? 3 : 1) void window_
         const int qq = query < N ? query : 0;
         const int yi = qq / ws, xi = qq - yi * ws;
         const int qbase = (yi + ws - 1) * (2 * ws - 1) + xi + ws - 1;
-        bf16x8_t qo = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));      // the query's one-hot region vector: dims 8 qd .. + 7, zeros from 16 up
-        if (mixed && qd < 2) qo = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Oh + qq * 32 + qd * 16));
+        const float* const tbq = Tb + qbase;
+        // straight-line copies of the key loop per bias form (0: expanded [N][N] rows from memory, 1: table, 4 keys per image row, 2: table, any window
+        // size), with and without the region product: left as run-time branches inside the loop they were re-evaluated for every key tile and kept
+        // the compiler from issuing the nine tiles' LDS reads ahead of their MFMAs
+        auto scores = [&](auto form, auto with_regions) {
+            constexpr int FORM = decltype(form)::value;
+            constexpr bool REG = decltype(with_regions)::value;
+            bf16x8_t qo;
+            if constexpr (REG) qo = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Oh + qq * QK_PITCH + ((qd ^ ((qq >> 1) & 3)) << 4)));
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                f32x4 b4;
+                if constexpr (FORM == 1) {
+                    const float* tp = tbq - kidx[kt];
+                    b4 = (f32x4){tp[0], tp[-1], tp[-2], tp[-3]};
+                } else if constexpr (FORM == 2) {
+                    const int4 kk = *(const int4*)(Kidx + kt * 16 + qd * 4);
+                    b4 = (f32x4){tbq[-kk.x], tbq[-kk.y], tbq[-kk.z], tbq[-kk.w]};
+                } else {
+                    const float4 bb = *(const float4*)(brow + kt * 16);
+                    b4 = (f32x4){bb.x, bb.y, bb.z, bb.w};
+                    if (mrow) {
+                        const float4 mm = *(const float4*)(mrow + kt * 16);
+                        b4 += (f32x4){mm.x, mm.y, mm.z, mm.w};
+                    }
+                }
+                const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Ks + (kt * 16 + r16) * QK_PITCH + sw));
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, b4, 0, 0, 0);
+                if constexpr (REG) {
+                    const bf16x8_t ko = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Oh + (kt * 16 + r16) * QK_PITCH + sw));
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ko, qo, s[kt], 0, 0, 0);
+                }
+            }
+        };
+        using std::integral_constant;
+        if (!rel_table) scores(integral_constant<int, 0>{}, std::false_type{});
+        else if (row4) {
+            if (mixed) scores(integral_constant<int, 1>{}, std::true_type{});
+            else scores(integral_constant<int, 1>{}, std::false_type{});
+        } else {
+            if (mixed) scores(integral_constant<int, 2>{}, std::true_type{});
+            else scores(integral_constant<int, 2>{}, std::false_type{});
+        }
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            f32x4 b4;
-            if (rel_table) {
-                if ((ws & 3) == 0) {   // 4 consecutive keys share an image row: their table entries are 4 consecutive floats
-                    const float* tp = Tb + (qbase - Kidx[kt * 16 + qd * 4]);
-                    b4 = (f32x4){tp[0], tp[-1], tp[-2], tp[-3]};
-                } else {
-                    const int4 kk = *(const int4*)(Kidx + kt * 16 + qd * 4);
-                    b4 = (f32x4){Tb[qbase - kk.x], Tb[qbase - kk.y], Tb[qbase - kk.z], Tb[qbase - kk.w]};
-                }
-            } else {
-                const float4 bb = *(const float4*)(brow + kt * 16);
-                b4 = (f32x4){bb.x, bb.y, bb.z, bb.w};
-                if (mrow) {
-                    const float4 mm = *(const float4*)(mrow + kt * 16);
-                    b4 += (f32x4){mm.x, mm.y, mm.z, mm.w};
-                }
-            }
-            const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Ks + (kt * 16 + r16) * QK_PITCH + sw));
-            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, b4, 0, 0, 0);
-            if (mixed) {
-                bf16x8_t ko = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
-                if (qd < 2) ko = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Oh + (kt * 16 + r16) * 32 + qd * 16));
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ko, qo, s[kt], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+        for (int kt = 0; kt < NT; ++kt) { mx = wa_max3(mx, s[kt][0], s[kt][1]); mx = wa_max3(mx, s[kt][2], s[kt][3]); }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         // p = 2^((s - mx) log2 e): one packed fma + two v_exp_f32 per pair of scores, the row sum in packed adds
@@ -1267,7 +1297,7 @@ static int window_attention_launch(const void* q, const void* k, const void* v, 
     const int NT = (N + 15) / 16;
     const int NP = NT * 16, NP2 = ((NT + 1) / 2) * 32;
     size_t lds = (size_t)2 * NP * 64 + (size_t)NP2 * 64;
-    if (rel_table) lds += ((size_t)2 * (2 * ws - 1) * (2 * ws - 1) + 4) * 4 + (size_t)NP * 4 + 16 + (size_t)NP * 32;
+    if (rel_table) lds += ((size_t)2 * (2 * ws - 1) * (2 * ws - 1) + 4) * 4 + (size_t)NP * 4 + 16 + (size_t)NP * 64;
     if (!rel_table) ws = 1;
     const dim3 grid(H, B), block(256);
     hipStream_t s = (hipStream_t)stream;
