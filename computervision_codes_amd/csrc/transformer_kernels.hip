@@ -301,11 +301,22 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
+__device__ __forceinline__ float wa_max3(float a, float b, float c) {      // (fmaxf chains compile to v_max_f32 + canonicalising copies: 47 instructions for 36 scores)
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+typedef short wa_v4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 wa_read_tr(const char* p) {     // ds_read_b64_tr_b16 (EXEC must be all ones where it is used)
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((wa_v4s_t __attribute__((address_space(3)))*)(uintptr_t)p));
+}
+
 // ---- multi-head attention core on the matrix units, large head dim (Q2L encoder / decoders: 4 heads x 256, 144 keys): bf16, no
 // bias / mask, Nk <= 16*NKT keys.  One workgroup = 64 queries of one (batch, head), a wave owns 16 of them.  As in the window kernel,
 // S^T = K Q^T leaves a lane with ONE query column (softmax = 2 xor-shuffles) and the probabilities are already the B operand of
-// O^T = V^T P^T.  The head dim runs through LDS in chunks of 64: K rows [key][64] for the scores, then V^T [64][key] for the output;
-// the wave's Q fragments (16 queries x HD, pre-scaled) stay in registers.
+// O^T = V^T P^T.  The head dim runs through LDS in chunks of 64: K rows [key][64] for the scores, then V rows [key][64] for the output, read
+// back transposed by `ds_read_b64_tr_b16` (the V^T image of rounds 1-3 was written with two-byte stores: 67 % of the kernel's LDS cycles were
+// bank conflicts); the wave's Q fragments (16 queries x HD, pre-scaled) stay in registers.
 template <int NKT, int HD>
 __global__ __launch_bounds__(256) void mha_mfma_kernel(const u16* __restrict__ q, const u16* __restrict__ k, const u16* __restrict__ v,
                                                        u16* __restrict__ out, int Nq, int Nk, int q_stride, int k_stride, int v_stride,
@@ -315,12 +326,13 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const u16* __restrict__ q
     constexpr int K_PITCH = 160;                 // bytes per K row of a chunk (128 used): conflict-free b128 fragment reads under the REAL lane grouping of
                                                  // ds_read_b128 ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md); 144 (rounds 1-3: conflict-free for 16 consecutive
                                                  // lanes) measured SQ_LDS_BANK_CONFLICT = 69 % of this kernel's LDS cycles (profiles/r04_swin_kernel_counters.txt)
-    constexpr int VT_PITCH = (NKP2 + 8) * 2;     // bytes per V^T row
+    constexpr int V_PITCH = 128;                 // bytes per V row of a chunk: 4 spans of 32 B (16 head dims each); span dt of key k sits at dt ^ ((k >> 1) & 3), so the
+                                                 // 8 keys a 32-lane half of a transposed read takes fall on 8 different bank groups
     constexpr int NCH = HD / 64;
-    static_assert(HD % 64 == 0 && NKP * K_PITCH <= 64 * VT_PITCH + NKP * K_PITCH, "shape");
+    static_assert(HD % 64 == 0, "shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                    // [NKP][K_PITCH]
-    char* Vt = smem + NKP * K_PITCH;    // [64][VT_PITCH]
+    char* Vs = smem + NKP * K_PITCH;    // [NKP2][V_PITCH]
     const int h = blockIdx.x, b = blockIdx.y, q0 = blockIdx.z * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, qd = lane >> 4;
@@ -373,19 +385,27 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const u16* __restrict__ q
     // softmax over the keys of this lane's query column: lane holds keys 16kt + 4qd .. +3
     float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 4; ++e)
             if (kt * 16 + qd * 4 + e >= Nk) s[kt][e] = -1e30f;
-            mx = fmaxf(mx, s[kt][e]);
-        }
+        mx = wa_max3(mx, s[kt][0], s[kt][1]);
+        mx = wa_max3(mx, s[kt][2], s[kt][3]);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
+    constexpr float L2E = 1.4426950408889634f;       // p = 2^((s - mx) log2 e): a packed fma + two v_exp_f32 per pair of scores
+    const float nmx = -mx * L2E;
+    mt4_f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { s[kt][e] = __expf(s[kt][e] - mx); sum += s[kt][e]; }
+    for (int kt = 0; kt < NKT; ++kt) {
+        const mt4_f32x2 t0 = (mt4_f32x2){s[kt][0], s[kt][1]} * L2E + nmx, t1 = (mt4_f32x2){s[kt][2], s[kt][3]} * L2E + nmx;
+        const mt4_f32x2 e0 = {__builtin_amdgcn_exp2f(t0.x), __builtin_amdgcn_exp2f(t0.y)}, e1 = {__builtin_amdgcn_exp2f(t1.x), __builtin_amdgcn_exp2f(t1.y)};
+        sum2 += e0;
+        sum2 += e1;
+        s[kt] = (f32x4){e0.x, e0.y, e1.x, e1.y};
+    }
+    float sum = sum2.x + sum2.y;
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
@@ -400,7 +420,7 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const u16* __restrict__ q
     }
     for (int c = 0; c < NCH; ++c) {
         __syncthreads();   // previous chunk's (or the K chunk's) readers are done
-        {   // V chunk, transposed: Vt[d][key] (loads first, as for K)
+        {   // V chunk, rows of 64 dims like K (loads first, as for K)
             constexpr int SI = (NKP2 * 8 + 255) / 256;
             uint4 vreg[SI];
 #pragma unroll
@@ -412,11 +432,7 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const u16* __restrict__ q
 #pragma unroll
             for (int i = 0; i < SI; ++i) {
                 const int e = tid + i * 256, row = e >> 3, pc = e & 7;
-                if (e < NKP2 * 8) {
-                    const u16* ve = (const u16*)&vreg[i];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) *(u16*)(Vt + (pc * 8 + j) * VT_PITCH + row * 2) = ve[j];
-                }
+                if (e < NKP2 * 8) *(uint4*)(Vs + row * V_PITCH + (((((pc >> 1) ^ ((row >> 1) & 3)) << 1) | (pc & 1)) << 4)) = vreg[i];
             }
         }
         __syncthreads();
@@ -427,9 +443,11 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const u16* __restrict__ q
         for (int kb = 0; kb < (NKT + 1) / 2; ++kb)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const char* vr = Vt + (dt * 16 + r16) * VT_PITCH + (kb * 32 + qd * 4) * 2;
-                const uint2 v0 = *(const uint2*)vr;
-                const uint2 v1 = *(const uint2*)(vr + 32);
+                // lane 4 q + p of the 16-lane group qd supplies key 32 kb (+ 16) + 4 qd + q, dims 16 dt + 4 p .. + 3 and receives dim 16 dt + r16 of the 4 keys
+                const int vkey = qd * 4 + (r16 >> 2), vp = r16 & 3;
+                const char* vr = Vs + (kb * 32 + vkey) * V_PITCH + ((((dt ^ ((vkey >> 1) & 3)) << 1) | (vp >> 1)) << 4) + (vp & 1) * 8;
+                const uint2 v0 = wa_read_tr(vr);
+                const uint2 v1 = wa_read_tr(vr + 16 * V_PITCH);
                 const uint4 vf = make_uint4(v0.x, v0.y, v1.x, v1.y);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[kb]), o[dt], 0, 0, 0);
             }
@@ -746,7 +764,7 @@ extern "C" int mt4_attention(const void* q, const void* k, const void* v, void* 
         {
             const int nkt = cdiv(Nk, 16);
             const dim3 grid(H, B, cdiv(Nq, 64)), block(256);
-#define MHA_LAUNCH_HD(NKTV, HDV) { constexpr int nkp = NKTV * 16, nkp2 = ((NKTV + 1) / 2) * 32; const size_t lds = (size_t)nkp * 160 + 64 * ((nkp2 + 8) * 2); \
+#define MHA_LAUNCH_HD(NKTV, HDV) { constexpr int nkp = NKTV * 16, nkp2 = ((NKTV + 1) / 2) * 32; const size_t lds = (size_t)nkp * 160 + (size_t)nkp2 * 128; \
             hipLaunchKernelGGL((mha_mfma_kernel<NKTV, HDV>), grid, block, lds, s, (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, Nq, Nk, \
                                q_stride, k_stride, v_stride, o_stride, scale); }
 #define MHA_LAUNCH(NKTV) { if (hd == 256) MHA_LAUNCH_HD(NKTV, 256) else MHA_LAUNCH_HD(NKTV, 384) }
@@ -1033,15 +1051,6 @@ extern "C" int mt4_kd_mix(const float* s, const float* tea_i, const float* tea_v
 // for e >= 4; the V^T fragment is read in the same order), so P never touches LDS.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float wa_max3(float a, float b, float c) {      // (fmaxf chains compile to v_max_f32 + canonicalising copies: 47 instructions for 36 scores)
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-typedef short wa_v4s_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint2 wa_read_tr(const char* p) {     // ds_read_b64_tr_b16 (EXEC must be all ones: the query-tile loops are wave-uniform)
-    return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((wa_v4s_t __attribute__((address_space(3)))*)(uintptr_t)p));
-}
 
 template <int NT, int NW = 4>  // key/query tiles of 16; waves per workgroup
 // (at 8 - 9 tiles -- Swin's 12 x 12 windows -- the kernel is held to 168 registers = three waves per SIMD: 10 spilled registers, +3 % unmasked and
