@@ -1254,13 +1254,17 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
         if (a.bias && n < a.Cout) { const float4 t = *(const float4*)(a.bias + n); bias4v[i] = (f32x4){t.x, t.y, t.z, t.w}; }
     }
     const int p0 = __builtin_amdgcn_readfirstlane((img * a.Hs + c0) * a.Ws + cs0);   // frame pixel of LDS pixel 0
-    int base[MT];                                  // wave-uniform part of the LDS pixel of tile j (scalar registers); + lane_px per lane
+    int base[MT], trow[MT], tcol0[MT];             // wave-uniform: LDS pixel of tile j (+ lane_px per lane), its conv row and first column
     const int lane_px = r16 + (q >> 1);
+    const int wave_m_u = __builtin_amdgcn_readfirstlane(wave_m);
+    const unsigned tpr_magic = 65536u / (unsigned)tpr + 1u;       // t / tpr == (t * magic) >> 16 for t < 5 tpr <= 320, tpr <= 64 (scalar unit: no division there)
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const int t = min(wave_m + 4 * j, ntile - 1);
-        const int row = t / tpr;
-        base[j] = __builtin_amdgcn_readfirstlane(row * a.rs + (t - row * tpr) * 16);
+        const int t = min(wave_m_u + 4 * j, ntile - 1);
+        const int row = (int)(((unsigned)t * tpr_magic) >> 16);
+        trow[j] = row;
+        tcol0[j] = (t - row * tpr) * 16;
+        base[j] = row * a.rs + tcol0[j];
     }
     const v4u rsx = make_srd(a.x, a.x_bytes);
     const v4u rsw = make_srd(a.w, a.w_bytes);
@@ -1334,24 +1338,31 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int jj = 0; jj < MTP; ++jj)
-                if (ps * MTP + jj < MT)
-                    res[i][ps * MTP + jj] = make_uint2(pack_bf16x2(fmaxf(acc[i][jj][0], 0.f), fmaxf(acc[i][jj][1], 0.f)),
-                                                       pack_bf16x2(fmaxf(acc[i][jj][2], 0.f), fmaxf(acc[i][jj][3], 0.f)));
+                if (ps * MTP + jj < MT) {      // ReLU on the packed pair: rounding commutes with it, one integer max with 0 per dword (-0.0 -> +0)
+                    uint2 o = make_uint2(pack_bf16x2(acc[i][jj][0], acc[i][jj][1]), pack_bf16x2(acc[i][jj][2], acc[i][jj][3]));
+                    asm("v_pk_max_i16 %0, %0, 0" : "+v"(o.x));
+                    asm("v_pk_max_i16 %0, %0, 0" : "+v"(o.y));
+                    res[i][ps * MTP + jj] = o;
+                }
     }
     __syncthreads();   // the conv rows go over the operands
 
     // conv tile: pixel (row, column - cs0) at (row * ctw + col) * 128 B, 16-byte chunks XOR-swizzled with col & 7 (columns the pooling does not
     // read are dropped: the wide form stays under 80 KB = two workgroups per CU)
+    int wr_lane[NT];      // lane part of the address (a tile's first column is a multiple of 16: (col & 7) == (r16 & 7))
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int cb = (wave_n * 32 + i * 16 + q * 4) * 2;
+        wr_lane[i] = r16 * 128 + (((cb >> 4) ^ (r16 & 7)) << 4) + (cb & 8);
+    }
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const int t = wave_m + 4 * j;
-        if (t < ntile) {
-            const int row = __builtin_amdgcn_readfirstlane(t / tpr);
-            const int col = __builtin_amdgcn_readfirstlane((t - row * tpr) * 16) + r16;
+        if (wave_m_u + 4 * j < ntile) {
+            const int col0 = tcol0[j];
+            const int wr_tile = (trow[j] * a.ctw + col0) * 128;             // wave-uniform
+            if (col0 + r16 < a.ctw) {
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int cb = (wave_n * 32 + i * 16 + q * 4) * 2;
-                if (col < a.ctw) *(uint2*)(smem + (row * a.ctw + col) * 128 + (((cb >> 4) ^ (col & 7)) << 4) + (cb & 8)) = res[i][j];
+                for (int i = 0; i < NT; ++i) *(uint2*)(smem + wr_tile + wr_lane[i]) = res[i][j];
             }
         }
     }
@@ -1365,23 +1376,27 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
         const int pc = Q0 + pp - pr * a.wp_seg;
         const int P = P0 + pr;
         if (P >= a.Hp || pc >= a.Wp || c8 * 8 >= a.Cout) continue;
+        // the 3 x 3 window without branches: a tap outside the map is clamped onto its neighbour inside (the maximum does not mind seeing a value
+        // twice; the window's centre is always inside), so every thread runs the same nine 16-byte reads
+        int roff[3], coff[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int jr = min(max(2 * pr + k, -c0), a.Ho - 1 - c0);          // conv row c0 + jr in [0, Ho)
+            roff[k] = jr * a.ctw * 128;
+            const int cr = min(max(2 * pc - 1 + k, 0), a.Wo - 1) - cs0;       // column inside the segment
+            coff[k] = cr * 128 + ((c8 ^ (cr & 7)) << 4);
+        }
         uint4 best = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int jr = 2 * pr + kh;
-            if ((unsigned)(c0 + jr) >= (unsigned)a.Ho) continue;
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int cc = 2 * pc - 1 + kw;
-                if ((unsigned)cc >= (unsigned)a.Wo) continue;
-                const int cr = cc - cs0;              // column inside the segment
-                const uint4 t = *(const uint4*)(smem + (jr * a.ctw + cr) * 128 + ((c8 ^ (cr & 7)) << 4));
+                const uint4 t = *(const uint4*)(smem + roff[kh] + coff[kw]);
                 asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.x) : "v"(t.x));
                 asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.y) : "v"(t.y));
                 asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.z) : "v"(t.z));
                 asm("v_pk_max_u16 %0, %0, %1" : "+v"(best.w) : "v"(t.w));
             }
-        }
         *(uint4*)(a.y + (((long long)img * a.Hp + P) * a.Wp + pc) * (a.Cout * 2) + c8 * 16) = best;
     }
 }
