@@ -1672,6 +1672,9 @@ int auto_tile(int M, int N, int nsteps, int es) {
         if (tiles(2) >= fill) return 2;
         if (tiles(3) >= fill) return 3;
     }
+    // small output, long K (the Q2L decoders' linear2: 768 ... 1920 rows x 1024 channels from K = 8192): the 64 x 64 tile with the deep ring as soon
+    // as it gives 3/4 of a round -- a quarter of the operand bytes the 32 x 32 tile pulls through L2 (1280 rows: 99.7 -> 60.3 us, 1920: 149.8 -> 61.3)
+    if (nsteps >= 32 && N > 32 && tiles(3) >= 192) return 9;
     // not enough work to fill the chip: take the tile with the most blocks
     int best = 6;
     long long best_tiles = -1;
