@@ -107,6 +107,7 @@ class Qeruy2Label:
         if self.loss_type not in ("i", "v", "t", "all"):
             raise ValueError(f"loss_type {self.loss_type}")
         self.tasks = ("i", "v", "t", "ivt") if self.loss_type == "all" else (self.loss_type,)
+        self.batch_decoders = True     # loss_type all: the shared encoder layer once over the four tasks' tokens (decode_all)
         self.teacher_dim = int(getattr(args, "teacher_dim", 512))
         self.cfg = SWIN_CFG[self.backbone_name]
         self.dtype, self.device = dtype, torch.device(device)
@@ -276,19 +277,19 @@ class Qeruy2Label:
                           scale=(d // nhead) ** -0.5)
         return ops.linear(o, *a["out"], residual=residual)
 
-    def decode(self, src_tokens: torch.Tensor, batch: int, task: Optional[str] = None):
-        """`Decoder.forward` (`network.py:163-171`): tokens [B*L, C] -> (feat [B,d] fp32, logits [B,K] fp32)"""
+    def _encode(self, s: torch.Tensor, batch: int, L: int):
+        """the transformer's encoder layer + pooled feature on projected tokens s [batch * L, d] (`transformer.py:64-98`): -> (memory, feat [batch, d] fp32)"""
         p = self._p
-        tp = p["task"][task or self.tasks[0]]
-        L = src_tokens.shape[0] // batch
-        kq = tp["query"].shape[0]
-        s = ops.linear(src_tokens, *tp["in_proj"])
         e = p["enc"]
         sp = ops.add_rowbcast(s, p["pos"])
         s = ops.layernorm(self._mha(e["attn"], sp, sp, s, batch, L, L, residual=s), *e["n1"])
         s = ops.layernorm(ops.linear(ops.linear(s, *e["l1"], act="relu"), *e["l2"], residual=s), *e["n2"])
-        memory = s
-        feat = ops.global_avgpool(memory.view(batch, L, 1, self.hidden))
+        return s, ops.global_avgpool(s.view(batch, L, 1, self.hidden))
+
+    def _decode_queries(self, memory: torch.Tensor, batch: int, L: int, tp):
+        """the decoder layers of one task on its encoder memory [batch * L, d] -> logits [batch, K] fp32"""
+        p = self._p
+        kq = tp["query"].shape[0]
         mem_pos = ops.add_rowbcast(memory, p["pos"])
         tgt = torch.zeros((batch * kq, self.hidden), dtype=self.dtype, device=memory.device)
         for dl in p["dec"]:
@@ -296,8 +297,29 @@ class Qeruy2Label:
             tgt = ops.layernorm(self._mha(dl["attn"], qin, mem_pos, memory, batch, kq, L, residual=tgt), *dl["n2"])
             tgt = ops.layernorm(ops.linear(ops.linear(tgt, *dl["l1"], act="relu"), *dl["l2"], residual=tgt), *dl["n3"])
         hs = ops.layernorm(tgt, *p["dec_norm"])
-        logits = ops.groupwise_linear(hs, tp["W"], tp["b"], batch, kq)
-        return feat, logits
+        return ops.groupwise_linear(hs, tp["W"], tp["b"], batch, kq)
+
+    def decode(self, src_tokens: torch.Tensor, batch: int, task: Optional[str] = None):
+        """`Decoder.forward` (`network.py:163-171`): tokens [B*L, C] -> (feat [B,d] fp32, logits [B,K] fp32)"""
+        tp = self._p["task"][task or self.tasks[0]]
+        L = src_tokens.shape[0] // batch
+        memory, feat = self._encode(ops.linear(src_tokens, *tp["in_proj"]), batch, L)
+        return feat, self._decode_queries(memory, batch, L, tp)
+
+    def decode_all(self, src_tokens: torch.Tensor, batch: int):
+        """the four decoders of `loss_type all` (`network.py:66-73,90-100`).  They share ONE transformer: its encoder layer runs once over the four
+        tasks' projected tokens stacked along the batch axis (rows, attention batches and LayerNorm rows are independent, so every task's memory
+        is bit-identical to its own `decode` call: 4 x fewer, 4 x larger launches); the query side runs per task (6 / 10 / 15 / 100 queries).
+        -> (feat of the last task, {task: logits})"""
+        p = self._p
+        L = src_tokens.shape[0] // batch
+        n = batch * L
+        s = torch.empty((len(self.tasks) * n, self.hidden), dtype=self.dtype, device=src_tokens.device)
+        for i, task in enumerate(self.tasks):
+            ops.linear(src_tokens, *p["task"][task]["in_proj"], out=s[i * n:(i + 1) * n])
+        memory, feat = self._encode(s, len(self.tasks) * batch, L)
+        ys = {task: self._decode_queries(memory[i * n:(i + 1) * n], batch, L, p["task"][task]) for i, task in enumerate(self.tasks)}
+        return feat[(len(self.tasks) - 1) * batch:].contiguous(), ys
 
     def forward(self, input: torch.Tensor, tool=None, verb=None, target=None):
         if self.training:
@@ -311,9 +333,12 @@ class Qeruy2Label:
             ys = {k: torch.zeros((b, n), device=feat.device) for k, n in _K.items()}  # `network.py:85-88`
             ys[self.loss_type] = y
             return (0, ys["i"]), (0, ys["v"]), (0, ys["t"]), (feat, ys["ivt"])
-        ys = {}
-        for task in self.tasks:          # four decoders, shared transformer weights; feat = the last one's (`:100`)
-            feat, ys[task] = self.decode(src, b, task)
+        if self.batch_decoders:
+            feat, ys = self.decode_all(src, b)          # four decoders, shared transformer weights; feat = the last one's (`:100`)
+        else:
+            ys = {}
+            for task in self.tasks:
+                feat, ys[task] = self.decode(src, b, task)
         if tool is None or verb is None or target is None:
             raise TypeError("loss_type 'all' runs the KD mixing unconditionally (network.py:98-124): pass tool, verb, target features")
         p = self._p

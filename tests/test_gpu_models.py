@@ -459,6 +459,22 @@ def test_q2l_loss_type_all_with_kd_vs_reference_golden(cuda, name):
         m(frames.to(cuda))
 
 
+def test_q2l_all_batched_encoder_equals_per_task_decoders(cuda):
+    """`decode_all` (the shared encoder layer once over the four tasks' tokens stacked along the batch axis) against four `decode` calls:
+    identical bits, fp32 and bf16"""
+    _, cfg = load_golden("q2l_swinB_384_all")
+    for dt in (torch.float32, torch.bfloat16):
+        m = _q2l_model(cfg, dt)
+        frames = synth.synthetic_frames(3, cfg["img"], cfg["img"], seed=5).to(cuda)
+        tf = [synth.synthetic_features(3, 512, seed=6 + k)[0].to(cuda) for k in (1, 2, 3)]
+        assert m.batch_decoders
+        a = m(frames, *tf)
+        m.batch_decoders = False
+        b = m(frames, *tf)
+        for x, y in zip(a, b):
+            assert torch.equal(x[1], y[1]) and (torch.equal(x[0], y[0]) if torch.is_tensor(x[0]) else x[0] == y[0])
+
+
 def test_q2l_swinB_384_all_bf16_vs_reference_golden(cuda):
     """BASELINE configs[2] in the mode `bench.py` quotes it in (Swin-B/384, `loss_type all`, bf16) against the REFERENCE golden: DECLARED logit
     error <= 4 % of each head's logit range, feature error <= 2 % of its range, per-head argmax and top-5 sets equal on the golden frame (measured
