@@ -189,6 +189,11 @@ def test_patchify_matches_conv4x4(cuda, dtype):
         rows = ops.patchify(inp, 4, dtype, synth.IMAGENET_MEAN, synth.IMAGENET_STD)
         got = rows.float().cpu() @ w.view(16, 48).t()
         assert (got - ref).abs().max().item() < _tol(dtype, 1e-4, 5e-2)
+    if dtype == torch.bfloat16:   # uint8 frames, P = 4, bf16 rows run a kernel of their own (12 bytes per thread, table-driven): the generic kernel's bits
+        for (b, h, w_) in ((2, 32, 48), (3, 96, 100), (1, 384, 384)):
+            fr = synth.synthetic_frames(b, h, w_, seed=h + w_).to(cuda)
+            assert torch.equal(ops.patchify(fr, 4, torch.bfloat16, synth.IMAGENET_MEAN, synth.IMAGENET_STD),
+                               ops.patchify(fr, 4, torch.float32, synth.IMAGENET_MEAN, synth.IMAGENET_STD).to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("dtype", DT)
