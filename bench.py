@@ -329,10 +329,16 @@ def device_frames(n, h, w, seed, dev, nbase=16):
     return (base[idx % nbase] ^ ((idx // nbase * 37) % 256).to(torch.uint8)[:, None, None, None]).contiguous()
 
 
-def swin_bench(dev, batch=128):
+SWIN_BATCH = {384: 227, 224: 668}     # frames per forward: stage 2 then has 510.75 / 511.4 row tiles of 256 tokens and stage 3 + the decoders 127.7 / 127.9 --
+                                      # whole rounds of the 256 CUs for the GEMMs with 2 or 4 column tiles (proj, fc2, linear2), which at 128 frames run
+                                      # 2.25 / 1.125 rounds (profiles/r04_swin_batch_sweep.txt: 384^2 4398 -> 4702 frames/s, 224^2 10542 -> 12849)
+
+
+def swin_bench(dev, batch=None):
     """BASELINE configs[2]: Swin-B + the CholecT50 triplet head = `loss_type all` (four Q2L decoders over the shared transformer +
     the KD mixing), bf16, frames/s at 384x384 (reference-legal swin_B_384_22k) and 224x224; the single-decoder teacher
-    configuration (`loss_type i`, what Scripts/train_fold1.sh trains) beside it."""
+    configuration (`loss_type i`, what Scripts/train_fold1.sh trains) beside it.  Frames per forward: SWIN_BATCH (and 128, the batch of the
+    rounds before, for the four-decoder configuration)."""
     from computervision_codes_amd import shapes, synth
     from computervision_codes_amd.spatial_transformer import build_q2l
     out = {}
@@ -341,13 +347,16 @@ def swin_bench(dev, batch=128):
             args = types.SimpleNamespace(backbone=name, img_size=img, hidden_dim=1024, loss_type=lt)
             m = build_q2l(args, dtype=torch.bfloat16, device=str(dev)).eval()
             m.load_state_dict(synth.fill_from_shapes(shapes.q2l_param_shapes(name, img, 1024, lt), seed=7))
-            frames = device_frames(batch, img, img, 7, dev)
-            tf = [synth.synthetic_features(batch, 512, seed=7 + k)[0].to(dev) for k in (1, 2, 3)] if lt == "all" else []
-            ms = _time_call(lambda: m(frames, *tf), iters=5)
             ndec = 4 if lt == "all" else 1
             gf = (94.2 + 15.3 * ndec) if img == 384 else (30.9 + 10.2 * ndec)
-            out[f"{name}_{lt}"] = dict(frames_per_s=round(batch / ms * 1e3, 1), ms_per_batch=round(ms, 3), batch=batch, decoders=ndec,
-                                       mfma_frac=round(gf * 1e9 * batch / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
+            for b in ([batch] if batch else ([SWIN_BATCH[img], 128] if lt == "all" else [SWIN_BATCH[img]])):
+                frames = device_frames(b, img, img, 7, dev)
+                tf = [synth.synthetic_features(b, 512, seed=7 + k)[0].to(dev) for k in (1, 2, 3)] if lt == "all" else []
+                ms = _time_call(lambda: m(frames, *tf), iters=5)
+                rec = dict(frames_per_s=round(b / ms * 1e3, 1), ms_per_batch=round(ms, 3), batch=b, decoders=ndec,
+                           mfma_frac=round(gf * 1e9 * b / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
+                out[f"{name}_{lt}" + ("" if b == (batch or SWIN_BATCH[img]) else f"_b{b}")] = rec
+                del frames, tf
             del m
     return out
 

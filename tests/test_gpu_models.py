@@ -475,6 +475,28 @@ def test_q2l_all_batched_encoder_equals_per_task_decoders(cuda):
             assert torch.equal(x[1], y[1]) and (torch.equal(x[0], y[0]) if torch.is_tensor(x[0]) else x[0] == y[0])
 
 
+def test_q2l_swinB_384_bench_batch_rows_equal_small_batch_rows(cuda):
+    """configs[2] as `bench.py` runs it (Swin-B/384, four decoders, bf16, bench.SWIN_BATCH frames per forward: whole rounds of 256 x 256 tiles):
+    a frame's logits and features do not depend on what shares its forward -- frames sampled across the big batch equal the same frames run three at a
+    time (those small batches are what the golden / agreement tests above pin to the reference)"""
+    import bench
+    _, cfg = load_golden("q2l_swinB_384_all")
+    m = _q2l_model(cfg, torch.bfloat16)
+    n = bench.SWIN_BATCH[384]
+    base = synth.synthetic_frames(16, cfg["img"], cfg["img"], seed=11).to(cuda)
+    frames = base.repeat((n + 15) // 16, 1, 1, 1)[:n].contiguous()
+    frames[n - 1] = synth.synthetic_frames(1, cfg["img"], cfg["img"], seed=12).to(cuda)[0]
+    tf = [synth.synthetic_features(n, 512, seed=13 + k)[0].to(cuda) for k in (1, 2, 3)]
+    big = m(frames, *tf)
+    torch.cuda.synchronize()
+    for idx in ([0, 1, 2], [111, 112, 113], [n - 3, n - 2, n - 1]):
+        small = m(frames[idx].contiguous(), *[t[idx].contiguous() for t in tf])
+        for a, b in zip(big, small):
+            assert torch.equal(a[1][idx], b[1]), idx
+        assert torch.equal(big[3][0][idx], small[3][0])
+    assert all(torch.isfinite(o[1]).all() for o in big)
+
+
 def test_q2l_swinB_384_all_bf16_vs_reference_golden(cuda):
     """BASELINE configs[2] in the mode `bench.py` quotes it in (Swin-B/384, `loss_type all`, bf16) against the REFERENCE golden: DECLARED logit
     error <= 4 % of each head's logit range, feature error <= 2 % of its range, per-head argmax and top-5 sets equal on the golden frame (measured
