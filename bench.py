@@ -532,16 +532,18 @@ def spatial_train_bench(dev):
     from computervision_codes_amd import shapes, synth
     from computervision_codes_amd.spatial_cnn_train import SpatialCnnTrainer
     out = {}
+    # (batch 256: layer3 / layer4 of a 64-frame batch give their GEMMs 0.2 ... 0.9 rounds of 256 x 256 tiles; 288 GB of HBM hold far more --
+    #  the step at 256 frames peaks at 31 GB -- and the rate rises 3.6 k -> 4.5 k frames/s)
     for net, B, odt in (("resnet18", 8, torch.float32), ("resnet50", 8, torch.float32), ("resnet50", 64, torch.float32), ("resnet50", 8, torch.bfloat16),
-                        ("resnet50", 64, torch.bfloat16)):
+                        ("resnet50", 64, torch.bfloat16), ("resnet50", 256, torch.bfloat16), ("resnet18", 256, torch.bfloat16)):
         H, W = 256, 448
         tr = SpatialCnnTrainer(net, lr=0.01, device=str(dev), operand_dtype=odt).load_state_dict(synth.fill_from_shapes(shapes.spatial_cnn_shapes(net), seed=5))
-        frames = synth.synthetic_frames(B, H, W, seed=1).to(dev)
+        frames = synth.synthetic_frames(B, H, W, seed=1).to(dev) if B <= 64 else device_frames(B, H, W, 1, dev)
         z = torch.cat([torch.from_numpy((synth.uniform01(5, i, B * k) < 0.15).reshape(B, k).astype(np.float32)) for i, k in
                        enumerate((6, 10, 15, 100))], 1).to(dev)
         tp = [synth.synthetic_features(B, k, seed=11 + i)[0].to(dev) for i, k in enumerate((6, 10, 15))]
         tf = [synth.synthetic_features(B, 1536, seed=21 + i)[0].to(dev) for i in range(3)]
-        ms = _time_call(lambda: tr.train_step(frames, z, tp, tf, use_graph=True), iters=10)
+        ms = _time_call(lambda: tr.train_step(frames, z, tp, tf, use_graph=True), iters=10 if B <= 64 else 4)
         bf = odt == torch.bfloat16
         out[f"{net}_b{B}_{H}x{W}" + ("_bf16" if bf else "")] = dict(
             ms_per_step=round(ms, 3), frames_per_s=round(B / ms * 1e3, 1), dtype="bf16 GEMM operands, fp32 master weights / sums" if bf else "f32",
@@ -847,6 +849,10 @@ def main():
             sw = res["swin_q2l"].get("swin_B_384_22k_all") or {}
             roofline.update(swin_b384_all_fps=sw.get("frames_per_s"), swin_b384_all_frac=sw.get("mfma_frac"))
             res["spatial_train"] = spatial_train_bench(dev)
+            st = res["spatial_train"]
+            roofline.update(train_resnet50_b64_bf16_fps=(st.get("resnet50_b64_256x448_bf16") or {}).get("frames_per_s"),
+                            train_resnet50_b256_bf16_fps=(st.get("resnet50_b256_256x448_bf16") or {}).get("frames_per_s"),
+                            train_resnet18_b256_bf16_fps=(st.get("resnet18_b256_256x448_bf16") or {}).get("frames_per_s"))
             res["e2e_script"] = e2e_script_bench(dev)
             res["parity_mode_f32"] = parity_mode_bench(dev, a.network, a.height, a.width)
         if world == 1 and not a.no_cpu_baseline:
