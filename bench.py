@@ -342,13 +342,16 @@ def swin_bench(dev, batch=None):
     from computervision_codes_amd import shapes, synth
     from computervision_codes_amd.spatial_transformer import build_q2l
     out = {}
-    for name, img in (("swin_B_384_22k", 384), ("swin_B_224_22k", 224)):
-        for lt in ("all", "i"):
-            args = types.SimpleNamespace(backbone=name, img_size=img, hidden_dim=1024, loss_type=lt)
+    # (the last row: the teacher Scripts/train_fold1.sh ships -- Swin-L/384, hidden 1536, one decoder; 2 x 103.9 GMAC backbone + the decoder at d = 1536)
+    for name, img, hidden, lts in (("swin_B_384_22k", 384, 1024, ("all", "i")), ("swin_B_224_22k", 224, 1024, ("all", "i")), ("swin_L_384_22k", 384, 1536, ("i",))):
+        for lt in lts:
+            args = types.SimpleNamespace(backbone=name, img_size=img, hidden_dim=hidden, loss_type=lt)
             m = build_q2l(args, dtype=torch.bfloat16, device=str(dev)).eval()
-            m.load_state_dict(synth.fill_from_shapes(shapes.q2l_param_shapes(name, img, 1024, lt), seed=7))
+            m.load_state_dict(synth.fill_from_shapes(shapes.q2l_param_shapes(name, img, hidden, lt), seed=7))
             ndec = 4 if lt == "all" else 1
             gf = (94.2 + 15.3 * ndec) if img == 384 else (30.9 + 10.2 * ndec)
+            if name.startswith("swin_L"):
+                gf = 207.8 + 15.3 * ndec * (1536 / 1024) ** 2
             for b in ([batch] if batch else ([SWIN_BATCH[img], 128] if lt == "all" else [SWIN_BATCH[img]])):
                 frames = device_frames(b, img, img, 7, dev)
                 tf = [synth.synthetic_features(b, 512, seed=7 + k)[0].to(dev) for k in (1, 2, 3)] if lt == "all" else []
@@ -847,7 +850,9 @@ def main():
                 res["student_resnet18"] = student_resnet18_bench(dev, a.streams)
             res["swin_q2l"] = swin_bench(dev)
             sw = res["swin_q2l"].get("swin_B_384_22k_all") or {}
-            roofline.update(swin_b384_all_fps=sw.get("frames_per_s"), swin_b384_all_frac=sw.get("mfma_frac"))
+            swl = res["swin_q2l"].get("swin_L_384_22k_i") or {}
+            roofline.update(swin_b384_all_fps=sw.get("frames_per_s"), swin_b384_all_frac=sw.get("mfma_frac"), swin_b384_all_frames_per_forward=sw.get("batch"),
+                            swin_l384_teacher_fps=swl.get("frames_per_s"), swin_l384_teacher_frac=swl.get("mfma_frac"))
             res["spatial_train"] = spatial_train_bench(dev)
             st = res["spatial_train"]
             roofline.update(train_resnet50_b64_bf16_fps=(st.get("resnet50_b64_256x448_bf16") or {}).get("frames_per_s"),

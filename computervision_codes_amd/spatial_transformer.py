@@ -55,7 +55,7 @@ def _rel_pos_index(ws: int) -> torch.Tensor:
 
 
 def _shift_regions(res: int, ws: int, shift: int) -> torch.Tensor:
-    """`swin_transformer.py:210-221`: region id of every token of every window type, [nW, N]"""
+    """`swin_transformer.py:210-221`: region id of every token of every window type, [nW, N] (ids 0 .. 8: `mt4_window_attention_rel_bf16` takes 0 .. 15)"""
     img = torch.zeros((res, res))
     cnt = 0
     for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
