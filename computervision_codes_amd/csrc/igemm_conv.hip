@@ -676,8 +676,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * KS * 64) void igemm_conv_kernel
 // through L2 -> LDS per 64-channel slice), and the K-loop of the N <= 128 layers waits on exactly that fill.  Here the INPUT PATCH
 // of the pixel tile is staged once per slice: output pixels are linear in (b, h, w) and so are input pixels (same H x W), so tap
 // (kh, kw) of tile row r is patch row r + kh*W + kw of the linear pixel range [m0 - W - 1, m0 + BM + W + 1).  A tap that leaves the
-// image (wraps to the neighbouring row / image in linear space) is zeroed on the pixel fragment: 9 validity bits per lane and
-// m-tile, one v_bfe + 8 v_and per m-tile and K-step.  Fill per slice: (BM + 2W + 2) + 9*BN rows instead of 9*(BM + BN).
+// image (wraps to the neighbouring row / image in linear space) contributes zeros: 9 validity bits per lane and
+// m-tile; such a tap reads a row of zeros (a select on the LDS address).  Fill per slice: (BM + 2W + 2) + 9*BN rows instead of 9*(BM + BN).
 // Epilogue: bias (in the accumulators) + optional residual + optional ReLU.
 // Same K walk (slice outer, taps inner) and the same MFMA chain as the generic kernel: results are bit-identical.
 // Weight K-steps (BN rows x 128 B) run through a ring of WS stages, issued WS-1 steps ahead: a K-step of the narrow tiles is shorter
@@ -744,6 +744,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 
         vm[j] = (ho > 0 ? wv : 0) | (wv << 3) | (ho < a.H - 1 ? wv << 6 : 0);
     }
 
+    const int zr = BM + 2 * a.W + 2;             // patch rows the taps reach; row zr holds zeros (see compute)
     const int shift = (a.W + 1) * a.pix_bytes;   // the patch starts W+1 pixels in front of the tile's first pixel
     const v4u rsx = make_srd(a.x - shift, a.x_bytes + (unsigned)shift);
     const v4u rsw = make_srd(a.w, a.w_bytes);
@@ -763,7 +764,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 
     auto issue_patch = [&](int piece, int cs, int buf) {
         if (piece * RPP + wave_u * 8 < pra) {   // wave-uniform: the last piece covers only the allocated rows
             const int p = m0 + piece * RPP + ld_row;   // linear pixel index + (W+1)
-            const unsigned v[1] = {p >= a.W + 1 ? (unsigned)(p * a.pix_bytes + gch * 16) : OOB};
+            // (rows behind the BM + 2W + 2 the taps reach are fetched out of range = written as ZEROS: the first of them is the row invalid taps read)
+            const unsigned v[1] = {(p >= a.W + 1 && piece * RPP + ld_row < zr) ? (unsigned)(p * a.pix_bytes + gch * 16) : OOB};
             lds_dma16_group<1, 0>(rsx, v, (unsigned)__builtin_amdgcn_readfirstlane(cs * 128),
                                   lds_base + buf * patch_bytes + piece * (RPP * 128) + wave_u * 1024);
         }
@@ -773,22 +775,25 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 
         lds_dma16_group<NLD_W, RPP * 128>(rsw, woff, (unsigned)__builtin_amdgcn_readfirstlane(wstep * 128), w_base + stage * WSTAGE + wave_u * 1024);
     };
     const int rd_w = (wave_n * WN + r16) * 128;
+    // a tap that leaves the image reads a ROW OF ZEROS instead of the patch: one select on the fragment's LDS address per m-tile and tap.  (Zeroing the
+    // fragment itself cost 8 v_and per m-tile and K-step -- with the address arithmetic 2 VALU instructions per MFMA, and on this chip VALU and MFMA
+    // issue do not overlap within a SIMD: instruction mix 1344 MFMA x 16 cycles + 2661 VALU x 4 cycles = the wave's lifetime x 1 / 4 waves per SIMD.)
+    // The row: patch row zr = BM + 2W + 2, the first one behind those the taps reach (the host allocates at least one), zero-filled by the staging DMA itself.
     auto compute = [&](const char* pb, const char* wb, int toff, int tap) {
         const int prow = wave_m * WM + r16 + toff;
-        unsigned msk[MT];
+        const int tbit = 1 << tap;
+        const char* xr[MT];
 #pragma unroll
-        for (int j = 0; j < MT; ++j) msk[j] = (unsigned)__builtin_amdgcn_sbfe(vm[j], (unsigned)tap, 1u);
+        for (int j = 0; j < MT; ++j) xr[j] = pb + ((vm[j] & tbit) ? prow + j * 16 : zr) * 128;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const int swx = ((kk * 4 + q) ^ (prow & 7)) << 4;
+            const int swx = ((kk * 4 + q) ^ (prow & 7)) << 4;     // (any swizzle of the zero row reads zeros)
             const int sww = ((kk * 4 + q) ^ (r16 & 7)) << 4;
             uint4 fx[MT], fw[NT];
 #pragma unroll
-            for (int j = 0; j < MT; ++j) fx[j] = *(const uint4*)(pb + (prow + j * 16) * 128 + swx);
+            for (int j = 0; j < MT; ++j) fx[j] = *(const uint4*)(xr[j] + swx);
 #pragma unroll
             for (int i = 0; i < NT; ++i) fw[i] = *(const uint4*)(wb + rd_w + i * 16 * 128 + sww);
-#pragma unroll
-            for (int j = 0; j < MT; ++j) { fx[j].x &= msk[j]; fx[j].y &= msk[j]; fx[j].z &= msk[j]; fx[j].w &= msk[j]; }
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -1566,7 +1571,7 @@ int launch_patch3x3(const ConvK& k, hipStream_t s) {
     }
     constexpr int threads = WM_ * WN_ * 64;
     constexpr int rpp = threads / 8;
-    const int pra = (BM + 2 * k.W + 2 + 7) / 8 * 8;
+    const int pra = (BM + 2 * k.W + 2 + 1 + 7) / 8 * 8;      // + 1: the row of zeros out-of-image taps read
     const int npatch = k.SPT > 1 ? 2 : 1;
     constexpr int epi = BM / (BN >= 256 ? 4 : 2) * (BN * 4 + 16);
     int lds = npatch * pra * 128 + WS * BN * 128;
