@@ -1190,10 +1190,10 @@ __global__ __launch_bounds__(NW * 64, (NT >= 8 && NT <= 9) ? 3 : 1) void window_
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int e = tid + i * nth;
-                if (e < 2 * T + 4) Tb[e] = tbv[i];
+                if (e < 2 * T + 4) Tb[2 * T + 3 - e] = tbv[i];      // the table is kept REVERSED in LDS (see the score loop)
             }
         } else {
-            for (int e = tid; e < 2 * T + 4; e += nth) Tb[e] = e < T ? rel_table[(long long)h * T + e] : -1e30f;
+            for (int e = tid; e < 2 * T + 4; e += nth) Tb[2 * T + 3 - e] = e < T ? rel_table[(long long)h * T + e] : -1e30f;
         }
         if (tid < NP) {
             const int e = tid;
@@ -1238,7 +1238,9 @@ __global__ __launch_bounds__(NW * 64, (NT >= 8 && NT <= 9) ? 3 : 1) void window_
         const int qq = query < N ? query : 0;
         const int yi = qq / ws, xi = qq - yi * ws;
         const int qbase = (yi + ws - 1) * (2 * ws - 1) + xi + ws - 1;
-        const float* const tbq = Tb + qbase;
+        // table entry qbase - k sits at Tb[2T + 3 - qbase + k]: the 4 consecutive keys of a lane (entries qbase - k0, ... - 3) are 4 ASCENDING floats that land
+        // in the accumulator's register order -- read in the table's own order they arrived reversed and cost a v_mov each (36 per query tile)
+        const float* const tbq = Tb + (2 * T + 3 - qbase);
         // straight-line copies of the key loop per bias form (0: expanded [N][N] rows from memory, 1: table, 4 keys per image row, 2: table, any window
         // size), with and without the region product: left as run-time branches inside the loop they were re-evaluated for every key tile and kept
         // the compiler from issuing the nine tiles' LDS reads ahead of their MFMAs
@@ -1251,11 +1253,11 @@ __global__ __launch_bounds__(NW * 64, (NT >= 8 && NT <= 9) ? 3 : 1) void window_
             for (int kt = 0; kt < NT; ++kt) {
                 f32x4 b4;
                 if constexpr (FORM == 1) {
-                    const float* tp = tbq - kidx[kt];
-                    b4 = (f32x4){tp[0], tp[-1], tp[-2], tp[-3]};
+                    const float* tp = tbq + kidx[kt];
+                    b4 = (f32x4){tp[0], tp[1], tp[2], tp[3]};
                 } else if constexpr (FORM == 2) {
                     const int4 kk = *(const int4*)(Kidx + kt * 16 + qd * 4);
-                    b4 = (f32x4){tbq[-kk.x], tbq[-kk.y], tbq[-kk.z], tbq[-kk.w]};
+                    b4 = (f32x4){tbq[kk.x], tbq[kk.y], tbq[kk.z], tbq[kk.w]};
                 } else {
                     const float4 bb = *(const float4*)(brow + kt * 16);
                     b4 = (f32x4){bb.x, bb.y, bb.z, bb.w};
