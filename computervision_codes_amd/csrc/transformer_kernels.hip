@@ -1132,16 +1132,18 @@ __global__ __launch_bounds__(NW * 64, (NT >= 8 && NT <= 9) ? 3 : 1) void window_
     // workgroup's lifetime
     constexpr int SI = (NP * 4 + nth - 1) / nth;
     uint4 qv[SI], kv[SI], vv[SI];
+    const u16* const qb = q + (long long)b * N * q_stride + h * 32;
+    const u16* const kb = k + (long long)b * N * k_stride + h * 32;
+    const u16* const vb = v + (long long)b * N * v_stride + h * 32;
 #pragma unroll
     for (int i = 0; i < SI; ++i) {
         const int e = tid + i * nth;
         const int row = e >> 2, pc = e & 3;
         qv[i] = make_uint4(0, 0, 0, 0); kv[i] = make_uint4(0, 0, 0, 0); vv[i] = make_uint4(0, 0, 0, 0);
-        if (row < N) {
-            const long long r = (long long)b * N + row;
-            qv[i] = *(const uint4*)(q + r * q_stride + h * 32 + pc * 8);
-            kv[i] = *(const uint4*)(k + r * k_stride + h * 32 + pc * 8);
-            vv[i] = *(const uint4*)(v + r * v_stride + h * 32 + pc * 8);
+        if (row < N) {      // (workgroup-uniform bases + 32-bit lane offsets: the 64-bit address arithmetic per load was a tenth of the kernel's VALU work)
+            qv[i] = *(const uint4*)(qb + (unsigned)(row * q_stride + pc * 8));
+            kv[i] = *(const uint4*)(kb + (unsigned)(row * k_stride + pc * 8));
+            vv[i] = *(const uint4*)(vb + (unsigned)(row * v_stride + pc * 8));
         }
     }
     // the window type's region ids (shifted blocks) travel with the first round of loads too: fetched where they are used, after the LDS stores,
@@ -1197,8 +1199,9 @@ __global__ __launch_bounds__(NW * 64, (NT >= 8 && NT <= 9) ? 3 : 1) void window_
         }
         if (tid < NP) {
             const int e = tid;
-            const int yj = e / ws, xj = e - yj * ws;
+            const int yj = (int)(((unsigned)e * (65536u / (unsigned)ws + 1u)) >> 16), xj = e - yj * ws;      // e / ws for e < 256, ws <= 16 (exact)
             Kidx[e] = e < N ? yj * (2 * ws - 1) + xj : -T - 3;                // padded keys index the -1e30 area
+          if (rg) {
             uint4 lo, hi;          // 10.0 (bf16 0x4120) at halfword rid_own of 16
             const unsigned hv = (rid_own & 1) ? 0x41200000u : 0x4120u;
             const int hw = rid_own >> 1;
@@ -1210,6 +1213,7 @@ __global__ __launch_bounds__(NW * 64, (NT >= 8 && NT <= 9) ? 3 : 1) void window_
             *(uint4*)(Oh + e * QK_PITCH + ((2 ^ osw) << 4)) = make_uint4(0, 0, 0, 0);
             *(uint4*)(Oh + e * QK_PITCH + ((3 ^ osw) << 4)) = make_uint4(0, 0, 0, 0);
             if (rid_own != rid_first) mixed = 1;
+          }
         }
         mixed = __syncthreads_or(mixed);
     }
@@ -1236,7 +1240,7 @@ __global__ __launch_bounds__(NW * 64, (NT >= 8 && NT <= 9) ? 3 : 1) void window_
         const float* brow = bias ? bias + ((long long)h * NP + query) * NP + qd * 4 : nullptr;
         const float* mrow = mask ? mask + ((long long)(b % nW) * NP + query) * NP + qd * 4 : nullptr;
         const int qq = query < N ? query : 0;
-        const int yi = qq / ws, xi = qq - yi * ws;
+        const int yi = (int)(((unsigned)qq * (65536u / (unsigned)ws + 1u)) >> 16), xi = qq - yi * ws;      // (exact for qq < 256, ws <= 16)
         const int qbase = (yi + ws - 1) * (2 * ws - 1) + xi + ws - 1;
         // table entry qbase - k sits at Tb[2T + 3 - qbase + k]: the 4 consecutive keys of a lane (entries qbase - k0, ... - 3) are 4 ASCENDING floats that land
         // in the accumulator's register order -- read in the table's own order they arrived reversed and cost a v_mov each (36 per query tile)
