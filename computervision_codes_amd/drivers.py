@@ -19,6 +19,11 @@ from . import cholect, extract, featfile
 from .metrics import Recognition, final_report, gather_recognition, recognition_from
 
 
+def extraction_batch(img_size, device_batch):
+    from .spatial_transformer import extraction_batch as f      # (the transformer stage loads on demand)
+    return f(img_size, device_batch)
+
+
 def _common(p: argparse.ArgumentParser):
     p.add_argument("--model", type=str, default="rendezvous")
     p.add_argument("--version", type=str, default="")
@@ -36,7 +41,8 @@ def _common(p: argparse.ArgumentParser):
     p.add_argument("--gpu", type=str, default="0")
     p.add_argument("--seed", type=int, default=47)
     p.add_argument("--dtype", type=str, default="fp32", choices=["fp32", "bf16"])
-    p.add_argument("--device_batch", type=int, default=512, help="frames per extraction pass on the GPU (results do not depend on it)")
+    p.add_argument("--device_batch", type=int, default=584, help="frames per extraction pass on the GPU (results do not depend on it; 584 frames of "
+                   "256 x 448 give layer3 / layer4 whole rounds of 256-row tiles on the 256 CUs)")
     p.add_argument("--decode_workers", type=int, default=8, help="host threads decoding PNGs")
     p.add_argument("--png_decode", type=str, default="host", choices=["host", "device"],
                    help="device: inflate + PNG unfiltering on the GPU (mt4_png_inflate / mt4_png_unfilter_rgb8), the host only reads the files")
@@ -103,7 +109,8 @@ def _spatial_cnn_videos(F, model, vids, labels):
     # of 1024 frames, two in flight on streams of their own (sweep: profiles/r04_png_pipeline_sweep.txt -- 9.7-10.2 k frames/s from 480 x 854 files
     # through ResNet-50; the host reader alone delivers > 100 k files/s, what bounds the loop is inflate time + extractor time, which share the CUs).
     plan = [(v, len(labels[v]["ivt"]), loader(v)) for v in vids]
-    for v, feat, lgs in extract.extract_videos_device(model, plan, F.device_batch, prefetch=2 if dev_dec else 1, load_batch=1024 if dev_dec else None):
+    for v, feat, lgs in extract.extract_videos_device(model, plan, F.device_batch, prefetch=2 if dev_dec else 1,
+                                                          load_batch=(1023 // F.device_batch + 1) * F.device_batch if dev_dec else None):      # (>= 1024 frames per device decode)
         lab = labels[v]
         scores_local[v] = {key: (lab[key][:, 1:], torch.sigmoid(torch.from_numpy(lg)).numpy())       # `test.py:162-169`
                            for key, lg in zip(("i", "v", "t", "ivt"), lgs)}
@@ -483,11 +490,11 @@ def spatial_transformer_test(argv=None) -> Dict[str, np.ndarray]:
         ids_all = labels[v]["ivt"][:, 0]
         # device batches (a frame's feature does not depend on the batch it rides in), decode on --decode_workers threads (or on the device), the
         # video's features stay on the GPU until its end: one D2H per video instead of one synchronous copy per --batch frames (`test.py:357-376`)
-        step = max(1, min(F.device_batch, 256))
+        step = extraction_batch(F.img_size, F.device_batch)
         load = lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.img_size, F.img_size, workers=F.decode_workers,
                                                        decode=F.png_decode)
         dev_dec = F.png_decode == "device"                     # (the device decoder wants >= 1024 frames per call; two loads run ahead)
-        lb = max(step, 1024 // step * step) if dev_dec else step
+        lb = (1023 // step + 1) * step if dev_dec else step
         spans = [(s, min(len(ids_all), s + lb)) for s in range(0, len(ids_all), lb)]
         for span in extract.iter_chunks(spans, load, 2 if dev_dec else 1):      # the next load is decoded while this one runs
             for s in range(0, span.shape[0], step):
@@ -507,7 +514,7 @@ def _q2l_scores(F, model, vids, labels):
     single = F.loss_type != "all"
     for v in vids:
         ids_all = labels[v]["ivt"][:, 0]
-        step = max(1, min(F.device_batch, 256))
+        step = extraction_batch(F.img_size, F.device_batch)
         load = lambda s, e: cholect.load_frames_device(F.data_dir, v, ids_all[s:e], F.img_size, F.img_size, workers=F.decode_workers, decode=F.png_decode)
         spans = [(s, min(len(ids_all), s + step)) for s in range(0, len(ids_all), step)]
         acc = {k: [] for k in ("i", "v", "t", "ivt")}

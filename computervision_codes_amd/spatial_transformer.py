@@ -350,6 +350,13 @@ class Qeruy2Label:
     __call__ = forward
 
 
+def extraction_batch(img_size: int, device_batch: int) -> int:
+    """frames per extraction pass (a frame's features do not depend on it): the GEMMs run 256 x 256 tiles on 256 CUs, and with 227 frames of 384^2 /
+    668 of 224^2 the stage-2 / stage-3 / decoder launches with 2 or 4 column tiles are whole rounds of the chip (at 256 frames of 384^2 they run
+    2.25 rounds: profiles/r04_swin_batch_sweep.txt); capped by --device_batch"""
+    return max(1, min(device_batch, {384: 227, 224: 668}.get(int(img_size), 256)))
+
+
 def build_q2l(args, dtype: torch.dtype = torch.float32, device: str = "cuda") -> Qeruy2Label:
     """`network.py:187-204`"""
     return Qeruy2Label(args, dtype=dtype, device=device)
