@@ -41,8 +41,7 @@ def _common(p: argparse.ArgumentParser):
     p.add_argument("--gpu", type=str, default="0")
     p.add_argument("--seed", type=int, default=47)
     p.add_argument("--dtype", type=str, default="fp32", choices=["fp32", "bf16"])
-    p.add_argument("--device_batch", type=int, default=584, help="frames per extraction pass on the GPU (results do not depend on it; 584 frames of "
-                   "256 x 448 give layer3 / layer4 whole rounds of 256-row tiles on the 256 CUs)")
+    p.add_argument("--device_batch", type=int, default=512, help="frames per extraction pass on the GPU (results do not depend on it)")
     p.add_argument("--decode_workers", type=int, default=8, help="host threads decoding PNGs")
     p.add_argument("--png_decode", type=str, default="host", choices=["host", "device"],
                    help="device: inflate + PNG unfiltering on the GPU (mt4_png_inflate / mt4_png_unfilter_rgb8), the host only reads the files")
