@@ -778,13 +778,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 
     // a tap that leaves the image reads a ROW OF ZEROS instead of the patch: one select on the fragment's LDS address per m-tile and tap.  (Zeroing the
     // fragment itself cost 8 v_and per m-tile and K-step -- with the address arithmetic 2 VALU instructions per MFMA, and on this chip VALU and MFMA
     // issue do not overlap within a SIMD: instruction mix 1344 MFMA x 16 cycles + 2661 VALU x 4 cycles = the wave's lifetime x 1 / 4 waves per SIMD.)
-    // The row: patch row zr = BM + 2W + 2, the first one behind those the taps reach (the host allocates at least one), zero-filled by the staging DMA itself.
+    // The rows: patch rows zr = BM + 2W + 2 and zr + 1, the first ones behind those the taps reach (the host allocates at least two), zero-filled by the
+    // staging DMA itself.  (With ONE zero row every second invalid lane read from the other half of the banks than its regular read would: 18.6 % of the
+    // kernel's LDS cycles were conflicts against 2.2 % with the masked fragments.)
     auto compute = [&](const char* pb, const char* wb, int toff, int tap) {
         const int prow = wave_m * WM + r16 + toff;
         const int tbit = 1 << tap;
         const char* xr[MT];
 #pragma unroll
-        for (int j = 0; j < MT; ++j) xr[j] = pb + ((vm[j] & tbit) ? prow + j * 16 : zr) * 128;
+        for (int j = 0; j < MT; ++j) xr[j] = pb + ((vm[j] & tbit) ? prow + j * 16 : zr + ((prow ^ zr) & 1)) * 128;   // (the zero row of the lane's own parity:
+                                                                                                                        //  rows are 128 B = half the banks, so the read keeps the bank set of the read it replaces)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int swx = ((kk * 4 + q) ^ (prow & 7)) << 4;     // (any swizzle of the zero row reads zeros)
@@ -1571,7 +1574,7 @@ int launch_patch3x3(const ConvK& k, hipStream_t s) {
     }
     constexpr int threads = WM_ * WN_ * 64;
     constexpr int rpp = threads / 8;
-    const int pra = (BM + 2 * k.W + 2 + 1 + 7) / 8 * 8;      // + 1: the row of zeros out-of-image taps read
+    const int pra = (BM + 2 * k.W + 2 + 2 + 7) / 8 * 8;      // + 2: the rows of zeros out-of-image taps read
     const int npatch = k.SPT > 1 ? 2 : 1;
     constexpr int epi = BM / (BN >= 256 ? 4 : 2) * (BN * 4 + 16);
     int lds = npatch * pra * 128 + WS * BN * 128;
