@@ -1355,13 +1355,15 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
     }
     __syncthreads();   // the conv rows go over the operands
 
-    // conv tile: pixel (row, column - cs0) at (row * ctw + col) * 128 B, 16-byte chunks XOR-swizzled with col & 7 (columns the pooling does not
+    // conv tile: pixel (row, column - cs0) at (row * ctw + col) * 128 B, 16-byte chunks XOR-swizzled with (col >> 1) & 7 -- a 128-byte row is half the
+    // banks, so columns of one parity share a bank half: the pooling window reads columns 2 apart (one parity per read), and keyed with col & 7
+    // those took 4 of the 8 chunk positions (2-way conflicts: 24 % of the kernel's LDS cycles) (columns the pooling does not
     // read are dropped: the wide form stays under 80 KB = two workgroups per CU)
     int wr_lane[NT];      // lane part of the address (a tile's first column is a multiple of 16: (col & 7) == (r16 & 7))
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int cb = (wave_n * 32 + i * 16 + q * 4) * 2;
-        wr_lane[i] = r16 * 128 + (((cb >> 4) ^ (r16 & 7)) << 4) + (cb & 8);
+        wr_lane[i] = r16 * 128 + (((cb >> 4) ^ ((r16 >> 1) & 7)) << 4) + (cb & 8);
     }
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
@@ -1392,7 +1394,7 @@ __global__ __launch_bounds__(512, 4) void stem_pool_kernel(const StemPoolK a) {
             const int jr = min(max(2 * pr + k, -c0), a.Ho - 1 - c0);          // conv row c0 + jr in [0, Ho)
             roff[k] = jr * a.ctw * 128;
             const int cr = min(max(2 * pc - 1 + k, 0), a.Wo - 1) - cs0;       // column inside the segment
-            coff[k] = cr * 128 + ((c8 ^ (cr & 7)) << 4);
+            coff[k] = cr * 128 + ((c8 ^ ((cr >> 1) & 7)) << 4);
         }
         uint4 best = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
