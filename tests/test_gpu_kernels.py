@@ -366,7 +366,7 @@ def test_conv3x3_expand_bit_identical_to_two_launches(cuda, b, h, w):
     assert small is None          # few tiles: the caller runs the two launches
 
 
-@pytest.mark.parametrize("b,h,w", [(2, 224, 224), (3, 6, 10), (1, 2, 2), (2, 32, 34)])
+@pytest.mark.parametrize("b,h,w", [(2, 224, 224), (3, 6, 10), (1, 2, 2), (2, 32, 34), (2, 256, 448)])
 def test_preprocess_u8_s2d_matches_torch(cuda, b, h, w):
     """`mt4_preprocess_u8_s2d` (ToTensor + Normalize of `Spatial_cnn/dataloader.py:153-162`, 3-pixel zero padding, 2 x 2 space-to-depth) against the
     same arithmetic in torch, bit for bit -- every border column and row (the kernel reads pixel pairs with clamped addresses)"""
